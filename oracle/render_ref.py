@@ -1,0 +1,224 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU restatement of the camera/projection/silhouette arithmetic behind the reference's
+``Renderer`` (smal_fitter/p3d_renderer.py:27-152).  The arithmetic itself lives in the
+un-vendored third-party ``pytorch3d`` (pinned 0.7.8, environment.yml:35) - this restates the
+published algorithm of ``FoVPerspectiveCameras`` / ``look_at_view_transform`` /
+``transform_points_screen`` / ``MeshRasterizer.transform`` and binds the C restatement of the
+naive rasteriser (oracle/raster_oracle.c).  PARITY UNPINNED by reference-owned vectors; pinned
+by analytic known-answer tests only (tests/test_oracle_raster.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SIGMA = 1e-4
+BLUR_RADIUS = float(np.log(1.0 / 1e-4 - 1.0) * SIGMA)  # p3d_renderer.py:44
+FACES_PER_PIXEL = 100  # p3d_renderer.py:45
+ZNEAR, ZFAR = 0.001, 1000.0  # p3d_renderer.py:24-25
+
+
+def build_oracle_lib() -> str:
+    so = os.path.join(_HERE, "_build", "libraster_oracle.so")
+    src = os.path.join(_HERE, "raster_oracle.c")
+    if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        lib = ctypes.CDLL(build_oracle_lib())
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        lib.oracle_silhouette_forward.argtypes = [fp, ip] + [ctypes.c_int] * 4 + [ctypes.c_float] * 2 + [
+            ctypes.c_int, fp, ip, ip, fp, fp]
+        lib.oracle_silhouette_forward.restype = ctypes.c_int
+        lib.oracle_silhouette_backward.argtypes = [fp, ip] + [ctypes.c_int] * 4 + [ctypes.c_float] * 2 + [
+            ctypes.c_int, fp, fp]
+        lib.oracle_silhouette_backward.restype = ctypes.c_int
+        lib.oracle_num_threads.restype = ctypes.c_int
+        _LIB = lib
+    return _LIB
+
+
+def num_threads() -> int:
+    return int(_lib().oracle_num_threads())
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def silhouette_forward_np(verts_ndc, faces, S, blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL,
+                          want_fragments=False):
+    verts_ndc = np.ascontiguousarray(verts_ndc, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    N, V, _ = verts_ndc.shape
+    F = faces.shape[0]
+    sil = np.empty((N, S, S), np.float32)
+    ncand = np.empty((N, S, S), np.int32)
+    null_i = ctypes.POINTER(ctypes.c_int32)()
+    null_f = ctypes.POINTER(ctypes.c_float)()
+    if want_fragments:
+        ff = np.empty((N, S, S, K), np.int32)
+        fd = np.empty((N, S, S, K), np.float32)
+        fz = np.empty((N, S, S, K), np.float32)
+        rc = _lib().oracle_silhouette_forward(_fp(verts_ndc), _ip(faces), N, V, F, S, blur, sigma, K,
+                                              _fp(sil), _ip(ncand), _ip(ff), _fp(fd), _fp(fz))
+        assert rc == 0
+        return sil, ncand, ff, fd, fz
+    rc = _lib().oracle_silhouette_forward(_fp(verts_ndc), _ip(faces), N, V, F, S, blur, sigma, K,
+                                          _fp(sil), _ip(ncand), null_i, null_f, null_f)
+    assert rc == 0
+    return sil, ncand
+
+
+def silhouette_backward_np(verts_ndc, faces, S, grad_sil, blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL):
+    verts_ndc = np.ascontiguousarray(verts_ndc, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    grad_sil = np.ascontiguousarray(grad_sil, np.float32)
+    N, V, _ = verts_ndc.shape
+    gv = np.empty((N, V, 3), np.float32)
+    rc = _lib().oracle_silhouette_backward(_fp(verts_ndc), _ip(faces), N, V, faces.shape[0], S, blur, sigma, K,
+                                           _fp(grad_sil), _fp(gv))
+    assert rc == 0
+    return gv
+
+
+class SoftSilhouette(torch.autograd.Function):
+    """verts_ndc (N,V,3) -> silhouette (N,S,S), differentiable wrt the xy of verts_ndc."""
+
+    @staticmethod
+    def forward(ctx, verts_ndc, faces, S, blur, sigma, K):
+        sil, _ = silhouette_forward_np(verts_ndc.detach().numpy(), faces.numpy(), S, blur, sigma, K)
+        ctx.save_for_backward(verts_ndc.detach(), faces)
+        ctx.cfg = (S, blur, sigma, K)
+        return torch.from_numpy(sil)
+
+    @staticmethod
+    def backward(ctx, grad_sil):
+        verts_ndc, faces = ctx.saved_tensors
+        S, blur, sigma, K = ctx.cfg
+        gv = silhouette_backward_np(verts_ndc.numpy(), faces.numpy(), S, grad_sil.contiguous().numpy(),
+                                    blur, sigma, K)
+        return torch.from_numpy(gv), None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# cameras (pytorch3d.renderer.cameras restated)
+# --------------------------------------------------------------------------------------
+def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees=True):
+    """R (n,3,3), T (n,3) of a camera looking at the origin, up = +y (pytorch3d convention:
+    X_view = X_world @ R + T).  Default Renderer camera: dist 2.7, elev 0, azim 0
+    (p3d_renderer.py:34) -> R = diag(-1,1,-1), T = (0,0,2.7)."""
+    dist = torch.as_tensor(dist, dtype=torch.float32).reshape(-1)
+    elev = torch.as_tensor(elev, dtype=torch.float32).reshape(-1)
+    azim = torch.as_tensor(azim, dtype=torch.float32).reshape(-1)
+    n = max(dist.numel(), elev.numel(), azim.numel())
+    dist, elev, azim = dist.expand(n), elev.expand(n), azim.expand(n)
+    if degrees:
+        elev = elev * (math.pi / 180.0)
+        azim = azim * (math.pi / 180.0)
+    x = dist * torch.cos(elev) * torch.sin(azim)
+    y = dist * torch.sin(elev)
+    z = dist * torch.cos(elev) * torch.cos(azim)
+    C = torch.stack([x, y, z], dim=1)  # camera centre in world coordinates
+    at = torch.zeros_like(C)
+    up = torch.tensor([0.0, 1.0, 0.0]).expand(n, 3)
+    z_axis = torch.nn.functional.normalize(at - C, eps=1e-5)
+    x_axis = torch.nn.functional.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = torch.nn.functional.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    is_close = torch.isclose(x_axis, torch.tensor(0.0), atol=5e-3).all(dim=1, keepdim=True)
+    if is_close.any():
+        replacement = torch.nn.functional.normalize(torch.cross(y_axis, z_axis, dim=1), eps=1e-5)
+        x_axis = torch.where(is_close, replacement, x_axis)
+    R = torch.cat((x_axis[:, None, :], y_axis[:, None, :], z_axis[:, None, :]), dim=1).transpose(1, 2)
+    T = -torch.bmm(R.transpose(1, 2), C[:, :, None])[:, :, 0]
+    return R, T
+
+
+def _tan_half_fov(fov_deg: torch.Tensor) -> torch.Tensor:
+    return torch.tan((fov_deg * (math.pi / 180.0)) / 2)
+
+
+def project_to_ndc(points: torch.Tensor, R, T, fov_deg, aspect=None):
+    """points (N,P,3) world -> (x_ndc, y_ndc, z_view) (N,P,3).  ``MeshRasterizer.transform``:
+    view transform first, then K00 = 1/(aspect tan), K11 = 1/tan, divide by view z."""
+    fov_deg = fov_deg.reshape(-1)
+    t = _tan_half_fov(fov_deg)
+    a = torch.ones_like(t) if aspect is None else aspect.reshape(-1)
+    view = torch.matmul(points, R) + T[:, None, :]
+    # K built as 2 znear / (max - min) like compute_projection_matrix
+    max_y = t * ZNEAR
+    max_x = max_y * a
+    k00 = 2.0 * ZNEAR / (max_x - (-max_x))
+    k11 = 2.0 * ZNEAR / (max_y - (-max_y))
+    z = view[..., 2]
+    x = view[..., 0] * k00[:, None] / z
+    y = view[..., 1] * k11[:, None] / z
+    return torch.stack([x, y, z], dim=-1)
+
+
+def project_points_screen(points, R, T, fov_deg, S: int, aspect=None):
+    """``cameras.transform_points_screen(points)[..., [1,0]]`` (p3d_renderer.py:137): returns
+    (y_s, x_s) pixels with x_s = S/2 - (S/2) x_ndc."""
+    ndc = project_to_ndc(points, R, T, fov_deg, aspect)
+    xs = S / 2.0 - (S / 2.0) * ndc[..., 0]
+    ys = S / 2.0 - (S / 2.0) * ndc[..., 1]
+    return torch.stack([ys, xs], dim=-1)
+
+
+def render_silhouette(verts, faces, R, T, fov_deg, S: int, aspect=None, blur=BLUR_RADIUS, sigma=SIGMA,
+                      K=FACES_PER_PIXEL):
+    """verts (N,V,3) world, one camera per image -> (N,1,S,S) soft silhouette."""
+    ndc = project_to_ndc(verts, R, T, fov_deg, aspect)
+    return SoftSilhouette.apply(ndc, faces.to(torch.int32), S, blur, sigma, K)[:, None]
+
+
+class OracleRenderer:
+    """Callable with the reference Renderer's forward signature (p3d_renderer.py:127)."""
+
+    def __init__(self, image_size: int, R=None, T=None, fov=None, aspect=None):
+        self.image_size = image_size
+        if R is None:
+            R, T = look_at_view_transform(2.7, 0.0, 0.0)
+        self.R, self.T = R, T
+        self.fov = torch.tensor([60.0]) if fov is None else fov
+        self.aspect = aspect
+
+    def _expand(self, n):
+        R = self.R.expand(n, 3, 3) if self.R.shape[0] != n else self.R
+        T = self.T.expand(n, 3) if self.T.shape[0] != n else self.T
+        fov = self.fov.reshape(-1)
+        fov = fov.expand(n) if fov.shape[0] != n else fov
+        a = self.aspect
+        if a is not None:
+            a = a.reshape(-1)
+            a = a.expand(n) if a.shape[0] != n else a
+        return R, T, fov, a
+
+    def __call__(self, vertices, points, faces, joints_only=False):
+        n = vertices.shape[0]
+        R, T, fov, a = self._expand(n)
+        proj = project_points_screen(points.float(), R, T, fov, self.image_size, a)
+        if joints_only:
+            return None, proj
+        f = faces[0] if faces.dim() == 3 else faces
+        sil = render_silhouette(vertices.float(), f, R, T, fov, self.image_size, a)
+        return sil, proj

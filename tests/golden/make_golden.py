@@ -1,0 +1,240 @@
+"""Generate golden vectors by running the REAL reference code (build container only).
+
+Run from the repo root:   python tests/golden/make_golden.py
+
+* imports ``/root/reference/smal_model`` and ``smal_fitter.fitter`` with a stub ``config``
+  module and import stubs for third-party packages that are absent here (cv2, nibabel,
+  pytorch3d - names only; recipe: SURVEY.md Appendix C),
+* converts the present model pickles to flat tables under ``data/models/*.npz``,
+* writes ``tests/golden/lbs_<model>.npz`` (batch_rodrigues, batch_global_rigid_transformation,
+  SMAL.__call__ outputs + autograd gradients) and ``tests/golden/fitter_<model>.npz``
+  (SMALFitter.forward loss terms + gradients, with the renderer replaced by the oracle's
+  restatement, because pytorch3d is not installed).
+
+Only inputs and outputs are stored - no reference source travels.  The GPU box never runs this.
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from smilify_amd import model_io  # noqa: E402
+from oracle import render_ref  # noqa: E402
+
+MODELS = {
+    "stick": os.path.join(REF, "3D_model_prep", "SMILy_STICK.pkl"),
+    "mouse": os.path.join(REF, "3D_model_prep", "SMILy_Mouse_static_joints.pkl"),
+}
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def vertex_probe(shape, k):
+    """Deterministic pseudo-random cotangent, reproducible from indices alone."""
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.cos(0.37 * np.arange(n) * (k + 1) + k).astype(np.float32).reshape(shape))
+
+
+def install_stubs(pkl_path):
+    dd = model_io.read_model_pickle(pkl_path)
+    cfg = types.ModuleType("config")
+    cfg.SMAL_FILE = pkl_path
+    cfg.dd = dd
+    cfg.DEBUG = False
+    cfg.ignore_sym = True
+    cfg.ignore_hardcoded_body = True
+    cfg.ALLOW_LIMB_SCALING = True
+    cfg.STATIC_JOINT_LOCATIONS = bool(dd.get("static_joint_locs", False))
+    cfg.joint_names = dd["J_names"]
+    cfg.N_POSE = len(dd["J_names"]) - 1
+    cfg.N_BETAS = dd["shapedirs"].shape[2]
+    cfg.CANONICAL_MODEL_JOINTS = list(range(len(dd["J_names"])))
+    cfg.MESH_COLOR = [0, 172, 223]
+    cfg.MARKER_TYPE = [0] * len(dd["J_names"])
+    cfg.MARKER_COLORS = [[0, 0, 0]] * len(dd["J_names"])
+    sys.modules["config"] = cfg
+
+    cv2 = types.ModuleType("cv2")
+    cv2.MARKER_STAR = 0
+    sys.modules["cv2"] = cv2
+
+    nib = types.ModuleType("nibabel")
+    eul = types.ModuleType("nibabel.eulerangles")
+
+    def euler2angle_axis(z=0, y=0, x=0):
+        # nibabel.eulerangles: euler2quat then quat2angle_axis (published formulas)
+        z, y, x = z / 2.0, y / 2.0, x / 2.0
+        cz, sz, cy, sy, cx, sx = math.cos(z), math.sin(z), math.cos(y), math.sin(y), math.cos(x), math.sin(x)
+        q = np.array([cx * cy * cz - sx * sy * sz, cx * sy * sz + cy * cz * sx,
+                      cx * cz * sy - sx * cy * sz, cx * cy * sz + sx * cz * sy])
+        w, v = q[0], q[1:]
+        n = np.linalg.norm(v)
+        if n < 1e-12:
+            return 0.0, np.array([1.0, 0, 0])
+        return 2 * math.acos(max(-1, min(1, w))), v / n
+
+    eul.euler2angle_axis = euler2angle_axis
+    nib.eulerangles = eul
+    sys.modules["nibabel"] = nib
+    sys.modules["nibabel.eulerangles"] = eul
+
+    p3d = types.ModuleType("pytorch3d")
+    p3r = types.ModuleType("pytorch3d.renderer")
+    p3s = types.ModuleType("pytorch3d.structures")
+    for name in ["look_at_view_transform", "RasterizationSettings", "MeshRenderer", "MeshRasterizer", "BlendParams",
+                 "PointLights", "HardPhongShader", "SoftSilhouetteShader", "Textures", "FoVPerspectiveCameras"]:
+        setattr(p3r, name, None)
+    p3s.Meshes = None
+    sys.modules["pytorch3d"] = p3d
+    sys.modules["pytorch3d.renderer"] = p3r
+    sys.modules["pytorch3d.structures"] = p3s
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k.startswith("smal_model") or k.startswith("smal_fitter")]:
+        del sys.modules[m]
+    return cfg, dd
+
+
+def lbs_goldens(key, pkl_path):
+    cfg, dd = install_stubs(pkl_path)
+    from smal_model import batch_lbs
+    from smal_model.smal_torch import SMAL
+
+    smal = SMAL("cpu")
+    J = smal.J_regressor.shape[1]
+    nB = smal.num_betas
+    g = torch.Generator().manual_seed(20240 + len(key))
+    out = {}
+
+    # (i) batch_rodrigues
+    th = torch.cat([torch.zeros(2, 3), torch.full((1, 3), 1e-9), 0.15 * torch.randn(8, 3, generator=g),
+                    torch.randn(8, 3, generator=g), 3.0 * torch.randn(8, 3, generator=g)])
+    out["rod_theta"] = th.numpy()
+    out["rod_R"] = batch_lbs.batch_rodrigues(th).numpy()
+
+    # (ii) chain with / without scale, trans, propagate
+    B = 3
+    Rs = batch_lbs.batch_rodrigues((0.4 * torch.randn(B * J, 3, generator=g))).view(B, J, 3, 3)
+    Js = torch.randn(B, J, 3, generator=g)
+    ls = 0.2 * torch.randn(B, J, 3, generator=g)
+    bt = 0.1 * torch.randn(B, J, 3, generator=g)
+    out["chain_Rs"], out["chain_Js"], out["chain_ls"], out["chain_bt"] = Rs.numpy(), Js.numpy(), ls.numpy(), bt.numpy()
+    for tag, kw in [("plain", {}), ("scale", dict(betas_logscale=ls)), ("scale_trans", dict(betas_logscale=ls, betas_trans=bt)),
+                    ("prop", dict(betas_logscale=ls, betas_trans=bt, propagate_scaling=True))]:
+        nj, A = batch_lbs.batch_global_rigid_transformation(Rs, Js, smal.parents, num_joints=J, **kw)
+        out[f"chain_{tag}_newJ"], out[f"chain_{tag}_A"] = nj.numpy(), A.numpy()
+
+    # (iii) SMAL.__call__ + gradients
+    B = 4
+    beta = (0.5 * torch.randn(B, nB, generator=g)).requires_grad_()
+    theta = (0.3 * torch.randn(B, J, 3, generator=g))
+    theta[0] = 0.0  # exact zero pose exercises the 1e-8 quirk
+    theta.requires_grad_()
+    trans = (0.1 * torch.randn(B, 3, generator=g)).requires_grad_()
+    ls = (0.1 * torch.randn(B, J, 3, generator=g)).requires_grad_()
+    bt = (0.05 * torch.randn(B, J, 3, generator=g)).requires_grad_()
+    verts, joints, Rs_o, v_shaped = smal(beta, theta, trans=trans, betas_logscale=ls, betas_trans=bt)
+    loss = (verts * vertex_probe(verts.shape, 0)).sum() + (joints * vertex_probe(joints.shape, 1)).sum()
+    loss.backward()
+    for n, t in [("beta", beta), ("theta", theta), ("trans", trans), ("ls", ls), ("bt", bt)]:
+        out[f"smal_{n}"] = t.detach().numpy()
+        out[f"smal_grad_{n}"] = t.grad.numpy()
+    out["smal_verts"], out["smal_joints"] = verts.detach().numpy(), joints.detach().numpy()
+    out["smal_Rs"], out["smal_v_shaped"] = Rs_o.detach().numpy(), v_shaped.detach().numpy()
+    out["smal_J_transformed"] = smal.J_transformed.detach().numpy()
+    out["smal_loss"] = np.float32(loss.item())
+
+    # (iii-b) the reference test-suite fixture (tests/test_triangulation_consistency.py:209-216)
+    torch.manual_seed(42)
+    betas0 = torch.zeros(2, nB)
+    theta0 = torch.randn(2, J, 3) * 0.15
+    theta0[:, 0, :] = 0.0
+    _, joints0, _, _ = smal(betas0, theta0)
+    out["fixture_theta"], out["fixture_joints"] = theta0.numpy(), joints0.numpy()
+
+    # (iii-c) shared betas, no scale/trans args (None path)
+    verts1, joints1, _, _ = smal(beta.detach()[:1].expand(2, nB), theta.detach()[1:3])
+    out["plain_verts"], out["plain_joints"] = verts1.numpy(), joints1.numpy()
+    np.savez_compressed(os.path.join(OUT, f"lbs_{key}.npz"), **out)
+    print(f"lbs_{key}: J={J} nB={nB} loss={loss.item():.6f}")
+
+
+def fitter_goldens(key, pkl_path, S=64, N=3):
+    cfg, dd = install_stubs(pkl_path)
+    import smal_fitter.fitter as ref_fitter
+
+    J = len(dd["J_names"])
+    g = torch.Generator().manual_seed(777 + len(key))
+    dist = 2.7 if key == "stick" else 4.0
+    R, T = render_ref.look_at_view_transform(dist, 10.0, torch.tensor([0.0, 40.0, -30.0])[:N])
+
+    class _Cams:
+        pass
+
+    class FakeRenderer(torch.nn.Module):
+        """Reference-shaped renderer whose arithmetic is the oracle restatement."""
+
+        def __init__(self, image_size, device):
+            super().__init__()
+            self.image_size = image_size
+            self.cameras = _Cams()
+            self.cameras.fov = torch.full((N,), 60.0)
+
+        def forward(self, vertices, points, faces, render_texture=False, joints_only=False):
+            r = render_ref.OracleRenderer(self.image_size, R, T, self.cameras.fov)
+            return r(vertices, points, faces, joints_only=joints_only)
+
+    ref_fitter.Renderer = FakeRenderer
+    rgb = torch.zeros(N, 3, S, S)
+    sil_t = (torch.rand(N, 1, S, S, generator=g) > 0.5).float()
+    tj = torch.rand(N, J, 2, generator=g) * S
+    vis = (torch.rand(N, J, generator=g) > 0.25).long()
+    fitter = ref_fitter.SMALFitter("cpu", (rgb, sil_t, tj.clone(), vis.clone()), N, -1, False)
+    with torch.no_grad():
+        fitter.global_rotation += 0.05 * torch.randn(N, 3, generator=g)
+        fitter.joint_rotations += 0.08 * torch.randn(N, J - 1, 3, generator=g)
+        fitter.trans += 0.05 * torch.randn(N, 3, generator=g)
+        fitter.betas += 0.3 * torch.randn(fitter.betas.shape, generator=g)
+        fitter.log_beta_scales += 0.05 * torch.randn(N, J, 3, generator=g)
+        fitter.betas_trans += 0.02 * torch.randn(N, J, 3, generator=g)
+    fitter.log_beta_scales.requires_grad = True
+    fitter.betas_trans.requires_grad = True
+    out = dict(S=np.int32(S), R=R.numpy(), T=T.numpy(), sil_target=sil_t.numpy(), target_joints=tj.numpy(),
+               visibility=vis.numpy(), mean_betas=fitter.mean_betas.numpy(), betas_prec=fitter.betas_prec.numpy(),
+               init_global_rotation=ref_fitter.eul_to_axis(np.array([-np.pi / 2, 0, -np.pi / 2])).astype(np.float32))
+    for n, p in fitter.named_parameters():
+        out[f"param_{n}"] = p.detach().numpy().copy()
+    weights = [25.0, 500.0, 1.0, 1.0, 100.0, 0.1]
+    out["weights"] = np.array(weights, np.float32)
+    loss, objs = fitter(list(range(N)), weights, 1)
+    jl, gl, tl = fitter.get_temporal(100.0)
+    total = loss.mean() + jl + gl + tl
+    total.backward()
+    for k, v in objs.items():
+        out[f"obj_{k}"] = np.float32(v.item())
+    out["loss"] = np.float32(loss.item())
+    out["temporal"] = np.array([jl.item(), gl.item(), tl.item()], np.float32)
+    for n, p in fitter.named_parameters():
+        out[f"grad_{n}"] = p.grad.numpy().copy() if p.grad is not None else np.zeros_like(p.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, f"fitter_{key}.npz"), **out)
+    print(f"fitter_{key}: loss={loss.item():.6f}", {k: round(v.item(), 6) for k, v in objs.items()})
+
+
+def main():
+    os.makedirs(os.path.join(REPO, "data", "models"), exist_ok=True)
+    for key, p in MODELS.items():
+        t = model_io.load_model(p)
+        t.save_npz(os.path.join(REPO, "data", "models", os.path.basename(p).replace(".pkl", ".npz")))
+        print("converted", p, "V", t.V, "F", t.F, "J", t.J, "nB", t.nB)
+        lbs_goldens(key, p)
+        fitter_goldens(key, p, S=64 if key == "stick" else 48)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+/*
+ * libsmilfit - C ABI of the MI355X-native SMIL fitting inner loop.
+ *
+ * The reference (FabianPlum/SMILify) has no FFI boundary for this path: the path is three
+ * Python classes over torch + pytorch3d.  This header is the boundary a binding would use
+ * instead; every entry point names the reference code it replaces.  All pointers are DEVICE
+ * pointers unless marked "host"; all arrays are dense, row-major fp32 / int32; `stream` is a
+ * hipStream_t passed as void*.  Every function returns 0 on success or a negative SMIL_E_*
+ * code (message via smil_last_error()); nothing throws, nothing synchronises the device,
+ * nothing allocates after smil_model_create() - the caller owns every buffer.
+ */
+#ifndef SMILFIT_H_
+#define SMILFIT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMIL_OK 0
+#define SMIL_E_INVALID (-1)  /* bad argument / shape */
+#define SMIL_E_DEVICE (-2)   /* HIP runtime error */
+#define SMIL_E_UNSUPPORTED (-3)
+
+#define SMIL_MAX_BONES 4     /* bones per vertex in the skin table */
+#define SMIL_MAX_JOINTS 256
+#define SMIL_MAX_BETAS 64
+#define SMIL_MAX_FACES_PER_PIXEL 128
+
+typedef struct SmilModel SmilModel; /* opaque: device-resident model constants */
+
+/* Host-side description of a model.  Replaces the buffers built in SMAL.__init__
+ * (reference smal_model/smal_torch.py:104-196).  All pointers are HOST pointers. */
+typedef struct {
+    int32_t V, F, J, nB;
+    const float *v_template;    /* (V,3) */
+    const float *shapedirs;     /* (nB,3V), inner index v*3+c */
+    const int32_t *faces;       /* (F,3) */
+    const int32_t *parents;     /* (J,), parents[0] = -1, parents[i] < i */
+    const int32_t *skin_idx;    /* (V,4) bone ids (padding: id 0, weight 0) */
+    const float *skin_w;        /* (V,4) */
+    const int32_t *jreg_rowptr; /* (J+1,) joint regressor, CSR by joint */
+    const int32_t *jreg_col;    /* (nnz,) vertex ids */
+    const float *jreg_val;      /* (nnz,) */
+    int32_t static_joints;      /* config.STATIC_JOINT_LOCATIONS (smal_torch.py:175,257,343) */
+    const float *J_static;      /* (J,3) when static_joints */
+} SmilModelDesc;
+
+int smil_model_create(const SmilModelDesc *desc, SmilModel **out);
+void smil_model_destroy(SmilModel *m);
+int smil_model_dims(const SmilModel *m, int32_t dims[4]); /* V,F,J,nB */
+const char *smil_last_error(void);
+const char *smil_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear blend skinning.  Replaces SMAL.__call__ (smal_torch.py:198-370) including
+ * batch_rodrigues (batch_lbs.py:31-50) and batch_global_rigid_transformation (batch_lbs.py:75-197).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B;
+    int32_t shared_beta;        /* 1: beta is one (nB_used,) row used by every frame */
+    int32_t nB_used;            /* beta.shape[1] in the reference call (<= nB) */
+    const float *beta;          /* (B,nB_used) or (nB_used,) */
+    const float *theta;         /* (B,J,3) axis-angle, or NULL when Rs_in is given */
+    const float *Rs_in;         /* (B,J,3,3) rotation matrices passed directly (smal_torch.py:288) */
+    const float *logscale;      /* betas_logscale (B,J,3) / (J,3) / NULL */
+    int32_t logscale_shared;    /* 1: one (J,3) table for every frame */
+    const float *btrans;        /* betas_trans, same conventions */
+    int32_t btrans_shared;
+    const float *trans;         /* (B,3) or NULL */
+    const float *del_v;         /* (B,V,3) or NULL */
+    const float *v_template;    /* (V,3) override or NULL */
+    int32_t propagate_scaling;  /* batch_lbs.py:163-168 */
+    int32_t allow_limb_scaling; /* config.ALLOW_LIMB_SCALING (batch_lbs.py:123) */
+} SmilLbsInputs;
+
+typedef struct {
+    float *v_shaped; /* (nS,V,3); nS = 1 when shared_beta && !del_v, else B */
+    float *J_rest;   /* (nS,J,3) rest joints */
+    float *Rs;       /* (B,J,3,3) */
+    float *G;        /* (B,J,3,4) world transforms, saved for backward */
+    float *A;        /* (B,J,3,4) relative skinning transforms */
+    float *new_J;    /* (B,J,3) = SMAL.J_transformed */
+    float *verts;    /* (B,V,3) */
+    float *joints;   /* (B,J,3) */
+} SmilLbsOutputs;
+
+int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, void *stream);
+
+typedef struct {
+    const float *d_verts;  /* (B,V,3) upstream gradient or NULL */
+    const float *d_joints; /* (B,J,3) upstream gradient or NULL */
+    float *d_beta;         /* (B,nB_used) or (nB_used,); NULL to skip */
+    float *d_theta;        /* (B,J,3); NULL to skip (ignored when Rs_in was used) */
+    float *d_logscale;     /* (B,J,3) or (J,3) when shared; NULL to skip */
+    float *d_btrans;       /* same */
+    float *d_trans;        /* (B,3); NULL to skip */
+    /* scratch owned by the caller */
+    float *d_A;            /* (B,J,3,4) */
+    float *d_Jrest;        /* (B,J,3) */
+    float *d_Rs;           /* (B,J,3,3) */
+} SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
+                              logscale_shared, btrans_shared) receive the sum over frames */
+
+int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *saved,
+                      const SmilLbsGrads *g, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cameras + projection.  Replaces FoVPerspectiveCameras as configured by Renderer
+ * (p3d_renderer.py:34-38,112-120) and transform_points_screen(...)[..., [1,0]] (:137).
+ * Image n = frame * views + view.  A table with k rows is indexed n % k (k = 1, views or N).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N;          /* images = frames * views */
+    int32_t views;      /* views per frame (>= 1) */
+    int32_t S;          /* square image side */
+    const float *R;     /* (nR,3,3) row-vector convention: X_view = X_world R + T */
+    int32_t nR;
+    const float *T;     /* (nT,3) */
+    int32_t nT;
+    const float *fov;   /* (nFov,) degrees */
+    int32_t nFov;
+    const float *aspect; /* (nAspect,) or NULL = 1 */
+    int32_t nAspect;
+} SmilCameras;
+
+/* pts (frames,P,3) world -> ndc (N,P,3) = (x_ndc, y_ndc, z_view); yx (N,P,2) = (y_s, x_s) px. Either
+ * output may be NULL. */
+int smil_project(const SmilCameras *cam, const float *pts, int32_t P, float *ndc, float *yx, void *stream);
+
+/* Backward of smil_project.  d_ndc (N,P,2) and/or d_yx (N,P,2) -> d_pts (frames,P,3) (summed over
+ * views; overwritten unless accumulate) and d_fov_img (N,): per-image raw sums
+ * sum_p (d x_ndc * x_ndc + d y_ndc * y_ndc), ATOMICALLY ADDED (caller zeroes once, then may call this for
+ * several point sets).  smil_fov_reduce turns them into d_fov (nFov,), overwritten. */
+int smil_project_backward(const SmilCameras *cam, const float *pts, int32_t P, const float *d_ndc,
+                          const float *d_yx, float *d_pts, float *d_fov_img, int32_t accumulate, void *stream);
+int smil_fov_reduce(const SmilCameras *cam, const float *d_fov_img, float *d_fov, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Soft silhouette.  Replaces MeshRasterizer(naive, K faces per pixel, blur) + SoftSilhouetteShader
+ * (p3d_renderer.py:41-52,142-146; arithmetic in un-vendored pytorch3d 0.7.8).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float blur_radius;        /* NDC^2; reference: log(1/1e-4 - 1) * 1e-4 */
+    float sigma;              /* 1e-4 */
+    int32_t faces_per_pixel;  /* K = 100 */
+    float z_clip;             /* znear / 2 = 5e-4 */
+} SmilRasterSettings;
+
+size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
+
+/* verts_ndc (N,V,3) -> sil (N,S,S) */
+int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
+                            const SmilRasterSettings *rs, float *sil, void *workspace, void *stream);
+/* grad_sil (N,S,S) -> d_ndc (N,V,2) (overwritten) */
+int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
+                             const SmilRasterSettings *rs, const float *grad_sil, float *d_ndc,
+                             void *workspace, void *stream);
+/* Fused forward + L1 against a target + backward, no silhouette materialised (SMALFitter path,
+ * fitter.py:332-333): loss_img[n] = sum_px |sil - target|, d_ndc (N,V,2) = d(sum_n pix_scale[n] *
+ * loss_img[n]) / d ndc.  target_sum[n] = sum_px target (constant, computed once by the caller) lets
+ * untouched tiles skip their target read.  sil_out may be NULL. */
+int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
+                             const SmilRasterSettings *rs, const float *target, const float *target_sum,
+                             const float *pix_scale, float *loss_img, float *d_ndc, float *sil_out,
+                             void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Priors / joint loss / temporal / Adam.  Replaces the loss block of SMALFitter.forward
+ * (fitter.py:292-333), get_temporal (:337-350) and the Adam step of optimize_to_joints.py:117-175.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N;            /* frames held by this rank */
+    int32_t J;            /* joints incl. root */
+    int32_t nB;
+    int32_t window;       /* config.WINDOW_SIZE: losses are means per window, summed over windows */
+    int32_t frame0;       /* global index of local frame 0 (multi-GPU shard offset) */
+    int32_t N_total;      /* frames of the whole sequence */
+    float w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay, w_temp;
+    float limit;          /* joint limit half-width (0.01) */
+} SmilFitConfig;
+
+/* objs is a 10-float accumulator, every entry ADDED to (caller zeroes once per iteration):
+ * [0] joint  [1] limit  [2] pose  [3] splay  [4] betas  [5] sil_reproj
+ * [6] temporal joint-rotations  [7] temporal global-rotation  [8] temporal translation  [9] unused */
+#define SMIL_N_OBJS 10
+
+/* Prior terms (limit, pose, splay, betas, temporal) and their gradients on the per-frame parameters.
+ * global_rot (N,3), joint_rot (N,J-1,3), trans (N,3), betas (nB,); masks global_mask (3,),
+ * rotation_mask (J-1,3) (fitter.py:213-219,242-243).  halo_prev / halo_next: the (3J+3,) parameter row
+ * [global, joints, trans] of the frame just before / after this shard (NULL at the sequence ends).
+ * accumulate = 1: d_global / d_joint hold gradients w.r.t. the MASKED rotations on entry (from
+ * smil_lbs_backward) and hold the final parameter gradients on exit ((in + prior) * mask); d_trans is
+ * added to.  accumulate = 0: overwritten.  d_betas (nB,) is ADDED to. */
+int smil_prior_losses(const SmilFitConfig *cfg, const float *global_rot, const float *joint_rot,
+                      const float *trans, const float *betas, const float *mean_betas,
+                      const float *betas_prec, const float *global_mask, const float *rotation_mask,
+                      const float *halo_prev, const float *halo_next, float *objs, float *d_global,
+                      float *d_joint, float *d_trans, float *d_betas, int32_t accumulate, void *stream);
+
+/* 2-D joint loss (fitter.py:283,292-296).  proj / d_proj (N*views,J,2) in (y,x) px over ALL model joints;
+ * canon (Jc,) = config.CANONICAL_MODEL_JOINTS (NULL: the first Jc joints); target (N*views,Jc,2);
+ * visibility (N*views,Jc) int32.  objs[0] ADDED, d_proj overwritten. */
+int smil_joint_loss(const SmilFitConfig *cfg, int32_t views, int32_t Jc, const int32_t *canon, const float *proj,
+                    const float *target, const int32_t *visibility, float *objs, float *d_proj, void *stream);
+
+/* Helpers of the fused silhouette term: pix_scale[n] = w_reproj / (b_w views S^2); target_sum[n] =
+ * sum_px |target[n]| (once per fit); objs[5] += sum_n pix_scale[n] loss_img[n]. */
+int smil_pix_scale(const SmilFitConfig *cfg, int32_t views, int32_t S, float *pix_scale, void *stream);
+int smil_image_abs_sum(const float *images, int32_t N, int32_t pixels, float *out, void *stream);
+int smil_sil_objective(const float *loss_img, const float *pix_scale, int32_t N, float *objs, void *stream);
+
+/* torch.optim.Adam semantics (no amsgrad, no weight decay). step = 1-based step count. */
+int smil_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int32_t step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMILFIT_H_ */

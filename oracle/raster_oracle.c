@@ -103,12 +103,37 @@ static inline float pix_to_ndc(int i, int S) {
     return -1.0f + (2.0f * (float)i + 1.0f) / (float)S;
 }
 
+static int frag_less(const void *a, const void *b);
+static int g_select_mode;
+
 /* Sequential K-nearest queue exactly as the naive kernel keeps it: unsorted array, tracked max,
  * strict '<' replacement. Returns number kept; q must hold K entries. */
 static int gather_pixel(const float *vn, const int32_t *faces, int F, float px, float py, float blur,
                         float sqrt_blur, int K, Frag *q, int *n_candidates) {
     int qsize = 0, qmax_idx = -1, ncand = 0;
     float qmax_z = -1000.f;
+    if (g_select_mode == 1) {
+        /* analysis variant: gather everything, keep the K smallest (z, face) keys */
+        int cap = 256;
+        Frag *all = (Frag *)malloc(sizeof(Frag) * (size_t)cap);
+        for (int f = 0; f < F; ++f) {
+            const float *v0 = vn + 3 * (size_t)faces[3 * f + 0];
+            const float *v1 = vn + 3 * (size_t)faces[3 * f + 1];
+            const float *v2 = vn + 3 * (size_t)faces[3 * f + 2];
+            float pz, sd;
+            int ins;
+            if (!eval_face(v0, v1, v2, px, py, blur, sqrt_blur, &pz, &sd, &ins)) continue;
+            if (ncand == cap) { cap *= 2; all = (Frag *)realloc(all, sizeof(Frag) * (size_t)cap); }
+            all[ncand].z = pz; all[ncand].f = f; all[ncand].dist = sd; all[ncand].inside = ins;
+            ++ncand;
+        }
+        qsort(all, (size_t)ncand, sizeof(Frag), frag_less);
+        qsize = ncand < K ? ncand : K;
+        memcpy(q, all, sizeof(Frag) * (size_t)qsize);
+        free(all);
+        if (n_candidates) *n_candidates = ncand;
+        return qsize;
+    }
     for (int f = 0; f < F; ++f) {
         const float *v0 = vn + 3 * (size_t)faces[3 * f + 0];
         const float *v1 = vn + 3 * (size_t)faces[3 * f + 1];
@@ -131,6 +156,9 @@ static int gather_pixel(const float *vn, const int32_t *faces, int F, float px, 
     if (n_candidates) *n_candidates = ncand;
     return qsize;
 }
+
+static int g_select_mode; /* 0 = faithful sequential queue; 1 = K smallest by (z, face) [analysis only] */
+void oracle_set_select_mode(int m) { g_select_mode = m; }
 
 static int frag_less(const void *a, const void *b) {
     const Frag *x = (const Frag *)a, *y = (const Frag *)b;

@@ -1,0 +1,265 @@
+// Loss terms that do not need the renderer, the 2-D joint loss, and Adam.
+//
+// Replaces (reference): smal_fitter/fitter.py:292-331 (joint / limit / pose / splay / betas terms of
+// SMALFitter.forward), :337-350 (get_temporal), smal_fitter/optimize_to_joints.py:117-127,173-175
+// (torch.optim.Adam(betas=(0.5,0.999)) step).  Losses follow the reference's "sum over windows of the
+// window mean" (optimize_to_joints.py:154-157): a frame's terms are divided by the size of ITS window.
+#include "common.h"
+
+__device__ __forceinline__ int window_size_of(const SmilFitConfig &c, int local_frame) {
+    const int gi = c.frame0 + local_frame;
+    const int w = c.window > 0 ? c.window : c.N_total;
+    const int start = (gi / w) * w;
+    return min(w, c.N_total - start);
+}
+
+// element e of frame i: [0,3) global rotation, [3,3J) joint rotations, [3J,3J+3) translation
+__global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const float *__restrict__ grot,
+                                                      const float *__restrict__ jrot, const float *__restrict__ trans,
+                                                      const float *__restrict__ gmask, const float *__restrict__ rmask,
+                                                      const float *__restrict__ halo_prev, const float *__restrict__ halo_next,
+                                                      float *__restrict__ objs, float *__restrict__ d_g,
+                                                      float *__restrict__ d_j, float *__restrict__ d_t, int accumulate) {
+    __shared__ float red[16];
+    const int E = 3 * c.J + 3;
+    const long long total = (long long)c.N * E;
+    float o_limit = 0.f, o_pose = 0.f, o_splay = 0.f, o_tj = 0.f, o_tg = 0.f, o_tt = 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / E), e = (int)(idx - (long long)i * E);
+        const float bw = (float)window_size_of(c, i);
+        const int gi = c.frame0 + i;
+        const bool has_prev = gi > 0, has_next = gi + 1 < c.N_total;
+        // value of this element in the previous / next frame (masked like the current one)
+        float mask, cur, prv = 0.f, nxt = 0.f, tnorm;
+        float *dst;
+        float grad = 0.f;
+        if (e < 3) {
+            mask = gmask[e];
+            cur = grot[3 * i + e] * mask;
+            if (has_prev) prv = (i > 0 ? grot[3 * (i - 1) + e] : halo_prev[e]) * mask;
+            if (has_next) nxt = (i + 1 < c.N ? grot[3 * (i + 1) + e] : halo_next[e]) * mask;
+            tnorm = 3.f;
+            dst = d_g + 3 * i + e;
+        } else if (e < 3 * c.J) {
+            const int k = e - 3;
+            const size_t stride = (size_t)3 * (c.J - 1);
+            mask = rmask[k];
+            cur = jrot[i * stride + k] * mask;
+            if (has_prev) prv = (i > 0 ? jrot[(i - 1) * stride + k] : halo_prev[e]) * mask;
+            if (has_next) nxt = (i + 1 < c.N ? jrot[(i + 1) * stride + k] : halo_next[e]) * mask;
+            tnorm = (float)stride;
+            dst = d_j + i * stride + k;
+            // joint limits (fitter.py:303-307): mean over b_w*(J-1)*3
+            if (c.w_limit > 0.f) {
+                const float s = c.w_limit / (bw * tnorm);
+                o_limit += s * (fmaxf(cur - c.limit, 0.f) + fmaxf(-c.limit - cur, 0.f));
+                grad += s * ((cur > c.limit ? 1.f : 0.f) - (cur < -c.limit ? 1.f : 0.f));
+            }
+            // pose prior (identity precision, root excluded; fitter.py:25-52,310-316): mean over b_w*3J
+            if (c.w_pose > 0.f) {
+                const float s = c.w_pose / (bw * 3.f * (float)c.J);
+                o_pose += s * cur * cur;
+                grad += 2.f * s * cur;
+            }
+            // splay (fitter.py:319): SUM over x and z components
+            if (c.w_splay > 0.f && (k % 3) != 1) {
+                o_splay += c.w_splay * cur * cur;
+                grad += 2.f * c.w_splay * cur;
+            }
+        } else {
+            const int k = e - 3 * c.J;
+            mask = 1.f;
+            cur = trans[3 * i + k];
+            if (has_prev) prv = i > 0 ? trans[3 * (i - 1) + k] : halo_prev[e];
+            if (has_next) nxt = i + 1 < c.N ? trans[3 * (i + 1) + k] : halo_next[e];
+            tnorm = 3.f;
+            dst = d_t + 3 * i + k;
+        }
+        if (c.w_temp > 0.f) {
+            const float s = c.w_temp / tnorm;
+            float tl = 0.f;
+            if (has_next) { const float d = cur - nxt; tl = s * d * d; grad += 2.f * s * d; }  // pair (i,i+1) is owned by i
+            if (has_prev) { const float d = cur - prv; grad += 2.f * s * d; }
+            if (e < 3) o_tg += tl; else if (e < 3 * c.J) o_tj += tl; else o_tt += tl;
+        }
+        grad *= mask;
+        if (accumulate) *dst = (e < 3 * c.J ? (*dst) * mask : *dst) + grad; else *dst = grad;
+    }
+    float v;
+    v = block_sum(o_limit, red); if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[1], v);
+    v = block_sum(o_pose, red);  if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[2], v);
+    v = block_sum(o_splay, red); if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[3], v);
+    v = block_sum(o_tj, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[6], v);
+    v = block_sum(o_tg, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[7], v);
+    v = block_sum(o_tt, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[8], v);
+}
+
+// shape prior (fitter.py:321-330): per window mean(((beta - mean) @ prec)^2); identical for every window
+__global__ void k_betas_prior(SmilFitConfig c, const float *__restrict__ betas, const float *__restrict__ mean_betas,
+                              const float *__restrict__ prec, float *__restrict__ objs, float *__restrict__ d_betas) {
+    __shared__ float diff[SMIL_MAX_BETAS], res[SMIL_MAX_BETAS];
+    const int nB = c.nB, t = threadIdx.x;
+    const int w = c.window > 0 ? c.window : c.N_total;
+    // windows whose first frame lies in this rank's shard
+    const int first = (c.frame0 + w - 1) / w, last = (c.frame0 + c.N + w - 1) / w;
+    const float n_win = (float)(last - first);
+    if (t < nB) diff[t] = betas[t] - mean_betas[t];
+    __syncthreads();
+    if (t < nB) {
+        float r = 0.f;
+        for (int m = 0; m < nB; ++m) r += diff[m] * prec[m * nB + t];
+        res[t] = r;
+    }
+    __syncthreads();
+    if (t < nB) {
+        float g = 0.f;
+        for (int k = 0; k < nB; ++k) g += res[k] * prec[t * nB + k];
+        atomicAdd(&d_betas[t], n_win * c.w_betas * 2.f * g / (float)nB);
+    }
+    if (t == 0) {
+        float s = 0.f;
+        for (int k = 0; k < nB; ++k) s += res[k] * res[k];
+        atomicAdd(&objs[4], n_win * c.w_betas * s / (float)nB);
+    }
+}
+
+extern "C" int smil_prior_losses(const SmilFitConfig *cfg, const float *global_rot, const float *joint_rot,
+                                 const float *trans, const float *betas, const float *mean_betas,
+                                 const float *betas_prec, const float *global_mask, const float *rotation_mask,
+                                 const float *halo_prev, const float *halo_next, float *objs, float *d_global,
+                                 float *d_joint, float *d_trans, float *d_betas, int32_t accumulate, void *stream_) {
+    SMIL_REQUIRE(cfg && global_rot && joint_rot && trans && global_mask && rotation_mask && objs && d_global && d_joint && d_trans,
+                 "smil_prior_losses: null argument");
+    SMIL_REQUIRE(cfg->N > 0 && cfg->J > 1 && cfg->N_total >= cfg->frame0 + cfg->N, "smil_prior_losses: bad sizes");
+    SMIL_REQUIRE(cfg->frame0 == 0 || halo_prev, "smil_prior_losses: halo_prev required for a shard that does not start the sequence");
+    SMIL_REQUIRE(cfg->frame0 + cfg->N == cfg->N_total || halo_next, "smil_prior_losses: halo_next required for a shard that does not end the sequence");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long total = (long long)cfg->N * (3 * cfg->J + 3);
+    const int grid = (int)std::min<long long>(512, (total + 255) / 256);
+    hipLaunchKernelGGL(k_prior_losses, dim3(grid), dim3(256), 0, stream, *cfg, global_rot, joint_rot, trans, global_mask,
+                       rotation_mask, halo_prev, halo_next, objs, d_global, d_joint, d_trans, accumulate);
+    SMIL_LAUNCH_CHECK();
+    if (cfg->w_betas > 0.f && cfg->nB > 0) {
+        SMIL_REQUIRE(betas && mean_betas && betas_prec && d_betas, "smil_prior_losses: shape prior tables missing");
+        SMIL_REQUIRE(cfg->nB <= SMIL_MAX_BETAS, "smil_prior_losses: nB too large");
+        hipLaunchKernelGGL(k_betas_prior, dim3(1), dim3(64), 0, stream, *cfg, betas, mean_betas, betas_prec, objs, d_betas);
+        SMIL_LAUNCH_CHECK();
+    }
+    return SMIL_OK;
+}
+
+// 2-D joint loss (fitter.py:292-296). proj/d_proj (Nimg,J,2) over all model joints; canon (Jc,) selects the
+// annotated ones (NULL = first Jc); target (Nimg,Jc,2), visibility (Nimg,Jc).  Mean over b_w*views*Jc*2 entries
+// with invisible entries contributing 0 but counted in the denominator.
+__global__ void __launch_bounds__(256) k_joint_loss(SmilFitConfig c, int views, int Jc, const int *__restrict__ canon,
+                                                    const float *__restrict__ proj, const float *__restrict__ target,
+                                                    const int *__restrict__ vis, float *__restrict__ objs,
+                                                    float *__restrict__ d_proj) {
+    __shared__ float red[16];
+    const long long total = (long long)c.N * views * Jc;
+    float acc = 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(idx / Jc), k = (int)(idx - (long long)img * Jc);
+        const int frame = img / views;
+        const int j = canon ? canon[k] : k;
+        const float s = c.w_j2d / ((float)window_size_of(c, frame) * (float)views * (float)Jc * 2.f);
+        const size_t po = ((size_t)img * c.J + j) * 2, to = ((size_t)img * Jc + k) * 2;
+        float gy = 0.f, gx = 0.f;
+        if (vis[(size_t)img * Jc + k] != 0) {
+            const float dy = proj[po] - target[to], dx = proj[po + 1] - target[to + 1];
+            acc += s * (dy * dy + dx * dx);
+            gy = 2.f * s * dy; gx = 2.f * s * dx;
+        }
+        d_proj[po] = gy; d_proj[po + 1] = gx;
+    }
+    const float v = block_sum(acc, red);
+    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[0], v);
+}
+
+extern "C" int smil_joint_loss(const SmilFitConfig *cfg, int32_t views, int32_t Jc, const int32_t *canon, const float *proj,
+                               const float *target, const int32_t *visibility, float *objs, float *d_proj, void *stream_) {
+    SMIL_REQUIRE(cfg && proj && target && visibility && objs && d_proj, "smil_joint_loss: null argument");
+    SMIL_REQUIRE(views > 0 && Jc > 0 && Jc <= cfg->J, "smil_joint_loss: bad sizes views=%d Jc=%d", views, Jc);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (canon || Jc < cfg->J) SMIL_HIP(hipMemsetAsync(d_proj, 0, (size_t)cfg->N * views * cfg->J * 2 * sizeof(float), stream));
+    const long long total = (long long)cfg->N * views * Jc;
+    const int grid = (int)std::min<long long>(256, (total + 255) / 256);
+    hipLaunchKernelGGL(k_joint_loss, dim3(grid), dim3(256), 0, stream, *cfg, views, Jc, canon, proj, target, visibility, objs, d_proj);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+// per-image silhouette loss -> objs[5]: sum_n scale[n] * loss_img[n]
+__global__ void __launch_bounds__(256) k_sil_objective(const float *__restrict__ loss_img, const float *__restrict__ pix_scale,
+                                                       int N, float *__restrict__ objs) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) acc += loss_img[n] * pix_scale[n];
+    const float v = block_sum(acc, red);
+    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[5], v);
+}
+
+extern "C" int smil_sil_objective(const float *loss_img, const float *pix_scale, int32_t N, float *objs, void *stream_) {
+    SMIL_REQUIRE(loss_img && pix_scale && objs && N > 0, "smil_sil_objective: bad argument");
+    hipLaunchKernelGGL(k_sil_objective, dim3(std::min(64, ceil_div(N, 256))), dim3(256), 0, (hipStream_t)stream_, loss_img,
+                       pix_scale, N, objs);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+// pix_scale[n] = w_reproj / (b_w * views * S^2) for image n of local frame n / views
+__global__ void k_pix_scale(SmilFitConfig c, int views, int S, float *__restrict__ pix_scale) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= c.N * views) return;
+    pix_scale[n] = c.w_reproj / ((float)window_size_of(c, n / views) * (float)views * (float)S * (float)S);
+}
+
+extern "C" int smil_pix_scale(const SmilFitConfig *cfg, int32_t views, int32_t S, float *pix_scale, void *stream_) {
+    SMIL_REQUIRE(cfg && pix_scale && views > 0 && S > 0, "smil_pix_scale: bad argument");
+    hipLaunchKernelGGL(k_pix_scale, dim3(ceil_div(cfg->N * views, 256)), dim3(256), 0, (hipStream_t)stream_, *cfg, views, S, pix_scale);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+// target_sum[n] = sum_px |target[n]|  (constant over the fit; computed once)
+__global__ void __launch_bounds__(256) k_image_abs_sum(const float *__restrict__ img, int pixels, float *__restrict__ out) {
+    __shared__ float red[16];
+    const float *p = img + (size_t)blockIdx.x * pixels;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < pixels; i += blockDim.x) acc += fabsf(p[i]);
+    const float v = block_sum(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+extern "C" int smil_image_abs_sum(const float *images, int32_t N, int32_t pixels, float *out, void *stream_) {
+    SMIL_REQUIRE(images && out && N > 0 && pixels > 0, "smil_image_abs_sum: bad argument");
+    hipLaunchKernelGGL(k_image_abs_sum, dim3(N), dim3(256), 0, (hipStream_t)stream_, images, pixels, out);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+// torch.optim.Adam (single tensor path, no amsgrad / weight decay / maximize)
+__global__ void __launch_bounds__(256) k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                              float *__restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                              float bc1, float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);     // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int smil_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, int32_t step, void *stream_) {
+    SMIL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "smil_adam_step: bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    const int grid = (int)std::min<long long>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq, (long long)n, lr,
+                       beta1, beta2, eps, bc1, sqrtf(bc2));
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}

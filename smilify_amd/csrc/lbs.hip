@@ -1,0 +1,642 @@
+// Linear blend skinning for gfx950: shape blend, rest joints, Rodrigues + kinematic chain, skinning,
+// joint regression - forward and hand-written backward.
+//
+// Replaces (reference): smal_model/batch_lbs.py:31-50 (batch_rodrigues), :75-197
+// (batch_global_rigid_transformation), smal_model/smal_torch.py:198-370 (SMAL.__call__).
+//
+// HBM layout: every per-frame tensor is frame-major and dense.  Transforms are stored as 3x4
+// row-major (12 floats) instead of the reference's 4x4 (the last row is constant).  The skin table is
+// one packed uint32 (4 x u8 bone ids) + one float4 of weights per vertex: 20 B/vertex, read
+// coalesced; the per-frame joint transforms (J x 48 B) are staged in LDS by each workgroup.
+#include "common.h"
+
+#define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels
+
+struct Mat34 {
+    float r[9];
+    float t[3];
+};
+
+__device__ __forceinline__ void rodrigues_fwd(float tx, float ty, float tz, float R[9]) {
+    // batch_lbs.py:37-38: the norm is taken of theta + 1e-8, the axis uses the unshifted theta
+    const float ax = tx + 1e-8f, ay = ty + 1e-8f, az = tz + 1e-8f;
+    const float angle = sqrtf(ax * ax + ay * ay + az * az);
+    const float rx = tx / angle, ry = ty / angle, rz = tz / angle;
+    const float c = cosf(angle), s = sinf(angle);
+    const float k = 1.0f - c;
+    R[0] = c + k * rx * rx;      R[1] = k * rx * ry - s * rz; R[2] = k * rx * rz + s * ry;
+    R[3] = k * ry * rx + s * rz; R[4] = c + k * ry * ry;      R[5] = k * ry * rz - s * rx;
+    R[6] = k * rz * rx - s * ry; R[7] = k * rz * ry + s * rx; R[8] = c + k * rz * rz;
+}
+
+// dR (3x3) -> dtheta for R = c I + (1-c) r r^T + s H(r), angle = |theta + eps|, r = theta / angle
+__device__ __forceinline__ void rodrigues_bwd(float tx, float ty, float tz, const float dR[9], float dth[3]) {
+    const float ax = tx + 1e-8f, ay = ty + 1e-8f, az = tz + 1e-8f;
+    const float angle = sqrtf(ax * ax + ay * ay + az * az);
+    const float inv = 1.0f / angle;
+    const float r[3] = {tx * inv, ty * inv, tz * inv};
+    const float c = cosf(angle), s = sinf(angle), k = 1.0f - c;
+    // d angle through cos/sin:  sum dR_mn * (-s d_mn + s r_m r_n + c H_mn)
+    const float trace = dR[0] + dR[4] + dR[8];
+    float rdr = 0.f;  // r^T dR r
+    for (int m = 0; m < 3; ++m)
+        for (int n = 0; n < 3; ++n) rdr += dR[3 * m + n] * r[m] * r[n];
+    // sum dR_mn H_mn with H = [[0,-r2,r1],[r2,0,-r0],[-r1,r0,0]]
+    const float hx = dR[7] - dR[5], hy = dR[2] - dR[6], hz = dR[3] - dR[1];
+    const float dRH = r[0] * hx + r[1] * hy + r[2] * hz;
+    float dangle = -s * trace + s * rdr + c * dRH;
+    // d r_k = (1-c) ((dR + dR^T) r)_k + s * (hx,hy,hz)_k
+    float dr[3];
+    dr[0] = k * ((dR[0] + dR[0]) * r[0] + (dR[1] + dR[3]) * r[1] + (dR[2] + dR[6]) * r[2]) + s * hx;
+    dr[1] = k * ((dR[3] + dR[1]) * r[0] + (dR[4] + dR[4]) * r[1] + (dR[5] + dR[7]) * r[2]) + s * hy;
+    dr[2] = k * ((dR[6] + dR[2]) * r[0] + (dR[7] + dR[5]) * r[1] + (dR[8] + dR[8]) * r[2]) + s * hz;
+    // r = theta / angle
+    dangle -= (dr[0] * tx + dr[1] * ty + dr[2] * tz) * inv * inv;
+    dth[0] = dr[0] * inv + dangle * ax * inv;
+    dth[1] = dr[1] * inv + dangle * ay * inv;
+    dth[2] = dr[2] * inv + dangle * az * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shape blend: v_shaped[s] = (v_template (+ del_v[s])) + beta[s] @ shapedirs     (smal_torch.py:240-248)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_shape_blend(const float *__restrict__ vt, const float *__restrict__ sd,
+                              const float *__restrict__ beta, const float *__restrict__ del_v,
+                              float *__restrict__ v_shaped, int V3, int nB_used, int beta_stride) {
+    __shared__ float sbeta[SMIL_MAX_BETAS];
+    const int s = blockIdx.y;
+    if (threadIdx.x < nB_used) sbeta[threadIdx.x] = beta[(size_t)s * beta_stride + threadIdx.x];
+    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= V3) return;
+    float acc = 0.f;
+    for (int k = 0; k < nB_used; ++k) acc += sbeta[k] * sd[(size_t)k * V3 + e];
+    float base = vt[e];
+    if (del_v) base += del_v[(size_t)s * V3 + e];
+    v_shaped[(size_t)s * V3 + e] = base + acc;
+}
+
+// rest joints: J = J_static or J_regressor^T v_shaped (CSR gather)               (smal_torch.py:257-264)
+__global__ void k_rest_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
+                              const float *__restrict__ val, const float *__restrict__ v_shaped,
+                              const float *__restrict__ J_static, float *__restrict__ J_rest, int V, int J,
+                              int is_static) {
+    const int s = blockIdx.x;
+    for (int idx = threadIdx.x; idx < 3 * J; idx += blockDim.x) {
+        float acc;
+        if (is_static) {
+            acc = J_static[idx];
+        } else {
+            const int j = idx / 3, c = idx - 3 * j;
+            acc = 0.f;
+            const float *vs = v_shaped + (size_t)s * V * 3;
+            for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) acc += vs[3 * col[e] + c] * val[e];
+        }
+        J_rest[(size_t)s * J * 3 + idx] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pose: Rodrigues + level-synchronous kinematic chain, one wavefront per frame, lane = joint.
+// World transforms live in LDS while the chain is walked (parents precede children, so level d only
+// reads level d-1).
+// ---------------------------------------------------------------------------------------------
+struct PoseArgs {
+    const float *theta, *Rs_in, *logscale, *btrans, *J_rest;
+    const int *parents, *depth;
+    float *Rs, *G, *A, *new_J, *joints_static;
+    int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
+};
+
+__global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) {
+    extern __shared__ float smem[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * FRAMES_PER_BLOCK + wid;
+    const bool live = b < a.B;
+    const int J = a.J;
+    float *sG = smem + (size_t)wid * J * 15;  // (J,12) world transforms
+    float *sIS = sG + J * 12;                  // (J,3) inverse scales
+    const float *Jr = a.J_rest + (size_t)(a.nS == 1 ? 0 : (live ? b : 0)) * J * 3;
+
+    for (int d = 0; d <= a.max_depth; ++d) {
+        if (live) {
+            for (int j = lane; j < J; j += WAVE) {
+                if (a.depth[j] != d) continue;
+                float R[9];
+                if (a.Rs_in) {
+                    for (int i = 0; i < 9; ++i) R[i] = a.Rs_in[((size_t)b * J + j) * 9 + i];
+                } else {
+                    const float *th = a.theta + ((size_t)b * J + j) * 3;
+                    rodrigues_fwd(th[0], th[1], th[2], R);
+                }
+                if (a.Rs)
+                    for (int i = 0; i < 9; ++i) a.Rs[((size_t)b * J + j) * 9 + i] = R[i];
+                float S[3] = {1.f, 1.f, 1.f};
+                if (a.use_scale) {
+                    const float *ls = a.logscale + ((size_t)(a.logscale_shared ? 0 : b) * J + j) * 3;
+                    S[0] = expf(ls[0]); S[1] = expf(ls[1]); S[2] = expf(ls[2]);
+                }
+                sIS[3 * j + 0] = 1.0f / S[0]; sIS[3 * j + 1] = 1.0f / S[1]; sIS[3 * j + 2] = 1.0f / S[2];
+                float G[12];
+                if (d == 0) {
+                    // root: rotation only, own scale never applied (batch_lbs.py:151)
+                    G[0] = R[0]; G[1] = R[1]; G[2] = R[2]; G[3] = Jr[3 * j + 0];
+                    G[4] = R[3]; G[5] = R[4]; G[6] = R[5]; G[7] = Jr[3 * j + 1];
+                    G[8] = R[6]; G[9] = R[7]; G[10] = R[8]; G[11] = Jr[3 * j + 2];
+                } else {
+                    const int p = a.parents[j];
+                    float t[3] = {Jr[3 * j] - Jr[3 * p], Jr[3 * j + 1] - Jr[3 * p + 1], Jr[3 * j + 2] - Jr[3 * p + 2]};
+                    if (a.btrans) {
+                        const float *bt = a.btrans + ((size_t)(a.btrans_shared ? 0 : b) * J + j) * 3;
+                        t[0] += bt[0]; t[1] += bt[1] * -1.0f; t[2] += bt[2];  // y flipped (batch_lbs.py:148)
+                    }
+                    float L[9];
+                    for (int m = 0; m < 3; ++m) {
+                        const float isp = a.propagate ? 1.0f : sIS[3 * p + m];
+                        for (int n = 0; n < 3; ++n) L[3 * m + n] = (isp * R[3 * m + n]) * S[n];
+                    }
+                    const float *P = sG + 12 * p;
+                    for (int m = 0; m < 3; ++m) {
+                        const float p0 = P[4 * m], p1 = P[4 * m + 1], p2 = P[4 * m + 2], p3 = P[4 * m + 3];
+                        G[4 * m + 0] = p0 * L[0] + p1 * L[3] + p2 * L[6];
+                        G[4 * m + 1] = p0 * L[1] + p1 * L[4] + p2 * L[7];
+                        G[4 * m + 2] = p0 * L[2] + p1 * L[5] + p2 * L[8];
+                        G[4 * m + 3] = p0 * t[0] + p1 * t[1] + p2 * t[2] + p3;
+                    }
+                }
+                for (int i = 0; i < 12; ++i) sG[12 * j + i] = G[i];
+                // outputs
+                const size_t o = ((size_t)b * J + j);
+                float *Go = a.G + o * 12, *Ao = a.A + o * 12;
+                const float jx = Jr[3 * j], jy = Jr[3 * j + 1], jz = Jr[3 * j + 2];
+                for (int m = 0; m < 3; ++m) {
+                    Go[4 * m] = G[4 * m]; Go[4 * m + 1] = G[4 * m + 1]; Go[4 * m + 2] = G[4 * m + 2]; Go[4 * m + 3] = G[4 * m + 3];
+                    Ao[4 * m] = G[4 * m]; Ao[4 * m + 1] = G[4 * m + 1]; Ao[4 * m + 2] = G[4 * m + 2];
+                    // A_t = G_t - G_R J   (batch_lbs.py:192-195)
+                    Ao[4 * m + 3] = G[4 * m + 3] - (G[4 * m] * jx + G[4 * m + 1] * jy + G[4 * m + 2] * jz);
+                }
+                a.new_J[o * 3 + 0] = G[3]; a.new_J[o * 3 + 1] = G[7]; a.new_J[o * 3 + 2] = G[11];
+                if (a.joints_static) {
+                    a.joints_static[o * 3 + 0] = G[3]; a.joints_static[o * 3 + 1] = G[7]; a.joints_static[o * 3 + 2] = G[11];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// skinning: verts = (sum_k w_k A_k) [v;1] + trans                               (smal_torch.py:320-340)
+// grid (ceil(V/256), B); the frame's J transforms are staged in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_skin_fwd(const float *__restrict__ A, const float *__restrict__ v_posed,
+                                                  const uint32_t *__restrict__ skin_idx,
+                                                  const float4 *__restrict__ skin_w, const float *__restrict__ trans,
+                                                  float *__restrict__ verts, int V, int J, int nS) {
+    extern __shared__ float sA[];
+    const int b = blockIdx.y;
+    const float *Ab = A + (size_t)b * J * 12;
+    for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = Ab[i];
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const uint32_t ids = skin_idx[v];
+    const float4 w4 = skin_w[v];
+    const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+    float T[12];
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    for (int k = 0; k < SMIL_MAX_BONES; ++k) {
+        if (w[k] == 0.f) continue;
+        const float *Ak = sA + 12 * ((ids >> (8 * k)) & 0xFF);
+        for (int i = 0; i < 12; ++i) T[i] += w[k] * Ak[i];
+    }
+    const float *vp = v_posed + ((size_t)(nS == 1 ? 0 : b) * V + v) * 3;
+    const float x = vp[0], y = vp[1], z = vp[2];
+    float ox = T[0] * x + T[1] * y + T[2] * z + T[3];
+    float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
+    float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    if (trans) { ox += trans[3 * b]; oy += trans[3 * b + 1]; oz += trans[3 * b + 2]; }
+    float *o = verts + ((size_t)b * V + v) * 3;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+}
+
+// posed joints by regression from the posed vertices                           (smal_torch.py:348-351)
+__global__ void k_regress_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                 const float *__restrict__ val, const float *__restrict__ verts,
+                                 float *__restrict__ joints, int V, int J) {
+    const int b = blockIdx.x;
+    const float *vb = verts + (size_t)b * V * 3;
+    for (int idx = threadIdx.x; idx < 3 * J; idx += blockDim.x) {
+        const int j = idx / 3, c = idx - 3 * j;
+        float acc = 0.f;
+        for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) acc += vb[3 * col[e] + c] * val[e];
+        joints[(size_t)b * J * 3 + idx] = acc;
+    }
+}
+
+extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, void *stream_) {
+    SMIL_REQUIRE(m && in && out, "smil_lbs_forward: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = in->B, V = m->V, J = m->J;
+    SMIL_REQUIRE(B > 0, "smil_lbs_forward: B=%d", B);
+    SMIL_REQUIRE(in->nB_used >= 0 && in->nB_used <= m->nB, "smil_lbs_forward: nB_used=%d but the model has %d betas",
+                 in->nB_used, m->nB);
+    SMIL_REQUIRE(in->nB_used == 0 || in->beta, "smil_lbs_forward: beta missing");
+    SMIL_REQUIRE(in->theta || in->Rs_in, "smil_lbs_forward: theta or Rs_in required");
+    SMIL_REQUIRE(out->v_shaped && out->J_rest && out->G && out->A && out->new_J && out->verts && out->joints,
+                 "smil_lbs_forward: null output");
+    const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
+    const float *vt = in->v_template ? in->v_template : m->v_template;
+    {
+        dim3 grid(ceil_div(3 * V, 256), nS);
+        hipLaunchKernelGGL(k_shape_blend, grid, dim3(256), 0, stream, vt, m->shapedirs, in->beta, in->del_v,
+                           out->v_shaped, 3 * V, in->nB_used, in->shared_beta ? 0 : in->nB_used);
+        SMIL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rest_joints, dim3(nS), dim3(256), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
+                       out->v_shaped, m->J_static, out->J_rest, V, J, m->static_joints ? 1 : 0);
+    SMIL_LAUNCH_CHECK();
+    {
+        PoseArgs a;
+        a.theta = in->theta; a.Rs_in = in->Rs_in;
+        a.use_scale = (in->logscale && in->allow_limb_scaling) ? 1 : 0;
+        a.logscale = in->logscale; a.btrans = in->btrans; a.J_rest = out->J_rest;
+        a.parents = m->parents; a.depth = m->depth;
+        a.Rs = out->Rs; a.G = out->G; a.A = out->A; a.new_J = out->new_J;
+        a.joints_static = m->static_joints ? out->joints : nullptr;
+        a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;
+        a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
+        a.propagate = in->propagate_scaling;
+        const size_t lds = (size_t)FRAMES_PER_BLOCK * J * 15 * sizeof(float);
+        hipLaunchKernelGGL(k_pose_fwd, dim3(ceil_div(B, FRAMES_PER_BLOCK)), dim3(64 * FRAMES_PER_BLOCK), lds, stream, a);
+        SMIL_LAUNCH_CHECK();
+    }
+    {
+        dim3 grid(ceil_div(V, 256), B);
+        hipLaunchKernelGGL(k_skin_fwd, grid, dim3(256), (size_t)J * 12 * sizeof(float), stream, out->A, out->v_shaped,
+                           m->skin_idx, m->skin_w, in->trans, out->verts, V, J, nS);
+        SMIL_LAUNCH_CHECK();
+    }
+    if (!m->static_joints) {
+        hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(256), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
+                           out->verts, out->joints, V, J);
+        SMIL_LAUNCH_CHECK();
+    }
+    return SMIL_OK;
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+
+// total upstream gradient on a posed vertex: d_verts + J_regressor (CSC gather) d_joints
+__device__ __forceinline__ void vertex_upstream(const float *__restrict__ d_verts_b, const float *sDJ,
+                                                const int *__restrict__ colptr, const int *__restrict__ row,
+                                                const float *__restrict__ cval, int v, bool regress, float dv[3]) {
+    dv[0] = dv[1] = dv[2] = 0.f;
+    if (d_verts_b) { dv[0] = d_verts_b[3 * v]; dv[1] = d_verts_b[3 * v + 1]; dv[2] = d_verts_b[3 * v + 2]; }
+    if (regress) {
+        for (int e = colptr[v]; e < colptr[v + 1]; ++e) {
+            const float w = cval[e];
+            const float *dj = sDJ + 3 * row[e];
+            dv[0] += w * dj[0]; dv[1] += w * dj[1]; dv[2] += w * dj[2];
+        }
+    }
+}
+
+// d_A[b][j] = sum_{v in bone j} w (dv (x) [v_posed;1]).  One block per frame, one wave per bone
+// (strided); deterministic (no atomics).
+__global__ void __launch_bounds__(256) k_skin_bwd_transforms(
+    const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ v_posed,
+    const int *__restrict__ bone_ptr, const int *__restrict__ bone_vid, const float *__restrict__ bone_w,
+    const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
+    float *__restrict__ d_A, int V, int J, int nS, int regress) {
+    extern __shared__ float sDJ[];  // (J,3)
+    const int b = blockIdx.x;
+    const bool reg = regress && d_joints;
+    if (reg)
+        for (int i = threadIdx.x; i < 3 * J; i += blockDim.x) sDJ[i] = d_joints[(size_t)b * J * 3 + i];
+    __syncthreads();
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const float *dvb = d_verts ? d_verts + (size_t)b * V * 3 : nullptr;
+    const float *vpb = v_posed + (size_t)(nS == 1 ? 0 : b) * V * 3;
+    for (int j = wid; j < J; j += nw) {
+        float acc[12];
+        for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+        for (int e = bone_ptr[j] + lane; e < bone_ptr[j + 1]; e += WAVE) {
+            const int v = bone_vid[e];
+            const float w = bone_w[e];
+            float dv[3];
+            vertex_upstream(dvb, sDJ, colptr, row, cval, v, reg, dv);
+            const float x = vpb[3 * v], y = vpb[3 * v + 1], z = vpb[3 * v + 2];
+            for (int r = 0; r < 3; ++r) {
+                const float g = w * dv[r];
+                acc[4 * r] += g * x; acc[4 * r + 1] += g * y; acc[4 * r + 2] += g * z; acc[4 * r + 3] += g;
+            }
+        }
+        for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
+        if (lane == 0)
+            for (int i = 0; i < 12; ++i) d_A[((size_t)b * J + j) * 12 + i] = acc[i];
+    }
+}
+
+struct ChainBwdArgs {
+    const float *theta, *Rs, *logscale, *btrans, *J_rest, *G, *d_A, *d_newJ;
+    const int *parents, *depth;
+    float *d_theta, *d_logscale, *d_btrans, *d_Jrest;
+    int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
+};
+
+// Reverse walk of the kinematic chain, one wavefront per frame, LDS accumulators for the gradients
+// that flow child -> parent.
+__global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArgs a) {
+    extern __shared__ float smem[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * FRAMES_PER_BLOCK + wid;
+    const bool live = b < a.B;
+    const int J = a.J;
+    float *sG = smem + (size_t)wid * J * 30;  // (J,12) world transforms
+    float *sdG = sG + J * 12;                  // (J,12) their gradients
+    float *sdJ = sdG + J * 12;                 // (J,3) gradient on rest joints
+    float *sdS = sdJ + J * 3;                  // (J,3) gradient on log scales
+    const size_t fb = live ? b : 0;
+    const float *Jr = a.J_rest + (size_t)(a.nS == 1 ? 0 : fb) * J * 3;
+    const float *ls = a.use_scale ? a.logscale + (size_t)(a.logscale_shared ? 0 : fb) * J * 3 : nullptr;
+
+    if (live) {
+        for (int j = lane; j < J; j += WAVE) {
+            const size_t o = fb * J + j;
+            float G[12], dA[12];
+            for (int i = 0; i < 12; ++i) { G[i] = a.G[o * 12 + i]; dA[i] = a.d_A[o * 12 + i]; }
+            const float jx = Jr[3 * j], jy = Jr[3 * j + 1], jz = Jr[3 * j + 2];
+            for (int m = 0; m < 3; ++m) {
+                const float dt = dA[4 * m + 3];
+                sG[12 * j + 4 * m] = G[4 * m]; sG[12 * j + 4 * m + 1] = G[4 * m + 1];
+                sG[12 * j + 4 * m + 2] = G[4 * m + 2]; sG[12 * j + 4 * m + 3] = G[4 * m + 3];
+                // A_R = G_R ; A_t = G_t - G_R J
+                sdG[12 * j + 4 * m] = dA[4 * m] - dt * jx;
+                sdG[12 * j + 4 * m + 1] = dA[4 * m + 1] - dt * jy;
+                sdG[12 * j + 4 * m + 2] = dA[4 * m + 2] - dt * jz;
+                sdG[12 * j + 4 * m + 3] = dt + (a.d_newJ ? a.d_newJ[o * 3 + m] : 0.f);
+            }
+            for (int n = 0; n < 3; ++n) {
+                sdJ[3 * j + n] = -(G[n] * dA[3] + G[4 + n] * dA[7] + G[8 + n] * dA[11]);
+                sdS[3 * j + n] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int d = a.max_depth; d >= 0; --d) {
+        if (live) {
+            for (int j = lane; j < J; j += WAVE) {
+                if (a.depth[j] != d) continue;
+                const size_t o = fb * J + j;
+                float dG[12];
+                for (int i = 0; i < 12; ++i) dG[i] = sdG[12 * j + i];
+                float dR[9];
+                if (d == 0) {
+                    for (int m = 0; m < 3; ++m) {
+                        dR[3 * m] = dG[4 * m]; dR[3 * m + 1] = dG[4 * m + 1]; dR[3 * m + 2] = dG[4 * m + 2];
+                        sdJ[3 * j + m] += dG[4 * m + 3];
+                    }
+                } else {
+                    const int p = a.parents[j];
+                    float R[9];
+                    for (int i = 0; i < 9; ++i) R[i] = a.Rs[o * 9 + i];
+                    float S[3] = {1.f, 1.f, 1.f}, isp[3] = {1.f, 1.f, 1.f};
+                    if (ls) {
+                        S[0] = expf(ls[3 * j]); S[1] = expf(ls[3 * j + 1]); S[2] = expf(ls[3 * j + 2]);
+                        if (!a.propagate) {
+                            isp[0] = 1.0f / expf(ls[3 * p]); isp[1] = 1.0f / expf(ls[3 * p + 1]); isp[2] = 1.0f / expf(ls[3 * p + 2]);
+                        }
+                    }
+                    float t[3] = {Jr[3 * j] - Jr[3 * p], Jr[3 * j + 1] - Jr[3 * p + 1], Jr[3 * j + 2] - Jr[3 * p + 2]};
+                    if (a.btrans) {
+                        const float *bt = a.btrans + ((size_t)(a.btrans_shared ? 0 : fb) * J + j) * 3;
+                        t[0] += bt[0]; t[1] -= bt[1]; t[2] += bt[2];
+                    }
+                    float L[9];
+                    for (int m = 0; m < 3; ++m)
+                        for (int n = 0; n < 3; ++n) L[3 * m + n] = (isp[m] * R[3 * m + n]) * S[n];
+                    const float *P = sG + 12 * p;
+                    // parent: dGp_R += dG_R L^T + dG_t (x) t ; dGp_t += dG_t
+                    for (int m = 0; m < 3; ++m) {
+                        for (int k = 0; k < 3; ++k) {
+                            const float g = dG[4 * m] * L[3 * k] + dG[4 * m + 1] * L[3 * k + 1] + dG[4 * m + 2] * L[3 * k + 2] +
+                                            dG[4 * m + 3] * t[k];
+                            atomicAdd(&sdG[12 * p + 4 * m + k], g);
+                        }
+                        atomicAdd(&sdG[12 * p + 4 * m + 3], dG[4 * m + 3]);
+                    }
+                    // local: dL = Gp_R^T dG_R ; dt = Gp_R^T dG_t
+                    float dL[9], dt[3];
+                    for (int k = 0; k < 3; ++k) {
+                        for (int n = 0; n < 3; ++n)
+                            dL[3 * k + n] = P[k] * dG[n] + P[4 + k] * dG[4 + n] + P[8 + k] * dG[8 + n];
+                        dt[k] = P[k] * dG[3] + P[4 + k] * dG[7] + P[8 + k] * dG[11];
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        sdJ[3 * j + k] += dt[k];
+                        atomicAdd(&sdJ[3 * p + k], -dt[k]);
+                    }
+                    if (a.d_btrans && a.btrans) {
+                        float *o_bt = a.d_btrans + o * 3;
+                        o_bt[0] = dt[0]; o_bt[1] = -dt[1]; o_bt[2] = dt[2];
+                    }
+                    for (int m = 0; m < 3; ++m) {
+                        float dis = 0.f;
+                        for (int n = 0; n < 3; ++n) {
+                            dR[3 * m + n] = isp[m] * dL[3 * m + n] * S[n];
+                            dis += R[3 * m + n] * S[n] * dL[3 * m + n];
+                        }
+                        if (ls && !a.propagate) atomicAdd(&sdS[3 * p + m], -dis * isp[m]);
+                    }
+                    if (ls) {
+                        for (int n = 0; n < 3; ++n) {
+                            float dS = 0.f;
+                            for (int m = 0; m < 3; ++m) dS += isp[m] * R[3 * m + n] * dL[3 * m + n];
+                            sdS[3 * j + n] += dS * S[n];
+                        }
+                    }
+                }
+                if (a.d_theta && a.theta) {
+                    const float *th = a.theta + o * 3;
+                    float dth[3];
+                    rodrigues_bwd(th[0], th[1], th[2], dR, dth);
+                    a.d_theta[o * 3] = dth[0]; a.d_theta[o * 3 + 1] = dth[1]; a.d_theta[o * 3 + 2] = dth[2];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        for (int j = lane; j < J; j += WAVE) {
+            const size_t o = fb * J + j;
+            for (int k = 0; k < 3; ++k) {
+                if (a.d_Jrest) a.d_Jrest[o * 3 + k] = sdJ[3 * j + k];
+                if (a.d_logscale) a.d_logscale[o * 3 + k] = a.use_scale ? sdS[3 * j + k] : 0.f;
+            }
+            if (a.d_btrans && (!a.btrans || j == 0))
+                for (int k = 0; k < 3; ++k) a.d_btrans[o * 3 + k] = 0.f;
+        }
+    }
+}
+
+#define BETA_CHUNK 8
+
+// Per frame: d v_posed = T_R^T dv (+ regressor^T d J_rest), reduced against shapedirs -> d_beta[b],
+// and d_trans[b] = sum_v dv.  One block per frame, deterministic.
+__global__ void __launch_bounds__(256) k_shape_bwd(
+    const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
+    const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
+    const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
+    const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_trans, int V, int J,
+    int nB_used, int regress) {
+    extern __shared__ float smem[];
+    float *sA = smem;            // (J,12)
+    float *sDJ = sA + J * 12;    // (J,3) upstream on posed joints
+    float *sDR = sDJ + J * 3;    // (J,3) gradient on rest joints
+    float *red = sDR + J * 3;    // 16
+    const int b = blockIdx.x;
+    const bool reg_j = regress && d_joints;
+    const bool reg_r = regress && d_Jrest;
+    for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = A[(size_t)b * J * 12 + i];
+    for (int i = threadIdx.x; i < J * 3; i += blockDim.x) {
+        sDJ[i] = reg_j ? d_joints[(size_t)b * J * 3 + i] : 0.f;
+        sDR[i] = reg_r ? d_Jrest[(size_t)b * J * 3 + i] : 0.f;
+    }
+    __syncthreads();
+    const float *dvb = d_verts ? d_verts + (size_t)b * V * 3 : nullptr;
+    const int V3 = 3 * V;
+    for (int k0 = 0; k0 < (nB_used > 0 ? nB_used : 1); k0 += BETA_CHUNK) {
+        float bsum[BETA_CHUNK];
+        for (int k = 0; k < BETA_CHUNK; ++k) bsum[k] = 0.f;
+        float tsum[3] = {0.f, 0.f, 0.f};
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            float dv[3];
+            vertex_upstream(dvb, sDJ, colptr, row, cval, v, reg_j, dv);
+            tsum[0] += dv[0]; tsum[1] += dv[1]; tsum[2] += dv[2];
+            if (nB_used == 0) continue;
+            const uint32_t ids = skin_idx[v];
+            const float4 w4 = skin_w[v];
+            const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+            float T[9];
+            for (int i = 0; i < 9; ++i) T[i] = 0.f;
+            for (int k = 0; k < SMIL_MAX_BONES; ++k) {
+                if (w[k] == 0.f) continue;
+                const float *Ak = sA + 12 * ((ids >> (8 * k)) & 0xFF);
+                for (int m = 0; m < 3; ++m) {
+                    T[3 * m] += w[k] * Ak[4 * m]; T[3 * m + 1] += w[k] * Ak[4 * m + 1]; T[3 * m + 2] += w[k] * Ak[4 * m + 2];
+                }
+            }
+            float dvp[3];
+            for (int n = 0; n < 3; ++n) dvp[n] = T[n] * dv[0] + T[3 + n] * dv[1] + T[6 + n] * dv[2];
+            if (reg_r) {
+                for (int e = colptr[v]; e < colptr[v + 1]; ++e) {
+                    const float wv = cval[e];
+                    const float *dr = sDR + 3 * row[e];
+                    dvp[0] += wv * dr[0]; dvp[1] += wv * dr[1]; dvp[2] += wv * dr[2];
+                }
+            }
+            for (int k = 0; k < BETA_CHUNK; ++k) {
+                if (k0 + k < nB_used) {
+                    const float *s3 = sd + (size_t)(k0 + k) * V3 + 3 * v;
+                    bsum[k] += s3[0] * dvp[0] + s3[1] * dvp[1] + s3[2] * dvp[2];
+                }
+            }
+        }
+        for (int k = 0; k < BETA_CHUNK; ++k) {
+            if (k0 + k < nB_used) {
+                const float r = block_sum(bsum[k], red);
+                if (threadIdx.x == 0 && d_beta_frame) d_beta_frame[(size_t)b * nB_used + k0 + k] = r;
+            }
+        }
+        if (k0 == 0 && d_trans) {
+            for (int c = 0; c < 3; ++c) {
+                const float r = block_sum(tsum[c], red);
+                if (threadIdx.x == 0) d_trans[3 * b + c] = r;
+            }
+        }
+    }
+}
+
+// out[c] = sum_b in[b][c]; grid ceil(C/64), block (64,4)
+__global__ void k_reduce_rows(const float *__restrict__ in, float *__restrict__ out, int B, int C) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float acc = 0.f;
+    if (c < C)
+        for (int b = threadIdx.y; b < B; b += 4) acc += in[(size_t)b * C + c];
+    part[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+int smil_reduce_rows(const float *in, float *out, int B, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(k_reduce_rows, dim3(ceil_div(C, 64)), dim3(64, 4), 0, stream, in, out, B, C);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv,
+                                 const SmilLbsGrads *g, void *stream_) {
+    SMIL_REQUIRE(m && in && sv && g, "smil_lbs_backward: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = in->B, V = m->V, J = m->J;
+    SMIL_REQUIRE(B > 0, "smil_lbs_backward: B=%d", B);
+    SMIL_REQUIRE(g->d_verts || g->d_joints, "smil_lbs_backward: no upstream gradient");
+    SMIL_REQUIRE(g->d_A && g->d_Jrest && g->d_Rs, "smil_lbs_backward: scratch buffers missing");
+    SMIL_REQUIRE(sv->v_shaped && sv->J_rest && sv->G && sv->A && sv->Rs, "smil_lbs_backward: saved forward tensors missing");
+    const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
+    const int regress = m->static_joints ? 0 : 1;
+    const int use_scale = (in->logscale && in->allow_limb_scaling) ? 1 : 0;
+
+    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(256), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
+                       g->d_joints, sv->v_shaped, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
+                       m->jreg_cval, g->d_A, V, J, nS, regress);
+    SMIL_LAUNCH_CHECK();
+
+    // per-frame scale / translation gradients go to the output directly, or to scratch (d_Rs) when the
+    // table is shared by all frames and has to be reduced over frames afterwards
+    float *scratch = g->d_Rs;  // (B,J,9)
+    float *dls_frame = nullptr, *dbt_frame = nullptr;
+    if (g->d_logscale) dls_frame = in->logscale_shared ? scratch : g->d_logscale;
+    if (g->d_btrans) dbt_frame = in->btrans_shared ? scratch + (size_t)B * J * 3 : g->d_btrans;
+    {
+        ChainBwdArgs a;
+        a.theta = in->Rs_in ? nullptr : in->theta; a.Rs = sv->Rs;
+        a.logscale = in->logscale; a.btrans = in->btrans; a.J_rest = sv->J_rest; a.G = sv->G; a.d_A = g->d_A;
+        a.d_newJ = m->static_joints ? g->d_joints : nullptr;
+        a.parents = m->parents; a.depth = m->depth;
+        a.d_theta = g->d_theta; a.d_logscale = dls_frame; a.d_btrans = dbt_frame; a.d_Jrest = g->d_Jrest;
+        a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;
+        a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
+        a.propagate = in->propagate_scaling; a.use_scale = use_scale;
+        const size_t lds = (size_t)FRAMES_PER_BLOCK * J * 30 * sizeof(float);
+        hipLaunchKernelGGL(k_chain_bwd, dim3(ceil_div(B, FRAMES_PER_BLOCK)), dim3(64 * FRAMES_PER_BLOCK), lds, stream, a);
+        SMIL_LAUNCH_CHECK();
+    }
+    if (g->d_logscale && in->logscale_shared) {
+        int rc = smil_reduce_rows(dls_frame, g->d_logscale, B, J * 3, stream);
+        if (rc) return rc;
+    }
+    if (g->d_btrans && in->btrans_shared) {
+        int rc = smil_reduce_rows(dbt_frame, g->d_btrans, B, J * 3, stream);
+        if (rc) return rc;
+    }
+    if (g->d_beta || g->d_trans) {
+        const int nBu = g->d_beta ? in->nB_used : 0;
+        float *dbeta_frame = nullptr;
+        if (g->d_beta && nBu > 0) dbeta_frame = in->shared_beta ? g->d_A : g->d_beta;  // d_A is free again
+        const size_t lds = ((size_t)J * 18 + 16) * sizeof(float);
+        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(256), lds, stream, g->d_verts, g->d_joints,
+                           m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
+                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, V, J, nBu, regress);
+        SMIL_LAUNCH_CHECK();
+        if (dbeta_frame && in->shared_beta) {
+            int rc = smil_reduce_rows(dbeta_frame, g->d_beta, B, nBu, stream);
+            if (rc) return rc;
+        }
+    }
+    return SMIL_OK;
+}

@@ -1,0 +1,156 @@
+// FoV-perspective cameras: world -> view -> NDC -> screen, forward and backward.
+//
+// Replaces (reference): smal_fitter/p3d_renderer.py:34-38,112-120 (FoVPerspectiveCameras set-up),
+// :137 (transform_points_screen(...)[..., [1,0]]) and the vertex transform pytorch3d's MeshRasterizer
+// applies before rasterising (:145).  Arithmetic restated from pytorch3d 0.7.x (un-vendored):
+//   X_view = X_world R + T ;  x_ndc = X_view.x K00 / z , y_ndc = X_view.y K11 / z , z = X_view.z
+//   K00 = 2 znear / (2 aspect tan(fov/2) znear) , K11 = 2 znear / (2 tan(fov/2) znear)
+//   x_s = S/2 - (S/2) x_ndc ; y_s likewise ; the reference returns (y_s, x_s).
+#include "common.h"
+
+#define SMIL_ZNEAR 0.001f  // Renderer.DEFAULT_ZNEAR (p3d_renderer.py:24)
+
+struct CamParams {
+    float R[9];
+    float T[3];
+    float k00, k11, tanh_;  // tan(fov/2)
+};
+
+__device__ __forceinline__ CamParams load_camera(const SmilCameras &c, int n) {
+    CamParams p;
+    const float *R = c.R + (size_t)(n % c.nR) * 9;
+    const float *T = c.T + (size_t)(n % c.nT) * 3;
+    for (int i = 0; i < 9; ++i) p.R[i] = R[i];
+    for (int i = 0; i < 3; ++i) p.T[i] = T[i];
+    const float fov = c.fov[n % c.nFov];
+    const float asp = c.aspect ? c.aspect[n % c.nAspect] : 1.0f;
+    const float t = tanf((fov * 0.017453292519943295f) / 2.0f);
+    const float max_y = t * SMIL_ZNEAR;
+    const float max_x = max_y * asp;
+    p.k00 = 2.0f * SMIL_ZNEAR / (max_x - (-max_x));
+    p.k11 = 2.0f * SMIL_ZNEAR / (max_y - (-max_y));
+    p.tanh_ = t;
+    return p;
+}
+
+// grid (ceil(P/256), N)
+__global__ void __launch_bounds__(256) k_project(SmilCameras c, const float *__restrict__ pts, int P,
+                                                 float *__restrict__ ndc, float *__restrict__ yx) {
+    const int n = blockIdx.y;
+    const int b = n / c.views;
+    const CamParams cp = load_camera(c, n);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float *X = pts + ((size_t)b * P + p) * 3;
+    const float x = X[0], y = X[1], z = X[2];
+    const float vx = x * cp.R[0] + y * cp.R[3] + z * cp.R[6] + cp.T[0];
+    const float vy = x * cp.R[1] + y * cp.R[4] + z * cp.R[7] + cp.T[1];
+    const float vz = x * cp.R[2] + y * cp.R[5] + z * cp.R[8] + cp.T[2];
+    const float xn = vx * cp.k00 / vz;
+    const float yn = vy * cp.k11 / vz;
+    const size_t o = (size_t)n * P + p;
+    if (ndc) { ndc[o * 3] = xn; ndc[o * 3 + 1] = yn; ndc[o * 3 + 2] = vz; }
+    if (yx) {
+        const float h = 0.5f * (float)c.S;
+        yx[o * 2] = h - h * yn;
+        yx[o * 2 + 1] = h - h * xn;
+    }
+}
+
+extern "C" int smil_project(const SmilCameras *cam, const float *pts, int32_t P, float *ndc, float *yx, void *stream) {
+    SMIL_REQUIRE(cam && pts, "smil_project: null argument");
+    SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && P > 0 && cam->S > 0,
+                 "smil_project: bad sizes N=%d views=%d P=%d S=%d", cam->N, cam->views, P, cam->S);
+    SMIL_REQUIRE(cam->R && cam->T && cam->fov && cam->nR > 0 && cam->nT > 0 && cam->nFov > 0, "smil_project: camera tables missing");
+    SMIL_REQUIRE(!cam->aspect || cam->nAspect > 0, "smil_project: aspect table empty");
+    dim3 grid(ceil_div(P, 256), cam->N);
+    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, (hipStream_t)stream, *cam, pts, P, ndc, yx);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+// grid (ceil(P/256), frames): each thread owns one world point and walks the views of its frame, so
+// d_pts needs no atomics; the per-image fov term is block-reduced and added once per block.
+__global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, const float *__restrict__ pts, int P,
+                                                     const float *__restrict__ d_ndc, const float *__restrict__ d_yx,
+                                                     float *__restrict__ d_pts, float *__restrict__ d_fov_img,
+                                                     int accumulate) {
+    __shared__ float red[16];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < P;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) {
+        const float *X = pts + ((size_t)b * P + p) * 3;
+        x = X[0]; y = X[1]; z = X[2];
+    }
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int v = 0; v < c.views; ++v) {
+        const int n = b * c.views + v;
+        const CamParams cp = load_camera(c, n);
+        float fsum = 0.f;
+        if (live) {
+            const float vx = x * cp.R[0] + y * cp.R[3] + z * cp.R[6] + cp.T[0];
+            const float vy = x * cp.R[1] + y * cp.R[4] + z * cp.R[7] + cp.T[1];
+            const float vz = x * cp.R[2] + y * cp.R[5] + z * cp.R[8] + cp.T[2];
+            const float iz = 1.0f / vz;
+            const float xn = vx * cp.k00 * iz, yn = vy * cp.k11 * iz;
+            const size_t o = (size_t)n * P + p;
+            float dxn = 0.f, dyn = 0.f;
+            if (d_ndc) { dxn = d_ndc[o * 2]; dyn = d_ndc[o * 2 + 1]; }
+            if (d_yx) {
+                const float h = 0.5f * (float)c.S;
+                dyn -= h * d_yx[o * 2];
+                dxn -= h * d_yx[o * 2 + 1];
+            }
+            const float dvx = dxn * cp.k00 * iz, dvy = dyn * cp.k11 * iz;
+            const float dvz = -(xn * dxn + yn * dyn) * iz;
+            gx += cp.R[0] * dvx + cp.R[1] * dvy + cp.R[2] * dvz;
+            gy += cp.R[3] * dvx + cp.R[4] * dvy + cp.R[5] * dvz;
+            gz += cp.R[6] * dvx + cp.R[7] * dvy + cp.R[8] * dvz;
+            fsum = dxn * xn + dyn * yn;
+        }
+        if (d_fov_img) {
+            const float r = block_sum(fsum, red);
+            if (threadIdx.x == 0 && r != 0.f) atomicAdd(&d_fov_img[n], r);
+        }
+    }
+    if (live && d_pts) {
+        float *o = d_pts + ((size_t)b * P + p) * 3;
+        if (accumulate) { o[0] += gx; o[1] += gy; o[2] += gz; }
+        else { o[0] = gx; o[1] = gy; o[2] = gz; }
+    }
+}
+
+extern "C" int smil_project_backward(const SmilCameras *cam, const float *pts, int32_t P, const float *d_ndc,
+                                     const float *d_yx, float *d_pts, float *d_fov_img, int32_t accumulate, void *stream) {
+    SMIL_REQUIRE(cam && pts, "smil_project_backward: null argument");
+    SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && P > 0, "smil_project_backward: bad sizes");
+    SMIL_REQUIRE(d_ndc || d_yx, "smil_project_backward: no upstream gradient");
+    dim3 grid(ceil_div(P, 256), cam->N / cam->views);
+    hipLaunchKernelGGL(k_project_bwd, grid, dim3(256), 0, (hipStream_t)stream, *cam, pts, P, d_ndc, d_yx, d_pts, d_fov_img,
+                       accumulate);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+// d fov_deg[c] = sum_{n = c mod nFov}  -(pi/360) (1 + t^2)/t * d_fov_img[n]      (x_ndc, y_ndc ~ 1/t)
+__global__ void k_fov_reduce(SmilCameras c, const float *__restrict__ d_fov_img, float *__restrict__ d_fov) {
+    __shared__ float red[16];
+    const int col = blockIdx.x;
+    float acc = 0.f;
+    for (int n = col + threadIdx.x * c.nFov; n < c.N; n += blockDim.x * c.nFov) acc += d_fov_img[n];
+    const float r = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float t = tanf((c.fov[col] * 0.017453292519943295f) / 2.0f);
+        d_fov[col] = -(0.008726646259971648f) * (1.0f + t * t) / t * r;
+    }
+}
+
+extern "C" int smil_fov_reduce(const SmilCameras *cam, const float *d_fov_img, float *d_fov, void *stream) {
+    SMIL_REQUIRE(cam && d_fov_img && d_fov, "smil_fov_reduce: null argument");
+    SMIL_REQUIRE(cam->nFov > 0 && cam->N % cam->nFov == 0, "smil_fov_reduce: N=%d not a multiple of nFov=%d", cam->N, cam->nFov);
+    hipLaunchKernelGGL(k_fov_reduce, dim3(cam->nFov), dim3(256), 0, (hipStream_t)stream, *cam, d_fov_img, d_fov);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}

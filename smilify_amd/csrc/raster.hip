@@ -1,0 +1,541 @@
+// Soft-silhouette rasteriser for gfx950: forward, backward and fused forward+L1+backward.
+//
+// Replaces (reference): smal_fitter/p3d_renderer.py:41-52,142-146 - MeshRasterizer(bin_size=0,
+// faces_per_pixel=100, blur_radius=log(1/1e-4-1)*1e-4, perspective-correct, clipped barycentrics) +
+// SoftSilhouetteShader (sigmoid_alpha_blend) - and, in the fused entry point, the silhouette L1 term of
+// SMALFitter.forward (fitter.py:332-333) with its gradient.  The per-(pixel,face) arithmetic restates
+// pytorch3d 0.7.x (un-vendored): CheckPixelInsideFace / RasterizeMeshesBackward / geometry_utils.
+//
+// Design (see DESIGN.md "raster"):
+//  * The reference visits all F faces for all S^2 pixels and stores (S,S,K) fragments in HBM
+//    (157 MB / image at 256^2).  Here nothing per-fragment ever reaches HBM.
+//  * k_raster_setup (one workgroup per image): per-face validity + blurred bbox in 8x8-pixel tile
+//    units (4 x u8 packed), a tile-occupancy bitmap in LDS, and the compacted list of touched tiles
+//    appended to a global work list.  Untouched tiles are never visited (their silhouette is 0).
+//  * k_raster_tiles (persistent, one 64-lane wavefront = one 8x8 tile, lane = pixel): dequeues work
+//    items, compacts the face ids whose bbox meets the tile (ballot prefix -> order preserved), stages
+//    their vertices through LDS in chunks of 64 and streams them to all 64 pixels (LDS broadcast reads).
+//      pass 1: candidate count, product of all candidates and a per-pixel max-heap (in LDS, 4 B/entry)
+//              of the K smallest depths;  pixels with <= K candidates are done.
+//      pass 2: (only if some pixel has > K candidates) product over the K nearest: depth < t, plus the
+//              first r faces (ascending face id) with depth == t, t = K-th smallest depth.
+//      pass 3: (backward / fused) per-face gradient, wave-reduced with DPP, 6 atomics per face.
+//  * Deviation from the reference kept on purpose: ties at the K-th depth are resolved by face id, the
+//    reference's unsorted-queue eviction depends on visiting history (measured effect on the L1 loss:
+//    ~1e-5 relative, tests/test_raster_parity.py).
+#include "common.h"
+
+#define TILE 8
+#define LIST_CAP 1024       // face ids per list segment (LDS)
+#define FCHUNK 64           // faces staged per chunk
+#define FREC 24             // floats per staged face record
+#define K_EPS 1e-8f
+#define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
+
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
+
+struct RasterCounters {
+    unsigned int n_items;
+    unsigned int next;
+};
+
+struct RasterArgs {
+    const float *verts_ndc;  // (N,V,3)
+    const int *faces;        // (F,3)
+    const uint32_t *tbox;    // (N,F)
+    const uint32_t *items;   // work list
+    RasterCounters *ctr;
+    int N, V, F, S, tiles_x, K;
+    float blur, sqrt_blur, inv_sigma;
+    // outputs / inputs per mode
+    float *sil;              // (N,S,S) FWD (or optional in FUSED)
+    const float *grad_sil;   // BWD
+    const float *target;     // FUSED
+    const float *pix_scale;  // FUSED (N,)
+    float *loss_img;         // FUSED (N,)
+    float *d_ndc;            // (N,V,2)
+};
+
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// setup: per-face tile boxes + touched-tile work list
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
+                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ items,
+                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x,
+                                                      float sqrt_blur) {
+    extern __shared__ uint32_t bitmap[];  // tiles_x*tiles_x bits, then 256 scan slots
+    const int n = blockIdx.x;
+    const int n_tiles = tiles_x * tiles_x;
+    const int n_words = (n_tiles + 31) >> 5;
+    uint32_t *scan = bitmap + n_words;
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) bitmap[i] = 0u;
+    __syncthreads();
+    const float *vn = verts_ndc + (size_t)n * V * 3;
+    const float fS = (float)S;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+        const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
+        const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
+        const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
+        uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
+        const float zmin = fminf(fminf(z0, z1), z2);
+        const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+        const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
+        if (finite && !(zmin < K_EPS) && !(area <= K_EPS && area >= -K_EPS)) {
+            const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
+            const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
+            // pixel index i (flipped axis) has centre -1 + (2i+1)/S ; widen by one pixel against rounding
+            int xi_lo = (int)floorf(((xlo + 1.0f) * fS - 1.0f) * 0.5f) - 1, xi_hi = (int)ceilf(((xhi + 1.0f) * fS - 1.0f) * 0.5f) + 1;
+            int yi_lo = (int)floorf(((ylo + 1.0f) * fS - 1.0f) * 0.5f) - 1, yi_hi = (int)ceilf(((yhi + 1.0f) * fS - 1.0f) * 0.5f) + 1;
+            xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
+            xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
+            if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
+                // output column xo = S-1-xi
+                const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
+                const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
+                box = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        const int t = ty * tiles_x + tx;
+                        atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+                    }
+            }
+        }
+        tbox[(size_t)n * F + f] = box;
+    }
+    __syncthreads();
+    // ordered compaction of touched tiles -> global work list
+    uint32_t mine = 0;
+    for (int w = threadIdx.x; w < n_words; w += blockDim.x) mine += __popc(bitmap[w]);
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    __shared__ uint32_t base_slot;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) { const uint32_t c = scan[i]; scan[i] = run; run += c; }
+        base_slot = run ? atomicAdd(&ctr->n_items, run) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = base_slot + scan[threadIdx.x];
+    for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+        uint32_t bits = bitmap[w];
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            items[pos++] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)(w * 32 + bit);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-(pixel, face) evaluation
+// ---------------------------------------------------------------------------------------------
+struct FaceRec {  // staged in LDS, FREC floats
+    float x0, y0, x1, y1;
+    float x2, y2, z0, z1;
+    float z2, rcp_area, rl01, rl02;
+    float rl12, xmin, xmax, ymin;
+    float ymax, z12, z02, z01;
+    int fid, i0, i1, i2;
+};
+
+__device__ __forceinline__ float seg_d2(float px, float py, float ax, float ay, float bx, float by, float rl2) {
+    const float bax = bx - ax, bay = by - ay;
+    if (rl2 < 0.f) {  // degenerate edge (|b-a|^2 <= 1e-8): distance to b
+        const float dx = px - bx, dy = py - by;
+        return dx * dx + dy * dy;
+    }
+    float t = (bax * (px - ax) + bay * (py - ay)) * rl2;
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    const float dx = (ax + t * bax) - px, dy = (ay + t * bay) - py;
+    return dx * dx + dy * dy;
+}
+
+struct Cand {
+    float pz, sd;   // clipped-barycentric depth, signed squared distance
+    bool inside;
+};
+
+template <bool WANT_PZ>
+__device__ __forceinline__ bool eval_face(const FaceRec &f, float px, float py, float blur, Cand &c) {
+    if (px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin) return false;
+    const float b0 = edge_fn(px, py, f.x1, f.y1, f.x2, f.y2) * f.rcp_area;
+    const float b1 = edge_fn(px, py, f.x2, f.y2, f.x0, f.y0) * f.rcp_area;
+    const float b2 = edge_fn(px, py, f.x0, f.y0, f.x1, f.y1) * f.rcp_area;
+    const float w0 = b0 * f.z12, w1 = b1 * f.z02, w2 = b2 * f.z01;
+    const float den = fmaxf(w0 + w1 + w2, K_EPS);
+    const bool inside = (w0 > 0.f) && (w1 > 0.f) && (w2 > 0.f);  // sign(w_i/den) = sign(w_i), den > 0
+    const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
+    const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
+    const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
+    const float dist = fminf(fminf(d01, d02), d12);
+    if (!inside && dist >= blur) return false;
+    c.inside = inside;
+    c.sd = inside ? -dist : dist;
+    if (WANT_PZ) {
+        const float p0 = w0 / den, p1 = w1 / den, p2 = w2 / den;
+        float c0 = fmaxf(p0, 0.f), c1 = fmaxf(p1, 0.f), c2 = fmaxf(p2, 0.f);
+        const float cs = fmaxf(c0 + c1 + c2, 1e-5f);
+        c0 = c0 / cs; c1 = c1 / cs; c2 = c2 / cs;  // exact division: x/x == 1 keeps shared-vertex depth ties exact
+        c.pz = c0 * f.z0 + c1 * f.z1 + c2 * f.z2;
+    }
+    return true;
+}
+
+__device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
+    // sigmoid(-dist / sigma)
+    return 1.0f / (1.0f + expf(sd * inv_sigma));
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile kernel
+// ---------------------------------------------------------------------------------------------
+struct TileLds {
+    uint32_t list[LIST_CAP];
+    float rec[FCHUNK * FREC];
+};
+
+// Build the ordered list of faces of [seg0, seg1) whose tile box contains (tx,ty). Returns the count.
+__device__ __forceinline__ int build_list(const uint32_t *__restrict__ tbox_n, int seg0, int seg1, int tx, int ty,
+                                          uint32_t *list, int lane) {
+    int cnt = 0;
+    for (int base = seg0; base < seg1; base += WAVE) {
+        const int f = base + lane;
+        bool hit = false;
+        if (f < seg1) {
+            const uint32_t b = tbox_n[f];
+            const int tx0 = b & 0xFF, ty0 = (b >> 8) & 0xFF, tx1 = (b >> 16) & 0xFF, ty1 = b >> 24;
+            hit = (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)f;
+        cnt += __popcll(mask);
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list,
+                                            int c0, int m, float *rec, int lane) {
+    if (lane < m) {
+        const int f = (int)list[c0 + lane];
+        const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
+        FaceRec r;
+        r.x0 = vn[3 * i0]; r.y0 = vn[3 * i0 + 1]; r.z0 = vn[3 * i0 + 2];
+        r.x1 = vn[3 * i1]; r.y1 = vn[3 * i1 + 1]; r.z1 = vn[3 * i1 + 2];
+        r.x2 = vn[3 * i2]; r.y2 = vn[3 * i2 + 1]; r.z2 = vn[3 * i2 + 2];
+        const float area = edge_fn(r.x2, r.y2, r.x0, r.y0, r.x1, r.y1) + K_EPS;
+        r.rcp_area = 1.0f / area;
+        const float l01 = (r.x1 - r.x0) * (r.x1 - r.x0) + (r.y1 - r.y0) * (r.y1 - r.y0);
+        const float l02 = (r.x2 - r.x0) * (r.x2 - r.x0) + (r.y2 - r.y0) * (r.y2 - r.y0);
+        const float l12 = (r.x2 - r.x1) * (r.x2 - r.x1) + (r.y2 - r.y1) * (r.y2 - r.y1);
+        r.rl01 = l01 <= K_EPS ? -1.f : 1.0f / l01;
+        r.rl02 = l02 <= K_EPS ? -1.f : 1.0f / l02;
+        r.rl12 = l12 <= K_EPS ? -1.f : 1.0f / l12;
+        r.xmin = fminf(fminf(r.x0, r.x1), r.x2) - a.sqrt_blur; r.xmax = fmaxf(fmaxf(r.x0, r.x1), r.x2) + a.sqrt_blur;
+        r.ymin = fminf(fminf(r.y0, r.y1), r.y2) - a.sqrt_blur; r.ymax = fmaxf(fmaxf(r.y0, r.y1), r.y2) + a.sqrt_blur;
+        r.z12 = r.z1 * r.z2; r.z02 = r.z0 * r.z2; r.z01 = r.z0 * r.z1;
+        r.fid = f; r.i0 = i0; r.i1 = i1; r.i2 = i2;
+        *reinterpret_cast<FaceRec *>(rec + lane * FREC) = r;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_raster_tiles(RasterArgs a) {
+    extern __shared__ float dyn[];          // heap: K * 64 floats, entry-major
+    __shared__ TileLds lds;
+    float *heap = dyn;
+    const int lane = threadIdx.x;
+    const int K = a.K;
+    const int n_tiles = a.tiles_x * a.tiles_x;
+    const unsigned int n_items = a.ctr->n_items;
+
+    while (true) {
+        unsigned int item = 0;
+        if (lane == 0) item = atomicAdd(&a.ctr->next, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const uint32_t code = a.items[item];
+        const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
+        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
+        const bool in_img = xo < a.S && yo < a.S;
+        const float px = pix_to_ndc(a.S - 1 - xo, a.S), py = pix_to_ndc(a.S - 1 - yo, a.S);
+        const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
+        const uint32_t *tbox_n = a.tbox + (size_t)n * a.F;
+        const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
+
+        // ---------------- pass 1: count, product of all, K-smallest-depth heap -----------------
+        int cnt = 0;
+        float prod_all = 1.0f;
+        for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
+            const int seg1 = min(a.F, seg0 + LIST_CAP);
+            const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
+            __syncthreads();
+            for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
+                const int m = min(FCHUNK, ln - c0);
+                stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
+                __syncthreads();
+                if (in_img) {
+                    for (int i = 0; i < m; ++i) {
+                        const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                        Cand c;
+                        if (!eval_face<true>(f, px, py, a.blur, c)) continue;
+                        prod_all *= (1.0f - face_prob(c.sd, a.inv_sigma));
+                        const float z = c.pz;
+                        if (cnt < K) {  // sift-up insert
+                            int h = cnt;
+                            while (h > 0) {
+                                const int par = (h - 1) >> 1;
+                                const float zp = heap[par * WAVE + lane];
+                                if (zp < z) { heap[h * WAVE + lane] = zp; h = par; } else break;
+                            }
+                            heap[h * WAVE + lane] = z;
+                        } else if (z < heap[lane]) {  // replace the maximum, sift down
+                            int h = 0;
+                            while (true) {
+                                int ch = 2 * h + 1;
+                                if (ch >= K) break;
+                                float zc = heap[ch * WAVE + lane];
+                                if (ch + 1 < K) {
+                                    const float zr = heap[(ch + 1) * WAVE + lane];
+                                    if (zr > zc) { zc = zr; ch = ch + 1; }
+                                }
+                                if (zc > z) { heap[h * WAVE + lane] = zc; h = ch; } else break;
+                            }
+                            heap[h * WAVE + lane] = z;
+                        }
+                        ++cnt;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const bool trunc = cnt > K;
+        float alpha = prod_all;
+        float zt = 3.0e38f;  // depth threshold (K-th smallest)
+        int r_ties = 0;
+        if (__ballot(trunc) != 0ull) {
+            if (trunc) {
+                zt = heap[lane];
+                for (int e = 0; e < K; ++e) r_ties += (heap[e * WAVE + lane] == zt) ? 1 : 0;
+            }
+            // ------------- pass 2: product over the K nearest for truncated pixels ---------------
+            float prod = 1.0f;
+            int ties = 0;
+            for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
+                const int seg1 = min(a.F, seg0 + LIST_CAP);
+                const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
+                __syncthreads();
+                for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
+                    const int m = min(FCHUNK, ln - c0);
+                    stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
+                    __syncthreads();
+                    if (trunc && prod != 0.0f) {
+                        for (int i = 0; i < m; ++i) {
+                            const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                            Cand c;
+                            if (!eval_face<true>(f, px, py, a.blur, c)) continue;
+                            bool keep = c.pz < zt;
+                            if (c.pz == zt && ties < r_ties) { keep = true; ++ties; }
+                            if (keep) prod *= (1.0f - face_prob(c.sd, a.inv_sigma));
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (trunc) alpha = prod;
+        }
+
+        // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
+        const float silv = 1.0f - alpha;
+        float g = 0.f;
+        if (MODE == MODE_FWD) {
+            if (in_img) a.sil[pix] = silv;
+        } else if (MODE == MODE_BWD) {
+            if (in_img) g = a.grad_sil[pix];
+        } else {
+            float lsum = 0.f;
+            if (in_img) {
+                const float tg = a.target[pix];
+                const float diff = silv - tg;
+                lsum = fabsf(diff) - fabsf(tg);  // loss_img starts at sum |0 - target|
+                g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+                if (a.sil) a.sil[pix] = silv;
+            }
+            lsum = wave_sum(lsum);
+            if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
+        }
+        if (MODE == MODE_FWD) continue;
+
+        // ---------------- pass 3: gradients ------------------------------------------------------
+        // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
+        const float coef = -g * alpha * a.inv_sigma;
+        const bool active = in_img && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
+        if (__ballot(active) == 0ull) continue;
+        float *dn = a.d_ndc + (size_t)n * a.V * 2;
+        int ties = 0;
+        for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
+            const int seg1 = min(a.F, seg0 + LIST_CAP);
+            const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
+            __syncthreads();
+            for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
+                const int m = min(FCHUNK, ln - c0);
+                stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
+                __syncthreads();
+                for (int i = 0; i < m; ++i) {
+                    const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                    float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
+                    bool contrib = false;
+                    Cand c;
+                    if (active && eval_face<true>(f, px, py, a.blur, c)) {
+                        bool keep = true;
+                        if (trunc) {
+                            keep = c.pz < zt;
+                            if (c.pz == zt && ties < r_ties) { keep = true; ++ties; }
+                        }
+                        if (keep) {
+                            const float pk = face_prob(c.sd, a.inv_sigma);
+                            float gd = coef * pk;          // d L / d (signed dist)
+                            gd = c.inside ? -gd : gd;       // d L / d (unsigned squared distance)
+                            if (gd != 0.f) {
+                                const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
+                                const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
+                                const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
+                                float ax, ay, bx, by;
+                                int e;
+                                if (d01 <= d02 && d01 <= d12) { ax = f.x0; ay = f.y0; bx = f.x1; by = f.y1; e = 0; }
+                                else if (d02 <= d01 && d02 <= d12) { ax = f.x0; ay = f.y0; bx = f.x2; by = f.y2; e = 1; }
+                                else { ax = f.x1; ay = f.y1; bx = f.x2; by = f.y2; e = 2; }
+                                const float bax = bx - ax, bay = by - ay;
+                                float t = (bax * (px - ax) + bay * (py - ay)) / (bax * bax + bay * bay);
+                                t = (t == t) ? fminf(fmaxf(t, 0.f), 1.f) : 0.f;
+                                const float qx = (1.0f - t) * ax + t * bx, qy = (1.0f - t) * ay + t * by;
+                                const float ex = 2.0f * (qx - px), ey = 2.0f * (qy - py);
+                                const float gax = gd * (1.0f - t) * ex, gay = gd * (1.0f - t) * ey;
+                                const float gbx = gd * t * ex, gby = gd * t * ey;
+                                if (e == 0) { g0x = gax; g0y = gay; g1x = gbx; g1y = gby; }
+                                else if (e == 1) { g0x = gax; g0y = gay; g2x = gbx; g2y = gby; }
+                                else { g1x = gax; g1y = gay; g2x = gbx; g2y = gby; }
+                                contrib = true;
+                            }
+                        }
+                    }
+                    if (__ballot(contrib) == 0ull) continue;
+                    g0x = wave_sum(g0x); g0y = wave_sum(g0y);
+                    g1x = wave_sum(g1x); g1y = wave_sum(g1y);
+                    g2x = wave_sum(g2x); g2y = wave_sum(g2y);
+                    if (lane == 0) {
+                        if (g0x != 0.f) atomicAdd(&dn[2 * f.i0], g0x);
+                        if (g0y != 0.f) atomicAdd(&dn[2 * f.i0 + 1], g0y);
+                        if (g1x != 0.f) atomicAdd(&dn[2 * f.i1], g1x);
+                        if (g1y != 0.f) atomicAdd(&dn[2 * f.i1 + 1], g1y);
+                        if (g2x != 0.f) atomicAdd(&dn[2 * f.i2], g2x);
+                        if (g2y != 0.f) atomicAdd(&dn[2 * f.i2 + 1], g2y);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
+    if (!m || N <= 0 || S <= 0) return 0;
+    const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
+    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t));
+}
+
+static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
+                         void *workspace, hipStream_t stream, RasterArgs &a) {
+    SMIL_REQUIRE(m && verts_ndc && rs && workspace, "raster: null argument");
+    SMIL_REQUIRE(N > 0 && S > 0 && S <= TILE * 256, "raster: bad sizes N=%d S=%d", N, S);
+    SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
+                 "raster: faces_per_pixel=%d outside 1..%d", rs->faces_per_pixel, SMIL_MAX_FACES_PER_PIXEL);
+    SMIL_REQUIRE(rs->sigma > 0.f && rs->blur_radius >= 0.f, "raster: bad blend settings");
+    const int tiles_x = ceil_div(S, TILE);
+    SMIL_REQUIRE((double)N * tiles_x * tiles_x < 4294967295.0, "raster: N * tiles exceeds the 32-bit work-item code");
+    char *ws = (char *)workspace;
+    uint32_t *tbox = (uint32_t *)ws;
+    ws += align256((size_t)N * m->F * sizeof(uint32_t));
+    RasterCounters *ctr = (RasterCounters *)ws;
+    ws += 256;
+    uint32_t *items = (uint32_t *)ws;
+    SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
+    const float sqrt_blur = sqrtf(rs->blur_radius);
+    const int n_words = (tiles_x * tiles_x + 31) / 32;
+    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), (size_t)(n_words + 256) * sizeof(uint32_t), stream, verts_ndc,
+                       m->faces, tbox, items, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+    SMIL_LAUNCH_CHECK();
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.items = items; a.ctr = ctr;
+    a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
+    a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
+    a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr; a.d_ndc = nullptr;
+    return SMIL_OK;
+}
+
+static int tile_grid(int N, int tiles_x) {
+    const long long max_items = (long long)N * tiles_x * tiles_x;
+    const long long resident = 256LL * 5;  // 256 CUs x blocks per CU admitted by the LDS footprint
+    return (int)(max_items < resident ? max_items : resident);
+}
+
+extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
+                                       const SmilRasterSettings *rs, float *sil, void *workspace, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    RasterArgs a;
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a);
+    if (rc) return rc;
+    SMIL_REQUIRE(sil, "smil_silhouette_forward: null output");
+    SMIL_HIP(hipMemsetAsync(sil, 0, (size_t)N * S * S * sizeof(float), stream));
+    a.sil = sil;
+    hipLaunchKernelGGL(k_raster_tiles<MODE_FWD>, dim3(tile_grid(N, a.tiles_x)), dim3(64), (size_t)a.K * WAVE * sizeof(float),
+                       stream, a);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
+                                        const SmilRasterSettings *rs, const float *grad_sil, float *d_ndc,
+                                        void *workspace, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    RasterArgs a;
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a);
+    if (rc) return rc;
+    SMIL_REQUIRE(grad_sil && d_ndc, "smil_silhouette_backward: null argument");
+    SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
+    a.grad_sil = grad_sil; a.d_ndc = d_ndc;
+    hipLaunchKernelGGL(k_raster_tiles<MODE_BWD>, dim3(tile_grid(N, a.tiles_x)), dim3(64), (size_t)a.K * WAVE * sizeof(float),
+                       stream, a);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
+                                        const SmilRasterSettings *rs, const float *target, const float *target_sum,
+                                        const float *pix_scale, float *loss_img, float *d_ndc, float *sil_out,
+                                        void *workspace, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    RasterArgs a;
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a);
+    if (rc) return rc;
+    SMIL_REQUIRE(target && target_sum && pix_scale && loss_img && d_ndc, "smil_silhouette_l1_fused: null argument");
+    SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
+    SMIL_HIP(hipMemcpyAsync(loss_img, target_sum, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
+    a.target = target; a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
+    hipLaunchKernelGGL(k_raster_tiles<MODE_FUSED>, dim3(tile_grid(N, a.tiles_x)), dim3(64),
+                       (size_t)a.K * WAVE * sizeof(float), stream, a);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}

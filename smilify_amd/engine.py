@@ -1,0 +1,323 @@
+"""Thin torch-tensor front end over the C ABI (include/smilfit.h).
+
+PyTorch is used for device memory, streams and autograd plumbing only; every arithmetic step of the hot
+path is a HIP kernel inside ``libsmilfit.so``.  All functions launch on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model_io import SmilModelTables
+
+# Renderer settings of the reference (smal_fitter/p3d_renderer.py:24-25,41-47)
+SIGMA = 1e-4
+BLUR_RADIUS = float(np.log(1.0 / 1e-4 - 1.0) * 1e-4)
+FACES_PER_PIXEL = 100
+ZNEAR, ZFAR = 0.001, 1000.0
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.SmilError(f"smilify_amd runs on an AMD GPU only (got device '{device}'); there is no CPU path")
+    if not torch.cuda.is_available():
+        raise _lib.SmilError("no GPU visible to PyTorch-ROCm; smilify_amd has no CPU fallback")
+    return device
+
+
+class DeviceModel:
+    """Model constants resident on one GPU (``SmilModel*``)."""
+
+    def __init__(self, tables: SmilModelTables, device):
+        self.device = require_gpu(device)
+        self.tables = tables
+        lib = _lib.load()
+        t = tables
+        arrs = dict(
+            v_template=np.ascontiguousarray(t.v_template, np.float32),
+            shapedirs=np.ascontiguousarray(t.shapedirs, np.float32),
+            faces=np.ascontiguousarray(t.faces, np.int32),
+            parents=np.ascontiguousarray(t.parents, np.int32),
+            skin_idx=np.ascontiguousarray(t.skin_idx, np.int32),
+            skin_w=np.ascontiguousarray(t.skin_w, np.float32),
+            jreg_rowptr=np.ascontiguousarray(t.jreg_rowptr, np.int32),
+            jreg_col=np.ascontiguousarray(t.jreg_col, np.int32),
+            jreg_val=np.ascontiguousarray(t.jreg_val, np.float32),
+        )
+        if t.static_joints:
+            arrs["J_static"] = np.ascontiguousarray(t.J_static, np.float32)
+        d = _lib.ModelDesc()
+        d.V, d.F, d.J, d.nB = t.V, t.F, t.J, t.nB
+        for k, a in arrs.items():
+            setattr(d, k, a.ctypes.data if a.size else None)
+        d.static_joints = 1 if t.static_joints else 0
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.smil_model_create(ctypes.byref(d), ctypes.byref(handle)), "smil_model_create")
+        self.handle = handle
+        self.V, self.F, self.J, self.nB = t.V, t.F, t.J, t.nB
+        self.static_joints = bool(t.static_joints)
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().smil_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace(self, N: int, S: int) -> torch.Tensor:
+        need = int(_lib.load().smil_raster_workspace_bytes(self.handle, N, S))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+
+@dataclass
+class CameraSet:
+    """FoV-perspective cameras; tables with k rows are indexed ``image % k`` (k = 1, views or N)."""
+
+    R: torch.Tensor  # (nR,3,3)
+    T: torch.Tensor  # (nT,3)
+    fov: torch.Tensor  # (nFov,) degrees
+    aspect: Optional[torch.Tensor]
+    views: int
+    S: int
+
+    def struct(self, N: int) -> _lib.Cameras:
+        c = _lib.Cameras()
+        c.N, c.views, c.S = N, self.views, self.S
+        c.R, c.nR = self.R.data_ptr(), self.R.shape[0]
+        c.T, c.nT = self.T.data_ptr(), self.T.shape[0]
+        c.fov, c.nFov = self.fov.data_ptr(), self.fov.numel()
+        if self.aspect is not None:
+            c.aspect, c.nAspect = self.aspect.data_ptr(), self.aspect.numel()
+        else:
+            c.aspect, c.nAspect = None, 0
+        for name, k in (("R", c.nR), ("T", c.nT), ("fov", c.nFov)):
+            if k not in (1, self.views, N):
+                raise _lib.SmilError(f"camera table {name} has {k} rows; expected 1, views={self.views} or N={N}")
+        return c
+
+
+def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL) -> _lib.RasterSettings:
+    rs = _lib.RasterSettings()
+    rs.blur_radius, rs.sigma, rs.faces_per_pixel, rs.z_clip = blur, sigma, K, ZNEAR / 2
+    return rs
+
+
+# ----------------------------------------------------------------------------------------------
+# LBS
+# ----------------------------------------------------------------------------------------------
+def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btrans=None, del_v=None,
+                v_template=None, Rs_in=None, shared_beta=False, logscale_shared=False, btrans_shared=False,
+                propagate_scaling=False, allow_limb_scaling=True) -> Dict[str, torch.Tensor]:
+    dev = model.device
+    B = int((theta if theta is not None else Rs_in).shape[0])
+    J, V = model.J, model.V
+    nB_used = int(beta.shape[-1])
+    nS = 1 if (shared_beta and del_v is None) else B
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    out = dict(v_shaped=f(nS, V, 3), J_rest=f(nS, J, 3), Rs=f(B, J, 3, 3), G=f(B, J, 3, 4), A=f(B, J, 3, 4),
+               new_J=f(B, J, 3), verts=f(B, V, 3), joints=f(B, J, 3))
+    inp = dict(beta=beta, theta=theta, Rs_in=Rs_in, logscale=logscale, btrans=btrans, trans=trans, del_v=del_v,
+               v_template=v_template)
+    i = _lib.LbsInputs()
+    i.B, i.shared_beta, i.nB_used = B, int(shared_beta), nB_used
+    i.logscale_shared, i.btrans_shared = int(logscale_shared), int(btrans_shared)
+    i.propagate_scaling, i.allow_limb_scaling = int(propagate_scaling), int(allow_limb_scaling)
+    for k, t in inp.items():
+        setattr(i, k, None if t is None else t.data_ptr())
+    o = _lib.LbsOutputs()
+    for k, t in out.items():
+        setattr(o, k, t.data_ptr())
+    _lib.check(_lib.load().smil_lbs_forward(model.handle, ctypes.byref(i), ctypes.byref(o), _stream()), "smil_lbs_forward")
+    out["_inputs"] = inp
+    out["_flags"] = dict(B=B, shared_beta=shared_beta, nB_used=nB_used, logscale_shared=logscale_shared,
+                         btrans_shared=btrans_shared, propagate_scaling=propagate_scaling,
+                         allow_limb_scaling=allow_limb_scaling)
+    return out
+
+
+def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=True, need_theta=True,
+                 need_logscale=True, need_btrans=True, need_trans=True) -> Dict[str, Optional[torch.Tensor]]:
+    dev = model.device
+    inp, fl = saved["_inputs"], saved["_flags"]
+    B, J = fl["B"], model.J
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g = dict(d_beta=None, d_theta=None, d_logscale=None, d_btrans=None, d_trans=None)
+    if need_beta and fl["nB_used"] > 0:
+        g["d_beta"] = f(fl["nB_used"]) if fl["shared_beta"] else f(B, fl["nB_used"])
+    if need_theta and inp["theta"] is not None:
+        g["d_theta"] = f(B, J, 3)
+    if need_logscale and inp["logscale"] is not None and fl["allow_limb_scaling"]:
+        g["d_logscale"] = f(J, 3) if fl["logscale_shared"] else f(B, J, 3)
+    if need_btrans and inp["btrans"] is not None:
+        g["d_btrans"] = f(J, 3) if fl["btrans_shared"] else f(B, J, 3)
+    if need_trans:
+        g["d_trans"] = f(B, 3)
+    scratch = dict(d_A=f(B, J, 12), d_Jrest=f(B, J, 3), d_Rs=f(B, J, 9))
+    i = _lib.LbsInputs()
+    i.B, i.shared_beta, i.nB_used = B, int(fl["shared_beta"]), fl["nB_used"]
+    i.logscale_shared, i.btrans_shared = int(fl["logscale_shared"]), int(fl["btrans_shared"])
+    i.propagate_scaling, i.allow_limb_scaling = int(fl["propagate_scaling"]), int(fl["allow_limb_scaling"])
+    for k, t in inp.items():
+        setattr(i, k, None if t is None else t.data_ptr())
+    o = _lib.LbsOutputs()
+    for k in ("v_shaped", "J_rest", "Rs", "G", "A", "new_J", "verts", "joints"):
+        setattr(o, k, saved[k].data_ptr())
+    gs = _lib.LbsGrads()
+    gs.d_verts = None if d_verts is None else d_verts.data_ptr()
+    gs.d_joints = None if d_joints is None else d_joints.data_ptr()
+    for k, t in {**g, **scratch}.items():
+        setattr(gs, k, None if t is None else t.data_ptr())
+    _lib.check(_lib.load().smil_lbs_backward(model.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(gs), _stream()),
+               "smil_lbs_backward")
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+# projection
+# ----------------------------------------------------------------------------------------------
+def project(cams: CameraSet, pts: torch.Tensor, want_ndc=True, want_yx=True):
+    frames, P = pts.shape[0], pts.shape[1]
+    N = frames * cams.views
+    ndc = torch.empty(N, P, 3, dtype=torch.float32, device=pts.device) if want_ndc else None
+    yx = torch.empty(N, P, 2, dtype=torch.float32, device=pts.device) if want_yx else None
+    c = cams.struct(N)
+    _lib.check(_lib.load().smil_project(ctypes.byref(c), _ptr(pts), P, _ptr(ndc), _ptr(yx), _stream()), "smil_project")
+    return ndc, yx
+
+
+def project_backward(cams: CameraSet, pts: torch.Tensor, d_ndc=None, d_yx=None, d_pts=None, d_fov_img=None,
+                     accumulate=False):
+    frames, P = pts.shape[0], pts.shape[1]
+    N = frames * cams.views
+    if d_pts is None:
+        d_pts = torch.empty_like(pts)
+        accumulate = False
+    if d_fov_img is None:
+        d_fov_img = torch.zeros(N, dtype=torch.float32, device=pts.device)
+    c = cams.struct(N)
+    _lib.check(_lib.load().smil_project_backward(ctypes.byref(c), _ptr(pts), P, _ptr(d_ndc), _ptr(d_yx), _ptr(d_pts),
+                                                 _ptr(d_fov_img), int(accumulate), _stream()), "smil_project_backward")
+    return d_pts, d_fov_img
+
+
+def fov_reduce(cams: CameraSet, d_fov_img: torch.Tensor) -> torch.Tensor:
+    N = d_fov_img.numel()
+    d_fov = torch.empty(cams.fov.numel(), dtype=torch.float32, device=d_fov_img.device)
+    c = cams.struct(N)
+    _lib.check(_lib.load().smil_fov_reduce(ctypes.byref(c), _ptr(d_fov_img), _ptr(d_fov), _stream()), "smil_fov_reduce")
+    return d_fov
+
+
+# ----------------------------------------------------------------------------------------------
+# silhouette
+# ----------------------------------------------------------------------------------------------
+def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=None) -> torch.Tensor:
+    rs = rs or raster_settings()
+    N = verts_ndc.shape[0]
+    sil = torch.empty(N, S, S, dtype=torch.float32, device=verts_ndc.device)
+    ws = model.workspace(N, S)
+    _lib.check(_lib.load().smil_silhouette_forward(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(sil), _ptr(ws),
+                                                   _stream()), "smil_silhouette_forward")
+    return sil
+
+
+def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, grad_sil: torch.Tensor, rs=None) -> torch.Tensor:
+    rs = rs or raster_settings()
+    N = verts_ndc.shape[0]
+    d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=verts_ndc.device)
+    ws = model.workspace(N, S)
+    _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(grad_sil),
+                                                    _ptr(d_ndc), _ptr(ws), _stream()), "smil_silhouette_backward")
+    return d_ndc
+
+
+def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pix_scale, rs=None, want_sil=False,
+                        loss_img=None, d_ndc=None):
+    rs = rs or raster_settings()
+    N = verts_ndc.shape[0]
+    dev = verts_ndc.device
+    if loss_img is None:
+        loss_img = torch.empty(N, dtype=torch.float32, device=dev)
+    if d_ndc is None:
+        d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=dev)
+    sil = torch.empty(N, S, S, dtype=torch.float32, device=dev) if want_sil else None
+    ws = model.workspace(N, S)
+    _lib.check(_lib.load().smil_silhouette_l1_fused(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(target),
+                                                    _ptr(target_sum), _ptr(pix_scale), _ptr(loss_img), _ptr(d_ndc), _ptr(sil),
+                                                    _ptr(ws), _stream()), "smil_silhouette_l1_fused")
+    return loss_img, d_ndc, sil
+
+
+def image_abs_sum(images: torch.Tensor) -> torch.Tensor:
+    N = images.shape[0]
+    pixels = images[0].numel()
+    out = torch.empty(N, dtype=torch.float32, device=images.device)
+    _lib.check(_lib.load().smil_image_abs_sum(_ptr(images), N, pixels, _ptr(out), _stream()), "smil_image_abs_sum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# losses / optimiser
+# ----------------------------------------------------------------------------------------------
+def fit_config(N, J, nB, window, weights, w_temp=0.0, frame0=0, N_total=None, limit=0.01) -> _lib.FitConfig:
+    """weights in the reference order (fitter.py:238): w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay."""
+    c = _lib.FitConfig()
+    c.N, c.J, c.nB, c.window, c.frame0 = N, J, nB, window, frame0
+    c.N_total = N if N_total is None else N_total
+    c.w_j2d, c.w_reproj, c.w_betas, c.w_pose, c.w_limit, c.w_splay = [float(w) for w in weights]
+    c.w_temp, c.limit = float(w_temp), float(limit)
+    return c
+
+
+def pix_scale(cfg: _lib.FitConfig, views: int, S: int, device) -> torch.Tensor:
+    out = torch.empty(cfg.N * views, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().smil_pix_scale(ctypes.byref(cfg), views, S, _ptr(out), _stream()), "smil_pix_scale")
+    return out
+
+
+def prior_losses(cfg, global_rot, joint_rot, trans, betas, mean_betas, betas_prec, global_mask, rotation_mask, objs,
+                 d_global, d_joint, d_trans, d_betas, halo_prev=None, halo_next=None, accumulate=True):
+    _lib.check(_lib.load().smil_prior_losses(ctypes.byref(cfg), _ptr(global_rot), _ptr(joint_rot), _ptr(trans), _ptr(betas),
+                                             _ptr(mean_betas), _ptr(betas_prec), _ptr(global_mask), _ptr(rotation_mask),
+                                             _ptr(halo_prev), _ptr(halo_next), _ptr(objs), _ptr(d_global), _ptr(d_joint),
+                                             _ptr(d_trans), _ptr(d_betas), int(accumulate), _stream()), "smil_prior_losses")
+
+
+def joint_loss(cfg, views, Jc, canon, proj, target, visibility, objs, d_proj):
+    _lib.check(_lib.load().smil_joint_loss(ctypes.byref(cfg), views, Jc, _ptr(canon), _ptr(proj), _ptr(target),
+                                           _ptr(visibility), _ptr(objs), _ptr(d_proj), _stream()), "smil_joint_loss")
+
+
+def sil_objective(loss_img, pscale, objs):
+    _lib.check(_lib.load().smil_sil_objective(_ptr(loss_img), _ptr(pscale), loss_img.numel(), _ptr(objs), _stream()),
+               "smil_sil_objective")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.5, beta2=0.999, eps=1e-8):
+    _lib.check(_lib.load().smil_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1,
+                                          beta2, eps, step, _stream()), "smil_adam_step")

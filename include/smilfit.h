@@ -70,6 +70,9 @@ typedef struct {
     const float *btrans;        /* betas_trans, same conventions */
     int32_t btrans_shared;
     const float *trans;         /* (B,3) or NULL */
+    int32_t trans_after_joints; /* 0: SMAL.__call__ semantics - joints are regressed from the translated
+                                   vertices (smal_torch.py:340-351); 1: SMALFitter semantics - trans is added
+                                   to verts AND joints after regression (fitter.py:280-281) */
     const float *del_v;         /* (B,V,3) or NULL */
     const float *v_template;    /* (V,3) override or NULL */
     int32_t propagate_scaling;  /* batch_lbs.py:163-168 */
@@ -167,6 +170,11 @@ int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t
                              const float *pix_scale, float *loss_img, float *d_ndc, float *sil_out,
                              void *workspace, void *stream);
 
+/* Measurement hook (bench.py): when enabled, every launch of the tile kernel is bracketed by HIP events on its
+ * launch stream; smil_profile_read synchronises those events and returns their summed duration + count. */
+int smil_profile_enable(int32_t on);
+int smil_profile_read(float *total_ms, int32_t *launches);
+
 /* ------------------------------------------------------------------------------------------
  * Priors / joint loss / temporal / Adam.  Replaces the loss block of SMALFitter.forward
  * (fitter.py:292-333), get_temporal (:337-350) and the Adam step of optimize_to_joints.py:117-175.
@@ -180,6 +188,8 @@ typedef struct {
     int32_t N_total;      /* frames of the whole sequence */
     float w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay, w_temp;
     float limit;          /* joint limit half-width (0.01) */
+    int32_t train_global, train_joints, train_trans; /* requires_grad of the per-frame groups
+                                                        (optimize_to_joints.py:129-144): 0 -> gradient zeroed */
 } SmilFitConfig;
 
 /* objs is a 10-float accumulator, every entry ADDED to (caller zeroes once per iteration):
@@ -188,17 +198,20 @@ typedef struct {
 #define SMIL_N_OBJS 10
 
 /* Prior terms (limit, pose, splay, betas, temporal) and their gradients on the per-frame parameters.
- * global_rot (N,3), joint_rot (N,J-1,3), trans (N,3), betas (nB,); masks global_mask (3,),
- * rotation_mask (J-1,3) (fitter.py:213-219,242-243).  halo_prev / halo_next: the (3J+3,) parameter row
- * [global, joints, trans] of the frame just before / after this shard (NULL at the sequence ends).
- * accumulate = 1: d_global / d_joint hold gradients w.r.t. the MASKED rotations on entry (from
- * smil_lbs_backward) and hold the final parameter gradients on exit ((in + prior) * mask); d_trans is
- * added to.  accumulate = 0: overwritten.  d_betas (nB,) is ADDED to. */
-int smil_prior_losses(const SmilFitConfig *cfg, const float *global_rot, const float *joint_rot,
-                      const float *trans, const float *betas, const float *mean_betas,
-                      const float *betas_prec, const float *global_mask, const float *rotation_mask,
-                      const float *halo_prev, const float *halo_next, float *objs, float *d_global,
-                      float *d_joint, float *d_trans, float *d_betas, int32_t accumulate, void *stream);
+ * pose (N,J,3): row 0 of each frame = global_rotation, rows 1.. = joint_rotations (UNMASKED parameters);
+ * mask (J,3): row 0 = global_mask, rows 1.. = rotation_mask (fitter.py:213-219,242-243); trans (N,3);
+ * betas (nB,).  halo_prev / halo_next: the (3J+3,) row [pose, trans] of the frame just before / after this
+ * shard (NULL at the sequence ends).
+ * accumulate = 1: d_pose holds gradients w.r.t. the MASKED pose on entry (from smil_lbs_backward) and the
+ * final parameter gradients on exit ((in + prior) * mask * train flag); d_trans is added to.
+ * accumulate = 0: overwritten.  d_betas (nB,) is ADDED to. */
+int smil_prior_losses(const SmilFitConfig *cfg, const float *pose, const float *trans, const float *betas,
+                      const float *mean_betas, const float *betas_prec, const float *mask,
+                      const float *halo_prev, const float *halo_next, float *objs, float *d_pose,
+                      float *d_trans, float *d_betas, int32_t accumulate, void *stream);
+
+/* out[i][c] = in[i][c] * mask[c]  (masked pose fed to smil_lbs_forward) */
+int smil_mask_rows(const float *in, const float *mask, int64_t rows, int32_t cols, float *out, void *stream);
 
 /* 2-D joint loss (fitter.py:283,292-296).  proj / d_proj (N*views,J,2) in (y,x) px over ALL model joints;
  * canon (Jc,) = config.CANONICAL_MODEL_JOINTS (NULL: the first Jc joints); target (N*views,Jc,2);

@@ -16,8 +16,8 @@ EXPORTS = [
     "smil_model_create", "smil_model_destroy", "smil_model_dims", "smil_last_error", "smil_version",
     "smil_lbs_forward", "smil_lbs_backward", "smil_project", "smil_project_backward", "smil_fov_reduce",
     "smil_raster_workspace_bytes", "smil_silhouette_forward", "smil_silhouette_backward",
-    "smil_silhouette_l1_fused", "smil_prior_losses", "smil_joint_loss", "smil_pix_scale",
-    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step",
+    "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
+    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_profile_enable", "smil_profile_read",
 ]
 
 N_OBJS = 10
@@ -37,7 +37,8 @@ class ModelDesc(Structure):
 class LbsInputs(Structure):
     _fields_ = [("B", c_int32), ("shared_beta", c_int32), ("nB_used", c_int32), ("beta", c_void_p),
                 ("theta", c_void_p), ("Rs_in", c_void_p), ("logscale", c_void_p), ("logscale_shared", c_int32),
-                ("btrans", c_void_p), ("btrans_shared", c_int32), ("trans", c_void_p), ("del_v", c_void_p),
+                ("btrans", c_void_p), ("btrans_shared", c_int32), ("trans", c_void_p), ("trans_after_joints", c_int32),
+                ("del_v", c_void_p),
                 ("v_template", c_void_p), ("propagate_scaling", c_int32), ("allow_limb_scaling", c_int32)]
 
 
@@ -64,7 +65,7 @@ class FitConfig(Structure):
     _fields_ = [("N", c_int32), ("J", c_int32), ("nB", c_int32), ("window", c_int32), ("frame0", c_int32),
                 ("N_total", c_int32), ("w_j2d", c_float), ("w_reproj", c_float), ("w_betas", c_float),
                 ("w_pose", c_float), ("w_limit", c_float), ("w_splay", c_float), ("w_temp", c_float),
-                ("limit", c_float)]
+                ("limit", c_float), ("train_global", c_int32), ("train_joints", c_int32), ("train_trans", c_int32)]
 
 
 _lib = None
@@ -100,7 +101,8 @@ def load():
                                              c_void_p, c_void_p, c_void_p]
     lib.smil_silhouette_l1_fused.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-    lib.smil_prior_losses.argtypes = [POINTER(FitConfig)] + [c_void_p] * 15 + [c_int32, c_void_p]
+    lib.smil_prior_losses.argtypes = [POINTER(FitConfig)] + [c_void_p] * 12 + [c_int32, c_void_p]
+    lib.smil_mask_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
     lib.smil_joint_loss.argtypes = [POINTER(FitConfig), c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]
     lib.smil_pix_scale.argtypes = [POINTER(FitConfig), c_int32, c_int32, c_void_p, c_void_p]
@@ -108,6 +110,8 @@ def load():
     lib.smil_sil_objective.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
     lib.smil_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                    c_int32, c_void_p]
+    lib.smil_profile_enable.argtypes = [c_int32]
+    lib.smil_profile_read.argtypes = [POINTER(c_float), POINTER(c_int32)]
     for name in EXPORTS:
         fn = getattr(lib, name)  # raises AttributeError if the symbol is missing
         if fn.restype is ctypes.c_int:

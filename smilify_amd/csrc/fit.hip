@@ -13,15 +13,16 @@ __device__ __forceinline__ int window_size_of(const SmilFitConfig &c, int local_
     return min(w, c.N_total - start);
 }
 
-// element e of frame i: [0,3) global rotation, [3,3J) joint rotations, [3J,3J+3) translation
-__global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const float *__restrict__ grot,
-                                                      const float *__restrict__ jrot, const float *__restrict__ trans,
-                                                      const float *__restrict__ gmask, const float *__restrict__ rmask,
+// element e of frame i: [0,3) global rotation, [3,3J) joint rotations, [3J,3J+3) translation.
+// pose is the combined (N,J,3) parameter buffer, mask the combined (J,3) mask.
+__global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const float *__restrict__ pose,
+                                                      const float *__restrict__ trans, const float *__restrict__ mask_tab,
                                                       const float *__restrict__ halo_prev, const float *__restrict__ halo_next,
-                                                      float *__restrict__ objs, float *__restrict__ d_g,
-                                                      float *__restrict__ d_j, float *__restrict__ d_t, int accumulate) {
+                                                      float *__restrict__ objs, float *__restrict__ d_pose,
+                                                      float *__restrict__ d_t, int accumulate) {
     __shared__ float red[16];
-    const int E = 3 * c.J + 3;
+    const int P3 = 3 * c.J;
+    const int E = P3 + 3;
     const long long total = (long long)c.N * E;
     float o_limit = 0.f, o_pose = 0.f, o_splay = 0.f, o_tj = 0.f, o_tg = 0.f, o_tt = 0.f;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -29,46 +30,43 @@ __global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const flo
         const float bw = (float)window_size_of(c, i);
         const int gi = c.frame0 + i;
         const bool has_prev = gi > 0, has_next = gi + 1 < c.N_total;
-        // value of this element in the previous / next frame (masked like the current one)
-        float mask, cur, prv = 0.f, nxt = 0.f, tnorm;
+        float mask, cur, prv = 0.f, nxt = 0.f, tnorm, train;
         float *dst;
         float grad = 0.f;
-        if (e < 3) {
-            mask = gmask[e];
-            cur = grot[3 * i + e] * mask;
-            if (has_prev) prv = (i > 0 ? grot[3 * (i - 1) + e] : halo_prev[e]) * mask;
-            if (has_next) nxt = (i + 1 < c.N ? grot[3 * (i + 1) + e] : halo_next[e]) * mask;
-            tnorm = 3.f;
-            dst = d_g + 3 * i + e;
-        } else if (e < 3 * c.J) {
-            const int k = e - 3;
-            const size_t stride = (size_t)3 * (c.J - 1);
-            mask = rmask[k];
-            cur = jrot[i * stride + k] * mask;
-            if (has_prev) prv = (i > 0 ? jrot[(i - 1) * stride + k] : halo_prev[e]) * mask;
-            if (has_next) nxt = (i + 1 < c.N ? jrot[(i + 1) * stride + k] : halo_next[e]) * mask;
-            tnorm = (float)stride;
-            dst = d_j + i * stride + k;
-            // joint limits (fitter.py:303-307): mean over b_w*(J-1)*3
-            if (c.w_limit > 0.f) {
-                const float s = c.w_limit / (bw * tnorm);
-                o_limit += s * (fmaxf(cur - c.limit, 0.f) + fmaxf(-c.limit - cur, 0.f));
-                grad += s * ((cur > c.limit ? 1.f : 0.f) - (cur < -c.limit ? 1.f : 0.f));
-            }
-            // pose prior (identity precision, root excluded; fitter.py:25-52,310-316): mean over b_w*3J
-            if (c.w_pose > 0.f) {
-                const float s = c.w_pose / (bw * 3.f * (float)c.J);
-                o_pose += s * cur * cur;
-                grad += 2.f * s * cur;
-            }
-            // splay (fitter.py:319): SUM over x and z components
-            if (c.w_splay > 0.f && (k % 3) != 1) {
-                o_splay += c.w_splay * cur * cur;
-                grad += 2.f * c.w_splay * cur;
+        if (e < P3) {
+            mask = mask_tab[e];
+            cur = pose[(size_t)i * P3 + e] * mask;
+            if (has_prev) prv = (i > 0 ? pose[(size_t)(i - 1) * P3 + e] : halo_prev[e]) * mask;
+            if (has_next) nxt = (i + 1 < c.N ? pose[(size_t)(i + 1) * P3 + e] : halo_next[e]) * mask;
+            dst = d_pose + (size_t)i * P3 + e;
+            if (e < 3) {
+                tnorm = 3.f;
+                train = c.train_global ? 1.f : 0.f;
+            } else {
+                tnorm = (float)(P3 - 3);
+                train = c.train_joints ? 1.f : 0.f;
+                // joint limits (fitter.py:303-307): mean over b_w*(J-1)*3
+                if (c.w_limit > 0.f) {
+                    const float s = c.w_limit / (bw * tnorm);
+                    o_limit += s * (fmaxf(cur - c.limit, 0.f) + fmaxf(-c.limit - cur, 0.f));
+                    grad += s * ((cur > c.limit ? 1.f : 0.f) - (cur < -c.limit ? 1.f : 0.f));
+                }
+                // pose prior (identity precision, root excluded; fitter.py:25-52,310-316): mean over b_w*3J
+                if (c.w_pose > 0.f) {
+                    const float s = c.w_pose / (bw * (float)P3);
+                    o_pose += s * cur * cur;
+                    grad += 2.f * s * cur;
+                }
+                // splay (fitter.py:319): SUM over the x and z components
+                if (c.w_splay > 0.f && (e % 3) != 1) {
+                    o_splay += c.w_splay * cur * cur;
+                    grad += 2.f * c.w_splay * cur;
+                }
             }
         } else {
-            const int k = e - 3 * c.J;
+            const int k = e - P3;
             mask = 1.f;
+            train = c.train_trans ? 1.f : 0.f;
             cur = trans[3 * i + k];
             if (has_prev) prv = i > 0 ? trans[3 * (i - 1) + k] : halo_prev[e];
             if (has_next) nxt = i + 1 < c.N ? trans[3 * (i + 1) + k] : halo_next[e];
@@ -80,10 +78,10 @@ __global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const flo
             float tl = 0.f;
             if (has_next) { const float d = cur - nxt; tl = s * d * d; grad += 2.f * s * d; }  // pair (i,i+1) is owned by i
             if (has_prev) { const float d = cur - prv; grad += 2.f * s * d; }
-            if (e < 3) o_tg += tl; else if (e < 3 * c.J) o_tj += tl; else o_tt += tl;
+            if (e < 3) o_tg += tl; else if (e < P3) o_tj += tl; else o_tt += tl;
         }
-        grad *= mask;
-        if (accumulate) *dst = (e < 3 * c.J ? (*dst) * mask : *dst) + grad; else *dst = grad;
+        const float upstream = accumulate ? *dst : 0.f;
+        *dst = (upstream + grad) * mask * train;
     }
     float v;
     v = block_sum(o_limit, red); if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[1], v);
@@ -92,6 +90,21 @@ __global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const flo
     v = block_sum(o_tj, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[6], v);
     v = block_sum(o_tg, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[7], v);
     v = block_sum(o_tt, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[8], v);
+}
+
+__global__ void __launch_bounds__(256) k_mask_rows(const float *__restrict__ in, const float *__restrict__ mask, long long n,
+                                                   int cols, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = in[i] * mask[i % cols];
+}
+
+extern "C" int smil_mask_rows(const float *in, const float *mask, int64_t rows, int32_t cols, float *out, void *stream_) {
+    SMIL_REQUIRE(in && mask && out && rows > 0 && cols > 0, "smil_mask_rows: bad argument");
+    const long long n = (long long)rows * cols;
+    hipLaunchKernelGGL(k_mask_rows, dim3((int)std::min<long long>(2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, in,
+                       mask, n, cols, out);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
 }
 
 // shape prior (fitter.py:321-330): per window mean(((beta - mean) @ prec)^2); identical for every window
@@ -123,26 +136,29 @@ __global__ void k_betas_prior(SmilFitConfig c, const float *__restrict__ betas, 
     }
 }
 
-extern "C" int smil_prior_losses(const SmilFitConfig *cfg, const float *global_rot, const float *joint_rot,
-                                 const float *trans, const float *betas, const float *mean_betas,
-                                 const float *betas_prec, const float *global_mask, const float *rotation_mask,
-                                 const float *halo_prev, const float *halo_next, float *objs, float *d_global,
-                                 float *d_joint, float *d_trans, float *d_betas, int32_t accumulate, void *stream_) {
-    SMIL_REQUIRE(cfg && global_rot && joint_rot && trans && global_mask && rotation_mask && objs && d_global && d_joint && d_trans,
-                 "smil_prior_losses: null argument");
+extern "C" int smil_prior_losses(const SmilFitConfig *cfg, const float *pose, const float *trans, const float *betas,
+                                 const float *mean_betas, const float *betas_prec, const float *mask, const float *halo_prev,
+                                 const float *halo_next, float *objs, float *d_pose, float *d_trans, float *d_betas,
+                                 int32_t accumulate, void *stream_) {
+    SMIL_REQUIRE(cfg && pose && trans && mask && objs && d_pose && d_trans, "smil_prior_losses: null argument");
     SMIL_REQUIRE(cfg->N > 0 && cfg->J > 1 && cfg->N_total >= cfg->frame0 + cfg->N, "smil_prior_losses: bad sizes");
-    SMIL_REQUIRE(cfg->frame0 == 0 || halo_prev, "smil_prior_losses: halo_prev required for a shard that does not start the sequence");
-    SMIL_REQUIRE(cfg->frame0 + cfg->N == cfg->N_total || halo_next, "smil_prior_losses: halo_next required for a shard that does not end the sequence");
+    SMIL_REQUIRE(cfg->frame0 == 0 || halo_prev || cfg->w_temp <= 0.f,
+                 "smil_prior_losses: halo_prev required for a shard that does not start the sequence");
+    SMIL_REQUIRE(cfg->frame0 + cfg->N == cfg->N_total || halo_next || cfg->w_temp <= 0.f,
+                 "smil_prior_losses: halo_next required for a shard that does not end the sequence");
     hipStream_t stream = (hipStream_t)stream_;
-    const long long total = (long long)cfg->N * (3 * cfg->J + 3);
+    SmilFitConfig c = *cfg;
+    if (!halo_prev && c.frame0 > 0 && c.w_temp <= 0.f) halo_prev = pose;  // never read as a neighbour value that matters
+    if (!halo_next && c.frame0 + c.N < c.N_total && c.w_temp <= 0.f) halo_next = pose;
+    const long long total = (long long)c.N * (3 * c.J + 3);
     const int grid = (int)std::min<long long>(512, (total + 255) / 256);
-    hipLaunchKernelGGL(k_prior_losses, dim3(grid), dim3(256), 0, stream, *cfg, global_rot, joint_rot, trans, global_mask,
-                       rotation_mask, halo_prev, halo_next, objs, d_global, d_joint, d_trans, accumulate);
+    hipLaunchKernelGGL(k_prior_losses, dim3(grid), dim3(256), 0, stream, c, pose, trans, mask, halo_prev, halo_next, objs, d_pose,
+                       d_trans, accumulate);
     SMIL_LAUNCH_CHECK();
-    if (cfg->w_betas > 0.f && cfg->nB > 0) {
+    if (c.w_betas > 0.f && c.nB > 0) {
         SMIL_REQUIRE(betas && mean_betas && betas_prec && d_betas, "smil_prior_losses: shape prior tables missing");
-        SMIL_REQUIRE(cfg->nB <= SMIL_MAX_BETAS, "smil_prior_losses: nB too large");
-        hipLaunchKernelGGL(k_betas_prior, dim3(1), dim3(64), 0, stream, *cfg, betas, mean_betas, betas_prec, objs, d_betas);
+        SMIL_REQUIRE(c.nB <= SMIL_MAX_BETAS, "smil_prior_losses: nB too large");
+        hipLaunchKernelGGL(k_betas_prior, dim3(1), dim3(64), 0, stream, c, betas, mean_betas, betas_prec, objs, d_betas);
         SMIL_LAUNCH_CHECK();
     }
     return SMIL_OK;

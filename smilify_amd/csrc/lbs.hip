@@ -105,6 +105,7 @@ struct PoseArgs {
     const float *theta, *Rs_in, *logscale, *btrans, *J_rest;
     const int *parents, *depth;
     float *Rs, *G, *A, *new_J, *joints_static;
+    const float *joints_trans;  // added to the static joints (SMALFitter semantics) or NULL
     int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
 };
 
@@ -177,7 +178,9 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) 
                 }
                 a.new_J[o * 3 + 0] = G[3]; a.new_J[o * 3 + 1] = G[7]; a.new_J[o * 3 + 2] = G[11];
                 if (a.joints_static) {
-                    a.joints_static[o * 3 + 0] = G[3]; a.joints_static[o * 3 + 1] = G[7]; a.joints_static[o * 3 + 2] = G[11];
+                    const float t0 = a.joints_trans ? a.joints_trans[3 * b] : 0.f, t1 = a.joints_trans ? a.joints_trans[3 * b + 1] : 0.f,
+                                t2 = a.joints_trans ? a.joints_trans[3 * b + 2] : 0.f;
+                    a.joints_static[o * 3 + 0] = G[3] + t0; a.joints_static[o * 3 + 1] = G[7] + t1; a.joints_static[o * 3 + 2] = G[11] + t2;
                 }
             }
         }
@@ -221,16 +224,19 @@ __global__ void __launch_bounds__(256) k_skin_fwd(const float *__restrict__ A, c
 }
 
 // posed joints by regression from the posed vertices                           (smal_torch.py:348-351)
+// trans_after != NULL: the vertices already carry the frame translation but the reference regresses the
+// joints from the untranslated vertices and adds the translation afterwards (fitter.py:280-281).
 __global__ void k_regress_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
                                  const float *__restrict__ val, const float *__restrict__ verts,
-                                 float *__restrict__ joints, int V, int J) {
+                                 const float *__restrict__ trans_after, float *__restrict__ joints, int V, int J) {
     const int b = blockIdx.x;
     const float *vb = verts + (size_t)b * V * 3;
     for (int idx = threadIdx.x; idx < 3 * J; idx += blockDim.x) {
         const int j = idx / 3, c = idx - 3 * j;
+        const float t = trans_after ? trans_after[3 * b + c] : 0.f;
         float acc = 0.f;
-        for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) acc += vb[3 * col[e] + c] * val[e];
-        joints[(size_t)b * J * 3 + idx] = acc;
+        for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) acc += (vb[3 * col[e] + c] - t) * val[e];
+        joints[(size_t)b * J * 3 + idx] = acc + t;
     }
 }
 
@@ -264,6 +270,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
         a.parents = m->parents; a.depth = m->depth;
         a.Rs = out->Rs; a.G = out->G; a.A = out->A; a.new_J = out->new_J;
         a.joints_static = m->static_joints ? out->joints : nullptr;
+        a.joints_trans = (in->trans_after_joints && in->trans) ? in->trans : nullptr;
         a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;
         a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
         a.propagate = in->propagate_scaling;
@@ -279,7 +286,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
     }
     if (!m->static_joints) {
         hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(256), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
-                           out->verts, out->joints, V, J);
+                           out->verts, (in->trans_after_joints && in->trans) ? in->trans : nullptr, out->joints, V, J);
         SMIL_LAUNCH_CHECK();
     }
     return SMIL_OK;
@@ -491,7 +498,7 @@ __global__ void __launch_bounds__(256) k_shape_bwd(
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
     const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_trans, int V, int J,
-    int nB_used, int regress) {
+    int nB_used, int regress, int trans_after) {
     extern __shared__ float smem[];
     float *sA = smem;            // (J,12)
     float *sDJ = sA + J * 12;    // (J,3) upstream on posed joints
@@ -515,7 +522,12 @@ __global__ void __launch_bounds__(256) k_shape_bwd(
         for (int v = threadIdx.x; v < V; v += blockDim.x) {
             float dv[3];
             vertex_upstream(dvb, sDJ, colptr, row, cval, v, reg_j, dv);
-            tsum[0] += dv[0]; tsum[1] += dv[1]; tsum[2] += dv[2];
+            if (trans_after) {
+                // translation bypasses the regressor: d_trans = sum_v d_verts + sum_j d_joints
+                if (dvb) { tsum[0] += dvb[3 * v]; tsum[1] += dvb[3 * v + 1]; tsum[2] += dvb[3 * v + 2]; }
+            } else {
+                tsum[0] += dv[0]; tsum[1] += dv[1]; tsum[2] += dv[2];
+            }
             if (nB_used == 0) continue;
             const uint32_t ids = skin_idx[v];
             const float4 w4 = skin_w[v];
@@ -552,6 +564,11 @@ __global__ void __launch_bounds__(256) k_shape_bwd(
             }
         }
         if (k0 == 0 && d_trans) {
+            if (trans_after && d_joints)
+                for (int j = threadIdx.x; j < J; j += blockDim.x) {
+                    const float *dj = d_joints + ((size_t)b * J + j) * 3;
+                    tsum[0] += dj[0]; tsum[1] += dj[1]; tsum[2] += dj[2];
+                }
             for (int c = 0; c < 3; ++c) {
                 const float r = block_sum(tsum[c], red);
                 if (threadIdx.x == 0) d_trans[3 * b + c] = r;
@@ -587,6 +604,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     SMIL_REQUIRE(g->d_verts || g->d_joints, "smil_lbs_backward: no upstream gradient");
     SMIL_REQUIRE(g->d_A && g->d_Jrest && g->d_Rs, "smil_lbs_backward: scratch buffers missing");
     SMIL_REQUIRE(sv->v_shaped && sv->J_rest && sv->G && sv->A && sv->Rs, "smil_lbs_backward: saved forward tensors missing");
+    SMIL_REQUIRE(!(g->d_beta && in->shared_beta) || in->nB_used <= J * 12, "smil_lbs_backward: nB_used exceeds the d_A scratch");
     const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
     const int regress = m->static_joints ? 0 : 1;
     const int use_scale = (in->logscale && in->allow_limb_scaling) ? 1 : 0;
@@ -631,7 +649,8 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         const size_t lds = ((size_t)J * 18 + 16) * sizeof(float);
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(256), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
-                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, V, J, nBu, regress);
+                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, V, J, nBu, regress,
+                           in->trans_after_joints ? 1 : 0);
         SMIL_LAUNCH_CHECK();
         if (dbeta_frame && in->shared_beta) {
             int rc = smil_reduce_rows(dbeta_frame, g->d_beta, B, nBu, stream);

@@ -484,6 +484,49 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     return SMIL_OK;
 }
 
+// ---- optional in-process timing of the tile kernel (bench.py): HIP events recorded on the launch stream ----
+#define PROF_SLOTS 512
+static bool g_prof_on = false;
+static hipEvent_t g_prof_ev[PROF_SLOTS][2];
+static int g_prof_n = 0;
+static bool g_prof_init = false;
+
+extern "C" int smil_profile_enable(int32_t on) {
+    if (on && !g_prof_init) {
+        for (int i = 0; i < PROF_SLOTS; ++i) {
+            SMIL_HIP(hipEventCreate(&g_prof_ev[i][0]));
+            SMIL_HIP(hipEventCreate(&g_prof_ev[i][1]));
+        }
+        g_prof_init = true;
+    }
+    g_prof_on = on != 0;
+    g_prof_n = 0;
+    return SMIL_OK;
+}
+
+// Sum / count of the tile-kernel durations recorded since smil_profile_enable(1).  Synchronises the events.
+extern "C" int smil_profile_read(float *total_ms, int32_t *launches) {
+    SMIL_REQUIRE(total_ms && launches, "smil_profile_read: null argument");
+    float tot = 0.f;
+    const int n = g_prof_n < PROF_SLOTS ? g_prof_n : PROF_SLOTS;
+    for (int i = 0; i < n; ++i) {
+        SMIL_HIP(hipEventSynchronize(g_prof_ev[i][1]));
+        float ms = 0.f;
+        SMIL_HIP(hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = n;
+    g_prof_n = 0;
+    return SMIL_OK;
+}
+
+#define PROF_BEGIN(stream) \
+    const int _slot = (g_prof_on && g_prof_n < PROF_SLOTS) ? g_prof_n++ : -1; \
+    if (_slot >= 0) (void)hipEventRecord(g_prof_ev[_slot][0], stream)
+#define PROF_END(stream) \
+    if (_slot >= 0) (void)hipEventRecord(g_prof_ev[_slot][1], stream)
+
 static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
     const long long resident = 256LL * 5;  // 256 CUs x blocks per CU admitted by the LDS footprint
@@ -499,8 +542,10 @@ extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_nd
     SMIL_REQUIRE(sil, "smil_silhouette_forward: null output");
     SMIL_HIP(hipMemsetAsync(sil, 0, (size_t)N * S * S * sizeof(float), stream));
     a.sil = sil;
+    PROF_BEGIN(stream);
     hipLaunchKernelGGL(k_raster_tiles<MODE_FWD>, dim3(tile_grid(N, a.tiles_x)), dim3(64), (size_t)a.K * WAVE * sizeof(float),
                        stream, a);
+    PROF_END(stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -515,8 +560,10 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
     SMIL_REQUIRE(grad_sil && d_ndc, "smil_silhouette_backward: null argument");
     SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
     a.grad_sil = grad_sil; a.d_ndc = d_ndc;
+    PROF_BEGIN(stream);
     hipLaunchKernelGGL(k_raster_tiles<MODE_BWD>, dim3(tile_grid(N, a.tiles_x)), dim3(64), (size_t)a.K * WAVE * sizeof(float),
                        stream, a);
+    PROF_END(stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -534,8 +581,10 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     SMIL_HIP(hipMemcpyAsync(loss_img, target_sum, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
     a.target = target; a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
+    PROF_BEGIN(stream);
     hipLaunchKernelGGL(k_raster_tiles<MODE_FUSED>, dim3(tile_grid(N, a.tiles_x)), dim3(64),
                        (size_t)a.K * WAVE * sizeof(float), stream, a);
+    PROF_END(stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }

@@ -132,7 +132,7 @@ def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL) -> _lib.Ra
 # ----------------------------------------------------------------------------------------------
 def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btrans=None, del_v=None,
                 v_template=None, Rs_in=None, shared_beta=False, logscale_shared=False, btrans_shared=False,
-                propagate_scaling=False, allow_limb_scaling=True) -> Dict[str, torch.Tensor]:
+                propagate_scaling=False, allow_limb_scaling=True, trans_after_joints=False) -> Dict[str, torch.Tensor]:
     dev = model.device
     B = int((theta if theta is not None else Rs_in).shape[0])
     J, V = model.J, model.V
@@ -147,6 +147,7 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     i.B, i.shared_beta, i.nB_used = B, int(shared_beta), nB_used
     i.logscale_shared, i.btrans_shared = int(logscale_shared), int(btrans_shared)
     i.propagate_scaling, i.allow_limb_scaling = int(propagate_scaling), int(allow_limb_scaling)
+    i.trans_after_joints = int(trans_after_joints)
     for k, t in inp.items():
         setattr(i, k, None if t is None else t.data_ptr())
     o = _lib.LbsOutputs()
@@ -156,7 +157,7 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     out["_inputs"] = inp
     out["_flags"] = dict(B=B, shared_beta=shared_beta, nB_used=nB_used, logscale_shared=logscale_shared,
                          btrans_shared=btrans_shared, propagate_scaling=propagate_scaling,
-                         allow_limb_scaling=allow_limb_scaling)
+                         allow_limb_scaling=allow_limb_scaling, trans_after_joints=trans_after_joints)
     return out
 
 
@@ -182,6 +183,7 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
     i.B, i.shared_beta, i.nB_used = B, int(fl["shared_beta"]), fl["nB_used"]
     i.logscale_shared, i.btrans_shared = int(fl["logscale_shared"]), int(fl["btrans_shared"])
     i.propagate_scaling, i.allow_limb_scaling = int(fl["propagate_scaling"]), int(fl["allow_limb_scaling"])
+    i.trans_after_joints = int(fl["trans_after_joints"])
     for k, t in inp.items():
         setattr(i, k, None if t is None else t.data_ptr())
     o = _lib.LbsOutputs()
@@ -284,9 +286,11 @@ def image_abs_sum(images: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # losses / optimiser
 # ----------------------------------------------------------------------------------------------
-def fit_config(N, J, nB, window, weights, w_temp=0.0, frame0=0, N_total=None, limit=0.01) -> _lib.FitConfig:
+def fit_config(N, J, nB, window, weights, w_temp=0.0, frame0=0, N_total=None, limit=0.01, train_global=True,
+               train_joints=True, train_trans=True) -> _lib.FitConfig:
     """weights in the reference order (fitter.py:238): w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay."""
     c = _lib.FitConfig()
+    c.train_global, c.train_joints, c.train_trans = int(train_global), int(train_joints), int(train_trans)
     c.N, c.J, c.nB, c.window, c.frame0 = N, J, nB, window, frame0
     c.N_total = N if N_total is None else N_total
     c.w_j2d, c.w_reproj, c.w_betas, c.w_pose, c.w_limit, c.w_splay = [float(w) for w in weights]
@@ -300,12 +304,20 @@ def pix_scale(cfg: _lib.FitConfig, views: int, S: int, device) -> torch.Tensor:
     return out
 
 
-def prior_losses(cfg, global_rot, joint_rot, trans, betas, mean_betas, betas_prec, global_mask, rotation_mask, objs,
-                 d_global, d_joint, d_trans, d_betas, halo_prev=None, halo_next=None, accumulate=True):
-    _lib.check(_lib.load().smil_prior_losses(ctypes.byref(cfg), _ptr(global_rot), _ptr(joint_rot), _ptr(trans), _ptr(betas),
-                                             _ptr(mean_betas), _ptr(betas_prec), _ptr(global_mask), _ptr(rotation_mask),
-                                             _ptr(halo_prev), _ptr(halo_next), _ptr(objs), _ptr(d_global), _ptr(d_joint),
-                                             _ptr(d_trans), _ptr(d_betas), int(accumulate), _stream()), "smil_prior_losses")
+def prior_losses(cfg, pose, trans, betas, mean_betas, betas_prec, mask, objs, d_pose, d_trans, d_betas, halo_prev=None,
+                 halo_next=None, accumulate=True):
+    """pose (N,J,3) = [global_rotation ; joint_rotations], mask (J,3) = [global_mask ; rotation_mask]."""
+    _lib.check(_lib.load().smil_prior_losses(ctypes.byref(cfg), _ptr(pose), _ptr(trans), _ptr(betas), _ptr(mean_betas),
+                                             _ptr(betas_prec), _ptr(mask), _ptr(halo_prev), _ptr(halo_next), _ptr(objs),
+                                             _ptr(d_pose), _ptr(d_trans), _ptr(d_betas), int(accumulate), _stream()),
+               "smil_prior_losses")
+
+
+def mask_rows(x: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    cols = mask.numel()
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().smil_mask_rows(_ptr(x), _ptr(mask), x.numel() // cols, cols, _ptr(out), _stream()), "smil_mask_rows")
+    return out
 
 
 def joint_loss(cfg, views, Jc, canon, proj, target, visibility, objs, d_proj):
@@ -321,3 +333,14 @@ def sil_objective(loss_img, pscale, objs):
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.5, beta2=0.999, eps=1e-8):
     _lib.check(_lib.load().smil_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1,
                                           beta2, eps, step, _stream()), "smil_adam_step")
+
+
+def profile_enable(on: bool) -> None:
+    _lib.check(_lib.load().smil_profile_enable(int(on)), "smil_profile_enable")
+
+
+def profile_read():
+    """(summed tile-kernel milliseconds, launches) since the last enable/read."""
+    ms, n = ctypes.c_float(), ctypes.c_int32()
+    _lib.check(_lib.load().smil_profile_read(ctypes.byref(ms), ctypes.byref(n)), "smil_profile_read")
+    return float(ms.value), int(n.value)

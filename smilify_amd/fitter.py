@@ -1,0 +1,453 @@
+"""Drop-in ``SMALFitter`` plus the fused whole-sequence fit step.
+
+``SMALFitter`` keeps the reference's constructor, parameter names and ``forward(batch_range, weights,
+stage_id) -> (loss, objs)`` / ``get_temporal`` / ``load_checkpoint`` contract
+(reference smal_fitter/fitter.py:55-371).  Every arithmetic step - LBS, projection, soft silhouette, the six
+loss terms and all their gradients - runs in HIP kernels of ``libsmilfit.so``; autograd only sees one node
+per call whose backward hands out the gradients the kernels already produced.
+
+``SMALFitter.fit_step`` is the fast path used by ``smilify_amd.optimize`` and ``bench.py``: one call = one
+epoch of reference optimize_to_joints.py:147-175 over all frames of this rank (sum over windows of window
+means + temporal terms, backward, Adam step), with no autograd graph and no per-window Python.
+
+Extensions over the reference, needed for the batched / multi-view configurations:
+``fov`` may have shape (1,), (views,) or (N*views,); ``log_beta_scales`` / ``betas_trans`` may be
+(1,J,3) shared or (N,J,3) per frame; cameras may be given per view; targets are (N*views, ...).
+"""
+from __future__ import annotations
+
+import math
+import os
+import pickle as pkl
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import config as _config
+from . import engine, model_io
+from ._lib import N_OBJS
+from .cameras import FoVCameras
+from .p3d_renderer import Renderer
+from .smal_torch import SMAL
+
+OBJ_NAMES = ("joint", "limit", "pose", "splay", "betas", "sil_reproj")  # reference objs keys, in objs[] order
+
+
+def default_global_rotation() -> np.ndarray:
+    """``eul_to_axis([-pi/2, 0, -pi/2])`` of reference fitter.py:206: nibabel's euler2angle_axis(z, y, x)
+    composes R_x(x) R_y(y) R_z(z); at y = 0 the quaternion is (cx cz, sx cz, -sx sz, cx sz)."""
+    hx = hz = -math.pi / 4
+    q = np.array([math.cos(hx) * math.cos(hz), math.sin(hx) * math.cos(hz), -math.sin(hx) * math.sin(hz), math.cos(hx) * math.sin(hz)])
+    angle = 2.0 * math.acos(q[0])
+    return (q[1:] / np.linalg.norm(q[1:]) * angle).astype(np.float32)
+
+
+def shape_prior_precision(shape_cov, n_betas: int) -> np.ndarray:
+    """Cholesky factor of the regularised inverse shape covariance (reference fitter.py:170-175)."""
+    cov = np.eye(n_betas) if shape_cov is None else np.asarray(shape_cov, np.float64)
+    prec = np.linalg.cholesky(np.linalg.inv(cov + 1e-5 * np.eye(cov.shape[0])))
+    return prec[:n_betas, :n_betas].astype(np.float32)
+
+
+class _Prior:
+    """Identity-precision pose prior (reference fitter.py:25-52); kept for API parity, evaluated in-kernel."""
+
+    def __init__(self, n_joints: int, device):
+        self.use_ind = np.ones(n_joints * 3, dtype=bool)
+        self.use_ind[:3] = False
+        self.use_ind_tch = torch.from_numpy(self.use_ind).float().to(device)
+
+
+class _FitWindow(torch.autograd.Function):
+    """(loss, objs) of one window; gradients were computed by the kernels in forward."""
+
+    @staticmethod
+    def forward(ctx, fitter, frames, weights, w_temp, betas, log_beta_scales, betas_trans, pose, trans, fov):
+        objs, grads = fitter._loss_and_grads(frames, weights, w_temp)
+        ctx.grads = grads
+        total = objs[:9].sum()
+        return total, objs.clone()
+
+    @staticmethod
+    def backward(ctx, g_total, _g_objs):
+        g = ctx.grads
+        s = lambda t: None if t is None else t * g_total  # noqa: E731
+        return (None, None, None, None, s(g["betas"]), s(g["log_beta_scales"]), s(g["betas_trans"]), s(g["pose"]), s(g["trans"]),
+                s(g["fov"]))
+
+
+class SMALFitter(nn.Module):
+    def __init__(self, device, data_batch, batch_size, shape_family=-1, use_unity_prior=False, rgb_only=False, *,
+                 tables: Optional[model_io.SmilModelTables] = None, model_path: Optional[str] = None,
+                 config: Optional[_config.FitterConfig] = None, views: int = 1, frame0: int = 0, n_frames_total: Optional[int] = None):
+        super().__init__()
+        if use_unity_prior or shape_family != -1:
+            raise NotImplementedError("the Unity / shape-family priors need MPI-licensed files that SMIL models do not use")
+        self.device = engine.require_gpu(device)
+        dev = self.device
+        if tables is None:
+            cfg0 = config or _config.current
+            path = model_path or (cfg0.SMAL_FILE if cfg0 is not None else None)
+            if path is None:
+                raise ValueError("SMALFitter needs tables=, model_path= or config.SMAL_FILE")
+            tables = model_io.load_model(path)
+        self.config = config or _config.current or _config.FitterConfig.from_tables(tables, model_path)
+        cfg = self.config
+        self.rgb_only = rgb_only
+        self.views = int(views)
+        J, nB = tables.J, tables.nB
+        if rgb_only:
+            self.rgb_imgs = data_batch
+            n_img = self.rgb_imgs.shape[0]
+            self.sil_imgs = None
+            self.target_joints = torch.zeros(n_img, len(cfg.CANONICAL_MODEL_JOINTS), 2)
+            self.target_visibility = torch.zeros(n_img, len(cfg.CANONICAL_MODEL_JOINTS)).long()
+        else:
+            self.rgb_imgs, self.sil_imgs, self.target_joints, self.target_visibility = data_batch
+            self.target_visibility = self.target_visibility.long()
+        n_img = self.sil_imgs.shape[0] if self.sil_imgs is not None else self.rgb_imgs.shape[0]
+        if n_img % self.views:
+            raise ValueError(f"{n_img} target images is not a multiple of views={self.views}")
+        self.num_images = n_img // self.views  # frames held by this rank
+        self.image_size = int(self.sil_imgs.shape[-1] if self.sil_imgs is not None else self.rgb_imgs.shape[2])
+        self.frame0 = int(frame0)
+        self.n_frames_total = int(n_frames_total) if n_frames_total is not None else self.num_images
+        self.use_unity_prior = False
+        self.batch_size = batch_size
+        self.n_betas = nB
+        self.shape_family_list = np.array(shape_family)
+        self.propagate_scaling = False
+        N = self.num_images
+
+        # shape prior learned from the scanned models, identity fallback (reference fitter.py:121-136,170-175)
+        mean = tables.shape_mean_betas if (tables.shape_cov is not None and tables.shape_mean_betas is not None) else None
+        self.mean_betas = (torch.zeros(nB) if mean is None else torch.from_numpy(np.asarray(mean, np.float32))[:nB]).to(dev).contiguous()
+        self.betas_prec = torch.from_numpy(shape_prior_precision(tables.shape_cov if mean is not None else None, nB)).to(dev).contiguous()
+        self.pose_prior = _Prior(J, dev)
+        self.max_limits = torch.full((J - 1, 3), cfg.JOINT_LIMIT, device=dev)
+        self.min_limits = -self.max_limits
+
+        # parameters (names as in the reference: optimize_to_joints.py:118-144 addresses them by name)
+        self.betas = nn.Parameter(self.mean_betas.clone())
+        self.log_beta_scales = nn.Parameter(torch.zeros(N, J, 3, device=dev), requires_grad=False)
+        self.betas_trans = nn.Parameter(torch.zeros(N, J, 3, device=dev), requires_grad=False)
+        # global_rotation and joint_rotations are views of ONE (N,J,3) pose buffer so the kernels read them without
+        # a concatenation; they stay ordinary leaf Parameters for torch.optim
+        self._pose = torch.zeros(N, J, 3, device=dev)
+        self._pose[:, 0] = torch.from_numpy(default_global_rotation()).to(dev)
+        self.global_rotation = nn.Parameter(self._pose[:, 0])
+        self.joint_rotations = nn.Parameter(self._pose[:, 1:])
+        self.trans = nn.Parameter(torch.zeros(N, 3, device=dev))
+        self.global_mask = torch.ones(1, 3, device=dev)
+        self.rotation_mask = torch.ones(J - 1, 3, device=dev)
+
+        self.smal_model = SMAL(dev, tables=tables, config=cfg)
+        self.renderer = Renderer(self.image_size, dev, views=self.views)
+        self.renderer.bind_model(self.smal_model.device_model)
+        self.fov = nn.Parameter(self.renderer.cameras.fov.clone())  # (1,) = 60 deg
+
+        # device-resident targets (the reference re-uploads them every forward, fitter.py:263-266)
+        self._targets_dirty = True
+        self._adam: Dict[str, Dict] = {}
+        self._adam_step = 0
+
+    # ------------------------------------------------------------------------------------------
+    # plumbing
+    # ------------------------------------------------------------------------------------------
+    @property
+    def device_model(self) -> engine.DeviceModel:
+        return self.smal_model.device_model
+
+    def set_cameras(self, R, T, fov=None, aspect_ratio=None):
+        """Install per-view or per-image cameras; ``fov`` (if given) replaces the trainable parameter."""
+        f = self.fov.data if fov is None else fov
+        self.renderer.set_camera_parameters(R, T, f, aspect_ratio)
+        if fov is not None:
+            self.fov = nn.Parameter(self.renderer.cameras.fov.clone())
+
+    def _refresh_targets(self):
+        dev = self.device
+        n_img = self.num_images * self.views
+        if self.sil_imgs is not None:
+            self._sil_dev = self.sil_imgs.to(dev).float().reshape(n_img, self.image_size, self.image_size).contiguous()
+            self._sil_sum = engine.image_abs_sum(self._sil_dev)
+        else:
+            self._sil_dev = self._sil_sum = None
+        self._tj_dev = self.target_joints.to(dev).float().contiguous()
+        self._vis_dev = self.target_visibility.to(dev).to(torch.int32).contiguous()
+        canon = list(self.config.CANONICAL_MODEL_JOINTS)
+        self._canon_identity = canon == list(range(self.smal_model.tables.J))
+        self._canon_dev = torch.tensor(canon, dtype=torch.int32, device=dev)
+        self._targets_dirty = False
+
+    def invalidate_targets(self):
+        """Call after editing ``target_joints`` / ``target_visibility`` / ``sil_imgs`` in place."""
+        self._targets_dirty = True
+
+    def __setattr__(self, name, value):
+        if name in ("target_visibility", "target_joints", "sil_imgs") and "_targets_dirty" in self.__dict__:
+            self.__dict__["_targets_dirty"] = True
+        super().__setattr__(name, value)
+
+    def _mask_table(self) -> torch.Tensor:
+        return torch.cat([self.global_mask.reshape(1, 3), self.rotation_mask.reshape(-1, 3)], 0).contiguous()
+
+    def _rows(self, p: torch.Tensor, idx: Optional[torch.Tensor], n_sel: int):
+        """(tensor, shared?) for a parameter that is either one shared row or one row per frame."""
+        if p.shape[0] == 1:
+            return p.detach()[0].contiguous(), True
+        if p.shape[0] != self.num_images:
+            raise ValueError(f"parameter with {p.shape[0]} rows for {self.num_images} frames")
+        return (p.detach() if idx is None else p.detach().index_select(0, idx)).contiguous(), False
+
+    # ------------------------------------------------------------------------------------------
+    # the fused loss + gradient evaluation
+    # ------------------------------------------------------------------------------------------
+    def _loss_and_grads(self, frames: Optional[Sequence[int]], weights, w_temp: float, window: Optional[int] = None,
+                        halo_prev=None, halo_next=None):
+        """Evaluate every loss term and the gradient of their sum for ``frames`` (None = all frames of this rank).
+
+        Returns ``(objs (10,), grads)`` with full-size gradient tensors (zero rows outside ``frames``).
+        ``window``: frames per loss window; None = the selected frames form one window (``forward`` semantics).
+        """
+        if self._targets_dirty:
+            self._refresh_targets()
+        dev, dm, cfg = self.device, self.device_model, self.config
+        J, nB, V, views, S = dm.J, dm.nB, dm.V, self.views, self.image_size
+        N_all = self.num_images
+        w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay = [float(w) for w in weights]
+        if self.rgb_only:
+            w_reproj = 0.0
+        if frames is None:
+            idx, n = None, N_all
+            frame0, n_total = self.frame0, self.n_frames_total
+            win = window if window is not None else n_total
+        else:
+            fl = list(frames)
+            n = len(fl)
+            idx = torch.tensor(fl, dtype=torch.long, device=dev)
+            frame0, n_total, win = 0, n, (window if window is not None else n)
+            w_temp = 0.0  # a window has no temporal term; get_temporal covers the sequence
+        sel = (lambda t: t) if idx is None else (lambda t: t.index_select(0, idx))
+        pose = sel(self._pose.detach()).contiguous()
+        trans = sel(self.trans.detach()).contiguous()
+        mask = self._mask_table()
+        theta = engine.mask_rows(pose, mask)
+        ls, ls_shared = self._rows(self.log_beta_scales, idx, n)
+        bt, bt_shared = self._rows(self.betas_trans, idx, n)
+        betas = self.betas.detach().contiguous()
+        fc = engine.fit_config(n, J, nB, win, [w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay], w_temp, frame0, n_total,
+                               cfg.JOINT_LIMIT, self.global_rotation.requires_grad, self.joint_rotations.requires_grad,
+                               self.trans.requires_grad)
+        objs = torch.zeros(N_OBJS, dtype=torch.float32, device=dev)
+        d_betas = torch.zeros(nB, dtype=torch.float32, device=dev)
+
+        # cameras: one table row per view, per image or shared; fov may be the trainable parameter
+        cam = self.renderer.cameras
+        fov = self.fov.detach().reshape(-1).contiguous()
+        img_idx = None
+        if idx is not None:
+            img_idx = (idx[:, None] * views + torch.arange(views, device=dev)[None]).reshape(-1)
+
+        def cam_rows(t, rows):
+            k = t.shape[0]
+            if k in (1, views) or idx is None:
+                return t.contiguous()
+            if k != N_all * views:
+                raise ValueError(f"camera table with {k} rows for {N_all * views} images")
+            return t.index_select(0, img_idx).contiguous()
+
+        cams = engine.CameraSet(cam_rows(cam.R, 9), cam_rows(cam.T, 3), cam_rows(fov, 1),
+                                None if cam.aspect_ratio is None else cam_rows(cam.aspect_ratio.reshape(-1), 1), views, S)
+
+        need_render = (w_j2d > 0) or (w_reproj > 0)
+        g_lbs = None
+        d_fov = torch.zeros_like(fov)
+        if need_render:
+            lbs = engine.lbs_forward(dm, betas, theta, trans=trans, logscale=ls, btrans=bt, shared_beta=True,
+                                     logscale_shared=ls_shared, btrans_shared=bt_shared, propagate_scaling=self.propagate_scaling,
+                                     allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True)
+            d_fov_img = torch.zeros(n * views, dtype=torch.float32, device=dev)
+            d_verts = d_joints = None
+            if w_j2d > 0:
+                _, yx = engine.project(cams, lbs["joints"], want_ndc=False)
+                tj = self._tj_dev if idx is None else self._tj_dev.index_select(0, img_idx)
+                vis = self._vis_dev if idx is None else self._vis_dev.index_select(0, img_idx)
+                d_yx = torch.empty_like(yx)
+                Jc = self._canon_dev.numel()
+                engine.joint_loss(fc, views, Jc, None if self._canon_identity else self._canon_dev, yx, tj.contiguous(),
+                                  vis.contiguous(), objs, d_yx)
+                d_joints, _ = engine.project_backward(cams, lbs["joints"], d_yx=d_yx, d_fov_img=d_fov_img)
+            if w_reproj > 0:
+                ndc, _ = engine.project(cams, lbs["verts"], want_yx=False)
+                tgt = self._sil_dev if idx is None else self._sil_dev.index_select(0, img_idx).contiguous()
+                tsum = self._sil_sum if idx is None else self._sil_sum.index_select(0, img_idx).contiguous()
+                pscale = engine.pix_scale(fc, views, S, dev)
+                loss_img, d_ndc, _ = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings)
+                engine.sil_objective(loss_img, pscale, objs)
+                d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img)
+            d_fov_sel = engine.fov_reduce(cams, d_fov_img)
+            if fov.numel() in (1, views) or idx is None:
+                d_fov = d_fov_sel
+            else:
+                d_fov.index_add_(0, img_idx, d_fov_sel)
+            g_lbs = engine.lbs_backward(dm, lbs, d_verts, d_joints, need_beta=self.betas.requires_grad,
+                                        need_logscale=self.log_beta_scales.requires_grad,
+                                        need_btrans=self.betas_trans.requires_grad, need_trans=self.trans.requires_grad)
+        if g_lbs is not None and g_lbs["d_theta"] is not None:
+            d_pose = g_lbs["d_theta"]
+            d_trans = g_lbs["d_trans"] if g_lbs["d_trans"] is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
+            if g_lbs["d_beta"] is not None:
+                d_betas += g_lbs["d_beta"]
+            accumulate = True
+        else:
+            d_pose = torch.empty(n, J, 3, dtype=torch.float32, device=dev)
+            d_trans = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+            accumulate = False
+        engine.prior_losses(fc, pose, trans, betas, self.mean_betas, self.betas_prec, mask, objs, d_pose, d_trans, d_betas,
+                            halo_prev=halo_prev, halo_next=halo_next, accumulate=accumulate)
+
+        def scatter(rows, like):
+            if idx is None:
+                return rows
+            full = torch.zeros_like(like)
+            full.index_copy_(0, idx, rows)
+            return full
+
+        def table_grad(g, shared, like):
+            if g is None:
+                return torch.zeros_like(like)
+            return g.reshape(like.shape) if shared else scatter(g, like)
+
+        grads = dict(
+            betas=d_betas if self.betas.requires_grad else None,
+            pose=scatter(d_pose, self._pose),
+            trans=scatter(d_trans, self.trans),
+            log_beta_scales=table_grad(g_lbs["d_logscale"] if g_lbs else None, ls_shared, self.log_beta_scales)
+            if self.log_beta_scales.requires_grad else None,
+            betas_trans=table_grad(g_lbs["d_btrans"] if g_lbs else None, bt_shared, self.betas_trans)
+            if self.betas_trans.requires_grad else None,
+            fov=d_fov.reshape(self.fov.shape) if self.fov.requires_grad else None,
+        )
+        return objs, grads
+
+    # ------------------------------------------------------------------------------------------
+    # reference API
+    # ------------------------------------------------------------------------------------------
+    def forward(self, batch_range, weights, stage_id):
+        """Reference fitter.py:236-335: ``(sum of the weighted terms, dict of the terms)`` for one window."""
+        total, objs = _FitWindow.apply(self, list(batch_range), [float(w) for w in weights], 0.0, self.betas, self.log_beta_scales,
+                                       self.betas_trans, self._pose_leaf(), self.trans, self.fov)
+        out = {}
+        for k, name in enumerate(OBJ_NAMES):
+            w = float(weights[{"joint": 0, "sil_reproj": 1, "betas": 2, "pose": 3, "limit": 4, "splay": 5}[name]])
+            if w > 0 and not (name == "sil_reproj" and self.rgb_only):
+                out[name] = objs[k]
+        return total, out
+
+    def _pose_leaf(self):
+        """Autograd handle tying the fused pose gradient to the two rotation Parameters."""
+        return torch.cat([self.global_rotation[:, None], self.joint_rotations], dim=1)
+
+    def get_temporal(self, w_temp):
+        """Reference fitter.py:337-350: (joint_loss, global_loss, trans_loss) over consecutive frames."""
+        total, objs = _TemporalTerm.apply(self, float(w_temp), self._pose_leaf(), self.trans)
+        # the three terms share one backward; hand the graph to the first and return the others detached
+        joint = total - (objs[7] + objs[8]).detach()
+        return joint, objs[7].detach(), objs[8].detach()
+
+    def load_checkpoint(self, checkpoint_path, epoch):
+        """Reference fitter.py:352-371: per-frame ``<frame>/<epoch>.pkl`` parameter dicts; betas/scales averaged."""
+        beta_list, scale_list = [], []
+        with torch.no_grad():
+            for frame_id in range(self.num_images):
+                with open(os.path.join(checkpoint_path, "{0:04}".format(frame_id), "{0}.pkl".format(epoch)), "rb") as f:
+                    p = pkl.load(f)
+                self.global_rotation[frame_id] = torch.from_numpy(np.asarray(p["global_rotation"])).float().to(self.device).reshape(3)
+                self.joint_rotations[frame_id] = torch.from_numpy(np.asarray(p["joint_rotations"])).float().to(self.device).view(-1, 3)
+                self.trans[frame_id] = torch.from_numpy(np.asarray(p["trans"])).float().to(self.device).reshape(3)
+                beta_list.append(np.asarray(p["betas"]).reshape(-1)[: self.n_betas])
+                scale_list.append(np.asarray(p["log_betascale"]))
+        self.betas = nn.Parameter(torch.from_numpy(np.mean(beta_list, axis=0)).float().to(self.device))
+        scales = torch.from_numpy(np.mean(scale_list, axis=0)).float().to(self.device).reshape(1, -1, 3)
+        self.log_beta_scales = nn.Parameter(scales, requires_grad=self.log_beta_scales.requires_grad)
+
+    def export_parameters(self, frame_id: int) -> Dict[str, np.ndarray]:
+        """The per-frame dict the reference pickles (optimize_to_joints.py:48-63, fitter.py:241-261,507)."""
+        ls = self.log_beta_scales.detach()
+        bt = self.betas_trans.detach()
+        return dict(
+            global_rotation=(self.global_rotation.detach()[frame_id] * self.global_mask[0]).cpu().numpy(),
+            joint_rotations=(self.joint_rotations.detach()[frame_id] * self.rotation_mask).cpu().numpy(),
+            betas=self.betas.detach().cpu().numpy(), trans=self.trans.detach()[frame_id].cpu().numpy(),
+            fov=self.fov.detach().reshape(-1)[min(frame_id, self.fov.numel() - 1)].cpu().numpy(),
+            log_betascale=ls[min(frame_id, ls.shape[0] - 1)].cpu().numpy(), betas_trans=bt[min(frame_id, bt.shape[0] - 1)].cpu().numpy())
+
+    # ------------------------------------------------------------------------------------------
+    # fused epoch (fast path)
+    # ------------------------------------------------------------------------------------------
+    def begin_stage(self, lr: float, fov_lr: float = 1.0, betas=(0.5, 0.999), eps: float = 1e-8):
+        """New Adam state per stage, like the reference's new optimiser per stage (optimize_to_joints.py:117-127)."""
+        self._adam = {}
+        self._adam_step = 0
+        self._adam_hyper = dict(lr=float(lr), fov_lr=float(fov_lr), betas=betas, eps=eps)
+
+    def _param_tensor(self, name: str) -> torch.Tensor:
+        return self._pose if name == "pose" else getattr(self, name).data
+
+    def apply_adam(self, grads: Dict[str, Optional[torch.Tensor]]):
+        """torch.optim.Adam(betas=(0.5,0.999)) semantics on every parameter that received a gradient."""
+        h = self._adam_hyper
+        self._adam_step += 1
+        for name, g in grads.items():
+            if g is None:
+                continue
+            p = self._param_tensor(name)
+            st = self._adam.get(name)
+            if st is None:
+                st = self._adam[name] = dict(m=torch.zeros_like(p), v=torch.zeros_like(p), t0=self._adam_step - 1)
+            lr = h["fov_lr"] if name == "fov" else h["lr"]
+            engine.adam_step(p, g.contiguous(), st["m"], st["v"], lr, self._adam_step - st["t0"], h["betas"][0], h["betas"][1], h["eps"])
+
+    def fit_step(self, weights, w_temp: float, window: Optional[int] = None, halo_prev=None, halo_next=None,
+                 shared_grad_hook=None):
+        """One epoch over all frames of this rank: losses + gradients + Adam.  Returns objs (10,) (device).
+
+        ``shared_grad_hook(dict of shared-parameter gradients)`` runs between backward and the optimiser step; the
+        multi-GPU driver all-reduces there."""
+        window = self.config.WINDOW_SIZE if window is None else window
+        objs, grads = self._loss_and_grads(None, weights, w_temp, window=window, halo_prev=halo_prev, halo_next=halo_next)
+        if shared_grad_hook is not None:
+            shared = {k: v for k, v in grads.items() if v is not None and self._is_shared(k)}
+            shared_grad_hook(shared, objs)
+        self.apply_adam(grads)
+        return objs
+
+    def _is_shared(self, name: str) -> bool:
+        if name in ("betas",):
+            return True
+        if name == "fov":
+            return self.fov.numel() in (1, self.views)
+        if name in ("log_beta_scales", "betas_trans"):
+            return getattr(self, name).shape[0] == 1
+        return False
+
+    def boundary_rows(self):
+        """(first, last) parameter rows [pose, trans] of this shard for the temporal halo exchange."""
+        rows = torch.cat([self._pose.reshape(self.num_images, -1), self.trans.detach()], 1)
+        return rows[0].contiguous(), rows[-1].contiguous()
+
+
+class _TemporalTerm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fitter, w_temp, pose, trans):
+        objs, grads = fitter._loss_and_grads(None, [0.0] * 6, w_temp, window=None)
+        ctx.grads = grads
+        return objs[6] + objs[7] + objs[8], objs.clone()
+
+    @staticmethod
+    def backward(ctx, g_total, _g):
+        g = ctx.grads
+        return None, None, g["pose"] * g_total, g["trans"] * g_total

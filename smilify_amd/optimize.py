@@ -1,0 +1,142 @@
+"""Stage / epoch driver of the fit, single- or multi-GPU.
+
+Mirrors the loop of reference smal_fitter/optimize_to_joints.py:110-178 (4 stages from ``OPT_WEIGHTS``, a
+fresh Adam(betas=(0.5,0.999)) per stage with ``fov`` in its own lr=1 group, stage 0 freezing
+joint rotations / betas / limb scales and masking visibility to the torso joints, every epoch = sum over
+windows of the window mean + temporal terms, one backward, one step) on top of ``SMALFitter.fit_step``.
+Image / mesh export of the reference driver is out of scope.
+
+Multi-GPU (one process per GPU, ``torch.distributed`` over RCCL): frames are split into contiguous shards
+aligned to ``WINDOW_SIZE`` so the sum over windows is a plain sum over ranks.  Per epoch there are two tiny
+collectives: an all-gather of each shard's first/last parameter row (temporal halo, 2 x (3J+3) floats per
+rank) and ONE all-reduce(SUM) of the flattened shared-parameter gradients + the 10 loss terms.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+
+@dataclass
+class ShardPlan:
+    """Contiguous frame range of one rank, aligned to loss windows."""
+
+    rank: int
+    world: int
+    n_total: int
+    window: int
+    start: int
+    stop: int
+
+    @property
+    def n_local(self) -> int:
+        return self.stop - self.start
+
+
+def plan_shards(n_total: int, world: int, window: int) -> List[ShardPlan]:
+    """Split ``n_total`` frames into ``world`` contiguous shards whose boundaries fall on window boundaries
+    (so that no loss window spans two ranks); earlier ranks take the extra windows."""
+    window = max(1, min(window, n_total))
+    n_win = (n_total + window - 1) // window
+    if n_win < world:
+        raise ValueError(f"{n_win} windows cannot be spread over {world} ranks; lower WINDOW_SIZE or use fewer GPUs")
+    base, extra = divmod(n_win, world)
+    plans, w0 = [], 0
+    for r in range(world):
+        w1 = w0 + base + (1 if r < extra else 0)
+        plans.append(ShardPlan(r, world, n_total, window, w0 * window, min(n_total, w1 * window)))
+        w0 = w1
+    return plans
+
+
+def exchange_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None
+                   ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """All-gather every shard's boundary rows; return (row before my first frame, row after my last frame)."""
+    if world == 1:
+        return None, None
+    mine = torch.stack([first_row, last_row]).contiguous()
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    prev_row = gathered[rank - 1][1].contiguous() if rank > 0 else None
+    next_row = gathered[rank + 1][0].contiguous() if rank + 1 < world else None
+    return prev_row, next_row
+
+
+def allreduce_shared(shared: Dict[str, torch.Tensor], objs: torch.Tensor, group=None) -> None:
+    """One fused all-reduce(SUM) over [shared-parameter gradients..., loss terms]; results written back in place."""
+    names = sorted(shared)
+    flat = torch.cat([shared[k].reshape(-1) for k in names] + [objs.reshape(-1)])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for k in names:
+        n = shared[k].numel()
+        shared[k].copy_(flat[o:o + n].reshape(shared[k].shape))
+        o += n
+    objs.copy_(flat[o:o + objs.numel()])
+
+
+@dataclass
+class StageSpec:
+    weights: Sequence[float]  # w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay
+    w_temp: float
+    epochs: int
+    lr: float
+
+
+def stages_from_config(cfg) -> List[StageSpec]:
+    tab = np.array(cfg.OPT_WEIGHTS, dtype=np.float64).T
+    return [StageSpec(list(row[:6]), float(row[6]), int(row[7]), float(row[8])) for row in tab]
+
+
+def configure_stage(fitter, stage_id: int, full_visibility: torch.Tensor) -> None:
+    """Parameter freezing and visibility masking of optimize_to_joints.py:129-145."""
+    cfg = fitter.config
+    if stage_id == 0:
+        fitter.joint_rotations.requires_grad = False
+        fitter.betas.requires_grad = False
+        fitter.log_beta_scales.requires_grad = False
+        fitter.fov.requires_grad = True
+        vis = torch.zeros_like(full_visibility)
+        vis[:, cfg.TORSO_JOINTS] = full_visibility[:, cfg.TORSO_JOINTS]
+        fitter.target_visibility = vis
+    else:
+        fitter.joint_rotations.requires_grad = True
+        fitter.betas.requires_grad = True
+        fitter.fov.requires_grad = True
+        if cfg.ALLOW_LIMB_SCALING:
+            fitter.log_beta_scales.requires_grad = True
+        fitter.target_visibility = full_visibility.clone()
+
+
+def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, world: int = 1, group=None,
+             on_epoch: Optional[Callable[[int, int, torch.Tensor], None]] = None, max_epochs: Optional[int] = None):
+    """Run the staged optimisation on this rank's shard; returns the per-epoch loss terms of the last stage."""
+    cfg = fitter.config
+    stages = stages or stages_from_config(cfg)
+    full_vis = fitter.target_visibility.clone()
+    hook = None
+    if world > 1:
+        hook = lambda shared, objs: allreduce_shared(shared, objs, group)  # noqa: E731
+    history = []
+    for stage_id, st in enumerate(stages):
+        configure_stage(fitter, stage_id, full_vis)
+        fitter.begin_stage(st.lr, fov_lr=1.0)
+        epochs = st.epochs if max_epochs is None else min(st.epochs, max_epochs)
+        history = []
+        for epoch in range(epochs):
+            first, last = fitter.boundary_rows()
+            halo_prev, halo_next = exchange_halos(first, last, rank, world, group)
+            objs = fitter.fit_step(st.weights, st.w_temp, window=cfg.WINDOW_SIZE, halo_prev=halo_prev, halo_next=halo_next,
+                                   shared_grad_hook=hook)
+            history.append(objs)
+            if on_epoch is not None:
+                on_epoch(stage_id, epoch, objs)
+    return history

@@ -1,0 +1,133 @@
+"""Drop-in ``Renderer`` module: same constructor, attributes and ``forward`` contract as the reference's
+``smal_fitter.p3d_renderer.Renderer`` (reference smal_fitter/p3d_renderer.py:21-152), without pytorch3d.
+
+``forward(vertices, points, faces)`` returns ``(silhouettes (B,1,S,S), projected points (B,P,2) in (y,x) px)``.
+Gradients flow to ``vertices``, ``points`` and ``cameras.fov``.  The colour (HardPhong) branch of the
+reference is visualisation only and is not part of this build: ``render_texture=True`` raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import engine, model_io
+from .cameras import FoVCameras, look_at_view_transform
+
+
+class _MeshTopology:
+    """Face table resident on the GPU for meshes that do not come from a SMAL model."""
+
+    def __init__(self, faces: np.ndarray, V: int, device):
+        J = 1
+        t = model_io.SmilModelTables(
+            name="topology", v_template=np.zeros((V, 3), np.float32), shapedirs=np.zeros((0, 3 * V), np.float32),
+            faces=faces.astype(np.int32), parents=np.array([-1], np.int32), depth=np.zeros(1, np.int32),
+            skin_idx=np.zeros((V, 4), np.int32), skin_w=np.concatenate([np.ones((V, 1), np.float32), np.zeros((V, 3), np.float32)], 1),
+            jreg_rowptr=np.zeros(J + 1, np.int32), jreg_col=np.zeros(0, np.int32), jreg_val=np.zeros(0, np.float32),
+            static_joints=True, J_static=np.zeros((1, 3), np.float32))
+        self.dm = engine.DeviceModel(t, device)
+
+
+class _RenderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dm, cams, S, rs, joints_only, vertices, points, fov):
+        v = vertices.detach().float().contiguous()
+        p = points.detach().float().contiguous()
+        cams = engine.CameraSet(cams.R, cams.T, fov.detach().float().contiguous(), cams.aspect, cams.views, S)
+        _, yx = engine.project(cams, p, want_ndc=False)
+        ctx.dm, ctx.cams, ctx.S, ctx.rs, ctx.joints_only = dm, cams, S, rs, joints_only
+        if joints_only:
+            ctx.save_for_backward(v, p)
+            return torch.zeros(0, device=v.device), yx
+        ndc, _ = engine.project(cams, v, want_yx=False)
+        sil = engine.silhouette_forward(dm, ndc, S, rs)
+        ctx.save_for_backward(v, p, ndc)
+        return sil[:, None], yx
+
+    @staticmethod
+    def backward(ctx, g_sil, g_yx):
+        cams = ctx.cams
+        if ctx.joints_only:
+            v, p = ctx.saved_tensors
+            ndc = None
+        else:
+            v, p, ndc = ctx.saved_tensors
+        N = p.shape[0] * cams.views
+        d_fov_img = torch.zeros(N, dtype=torch.float32, device=p.device)
+        d_v = None
+        if ndc is not None and g_sil is not None and ctx.needs_input_grad[5]:
+            d_ndc = engine.silhouette_backward(ctx.dm, ndc, ctx.S, g_sil.reshape(N, ctx.S, ctx.S).contiguous().float(), ctx.rs)
+            d_v, _ = engine.project_backward(cams, v, d_ndc=d_ndc, d_fov_img=d_fov_img)
+        d_p = None
+        if g_yx is not None:
+            d_p, _ = engine.project_backward(cams, p, d_yx=g_yx.contiguous().float(), d_fov_img=d_fov_img)
+        d_fov = engine.fov_reduce(cams, d_fov_img) if ctx.needs_input_grad[7] else None
+        return None, None, None, None, None, d_v, d_p, d_fov
+
+
+class Renderer(torch.nn.Module):
+    DEFAULT_ZNEAR = 0.001  # reference p3d_renderer.py:24-25
+    DEFAULT_ZFAR = 1000.0
+
+    def __init__(self, image_size, device, views: int = 1):
+        super().__init__()
+        self.image_size = int(image_size)
+        self.device = engine.require_gpu(device)
+        self.views = int(views)
+        R, T = look_at_view_transform(2.7, 0, 0, device=self.device)  # reference :34
+        self.cameras = FoVCameras(R, T, torch.tensor([60.0], device=self.device), None, self.DEFAULT_ZNEAR, self.DEFAULT_ZFAR)
+        self.raster_settings = engine.raster_settings()
+        self._topologies = {}
+        self._bound_model: Optional[engine.DeviceModel] = None
+
+    def bind_model(self, dm: engine.DeviceModel) -> None:
+        """Use the face table already resident with a SMAL model (skips the per-call topology lookup)."""
+        self._bound_model = dm
+
+    def set_camera_parameters(self, R, T, fov, aspect_ratio=None):
+        """Same contract as reference p3d_renderer.py:72-125 (fov squeezed to 1-D, scalar aspect broadcast)."""
+        dev = self.device
+        R = R.to(device=dev, dtype=torch.float32).reshape(-1, 3, 3).contiguous()
+        T = T.to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
+        fov = fov.to(device=dev, dtype=torch.float32)
+        if fov.dim() > 1:
+            fov = fov.squeeze(-1)
+        if fov.dim() == 0:
+            fov = fov.unsqueeze(0)
+        if aspect_ratio is not None:
+            if not isinstance(aspect_ratio, torch.Tensor):
+                aspect_ratio = torch.tensor(aspect_ratio, dtype=torch.float32, device=dev)
+            aspect_ratio = aspect_ratio.to(device=dev, dtype=torch.float32).reshape(-1)
+            if aspect_ratio.numel() == 1 and fov.numel() > 1:
+                aspect_ratio = aspect_ratio.expand_as(fov).contiguous()
+        self.cameras = FoVCameras(R, T, fov, aspect_ratio, self.DEFAULT_ZNEAR, self.DEFAULT_ZFAR)
+
+    def _device_model(self, faces: torch.Tensor, V: int) -> engine.DeviceModel:
+        dm = self._bound_model
+        f = faces[0] if faces.dim() == 3 else faces
+        if dm is not None and dm.V == V and dm.F == f.shape[0]:
+            return dm
+        key = (f.data_ptr(), tuple(f.shape), V)
+        if key not in self._topologies:
+            self._topologies[key] = _MeshTopology(f.detach().cpu().numpy(), V, self.device)
+        return self._topologies[key].dm
+
+    def forward(self, vertices, points, faces, render_texture=False, joints_only=False):
+        if render_texture:
+            raise NotImplementedError("the colour / HardPhong branch is visualisation only and not part of this build")
+        cam = self.cameras
+        B = vertices.shape[0]
+        views = self.views
+        N = B * views
+        cs = engine.CameraSet(cam.R.contiguous(), cam.T.contiguous(), cam.fov, None if cam.aspect_ratio is None else cam.aspect_ratio.contiguous(),
+                              views, self.image_size)
+        for name, k in (("R", cam.R.shape[0]), ("T", cam.T.shape[0]), ("fov", cam.fov.numel())):
+            if k not in (1, views, N):
+                raise ValueError(f"cameras.{name} has {k} entries for {N} images")
+        dm = None if joints_only else self._device_model(faces.long(), vertices.shape[1])
+        sil, proj = _RenderFunction.apply(dm, cs, self.image_size, self.raster_settings, bool(joints_only), vertices, points, cam.fov)
+        if joints_only:
+            return None, proj
+        return sil, proj

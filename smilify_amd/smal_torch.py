@@ -1,0 +1,131 @@
+"""Drop-in ``SMAL`` module: same constructor, attributes and ``__call__`` contract as the reference's
+``smal_model.smal_torch.SMAL`` (reference smal_model/smal_torch.py:88-370), computed by the HIP library.
+
+Differences that are deliberate and documented:
+* the model path comes from ``model_path=`` / ``tables=`` / ``smilify_amd.config.current.SMAL_FILE``
+  (the reference reads the global ``config.SMAL_FILE`` at construction, :92);
+* dense ``weights`` / ``J_regressor`` / ``posedirs`` attributes exist for callers that read them, but the
+  kernels use the compact tables of ``model_io``;
+* gradients flow to ``beta, theta (axis-angle), trans, betas_logscale, betas_trans`` through ``verts`` and
+  ``joints``; ``Rs`` and ``v_shaped`` are returned without gradient, and ``del_v`` / rotation-matrix ``theta``
+  receive none;
+* non-empty pose blend shapes (legacy SMAL ``posedirs``) are not supported: every SMIL model ships an empty
+  table (reference :182-190) - a model with real posedirs raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import config as _config
+from . import engine, model_io
+
+
+class _LbsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dm, flags, beta, theta, trans, logscale, btrans, del_v, v_template):
+        dev = dm.device
+        c = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        theta_c = c(theta)
+        rot_in = theta_c is not None and theta_c.dim() == 4
+        out = engine.lbs_forward(
+            dm, c(beta), None if rot_in else theta_c, trans=c(trans), logscale=c(logscale), btrans=c(btrans), del_v=c(del_v),
+            v_template=c(v_template), Rs_in=theta_c if rot_in else None, propagate_scaling=flags["propagate_scaling"],
+            allow_limb_scaling=flags["allow_limb_scaling"])
+        ctx.dm, ctx.saved = dm, out
+        ctx.has = (beta is not None and beta.shape[-1] > 0, not rot_in, trans is not None, logscale is not None, btrans is not None)
+        v_shaped = out["v_shaped"]
+        ctx.mark_non_differentiable(out["Rs"], v_shaped, out["new_J"])
+        return out["verts"], out["joints"], out["Rs"], v_shaped, out["new_J"]
+
+    @staticmethod
+    def backward(ctx, d_verts, d_joints, _dRs, _dvs, _dnj):
+        need = ctx.needs_input_grad  # (dm, flags, beta, theta, trans, logscale, btrans, del_v, v_template)
+        dv = None if d_verts is None else d_verts.contiguous()
+        dj = None if d_joints is None else d_joints.contiguous()
+        if dv is None and dj is None:
+            return (None,) * 9
+        g = engine.lbs_backward(ctx.dm, ctx.saved, dv, dj, need_beta=need[2] and ctx.has[0], need_theta=need[3] and ctx.has[1],
+                                need_logscale=need[5] and ctx.has[3], need_btrans=need[6] and ctx.has[4],
+                                need_trans=need[4] and ctx.has[2])
+        return None, None, g["d_beta"], g["d_theta"], g["d_trans"], g["d_logscale"], g["d_btrans"], None, None
+
+
+class SMAL(nn.Module):
+    def __init__(self, device, shape_family_id=-1, dtype=torch.float, model_path: Optional[str] = None,
+                 tables: Optional[model_io.SmilModelTables] = None, config: Optional[_config.FitterConfig] = None):
+        super().__init__()
+        if shape_family_id != -1:
+            raise NotImplementedError("shape families need the MPI-licensed SMAL data file, which SMIL models do not use")
+        if dtype not in (torch.float, torch.float32):
+            raise NotImplementedError("the HIP path computes in fp32")
+        if tables is None:
+            cfg0 = config or _config.current
+            path = model_path or (cfg0.SMAL_FILE if cfg0 is not None else None)
+            if path is None:
+                raise ValueError("SMAL needs model_path=, tables= or smilify_amd.config.current.SMAL_FILE")
+            tables = model_io.load_model(path)
+        if tables.posedirs is not None:
+            raise NotImplementedError("non-empty pose blend shapes are not supported by the HIP path")
+        self.tables = tables
+        self.config = config or _config.current or _config.FitterConfig.from_tables(tables, model_path)
+        self.device = engine.require_gpu(device)
+        self._dm = engine.DeviceModel(tables, self.device)
+        t = tables
+        dev = self.device
+        # attributes the reference exposes (plain tensors, not registered buffers: smal_torch.py:104-196)
+        self.f = t.faces
+        self.faces = torch.from_numpy(t.faces.astype(np.int64)).to(dev)
+        self.size = [t.V, 3]
+        self.num_betas = t.nB
+        self.v_template = torch.from_numpy(t.v_template).to(dev)
+        self.shapedirs = torch.from_numpy(t.shapedirs).to(dev)
+        self.parents = t.parents.copy()
+        self.left_inds = self.right_inds = self.center_inds = np.array([])
+        if t.static_joints:
+            self.J = torch.from_numpy(t.J_static).to(dev)
+        self.J_transformed = None
+        self._dense = {}
+
+    # dense views are built lazily: nothing on the hot path reads them
+    def _lazy(self, name, builder):
+        if name not in self._dense:
+            self._dense[name] = torch.from_numpy(builder()).to(self.device)
+        return self._dense[name]
+
+    @property
+    def weights(self):
+        return self._lazy("weights", self.tables.dense_weights)
+
+    @property
+    def J_regressor(self):
+        return self._lazy("J_regressor", self.tables.dense_J_regressor)
+
+    @property
+    def posedirs(self):
+        return self._lazy("posedirs", lambda: np.zeros(((self.tables.J - 1) * 9, self.tables.V * 3), np.float32))
+
+    @property
+    def device_model(self) -> engine.DeviceModel:
+        return self._dm
+
+    def __call__(self, beta, theta, trans=None, del_v=None, betas_logscale=None, betas_trans=None, get_skin=True,
+                 v_template=None, propagate_scaling=False):
+        J = self.tables.J
+        if theta.shape[1] != J:  # reference :282-287: wrong joint count -> zero pose
+            theta = torch.zeros(beta.shape[0] if beta.shape[1] > 0 else 1, J, 3, device=self.device)
+        B = theta.shape[0]
+        if beta.shape[0] != B:
+            beta = beta.expand(B, -1)
+        if beta.shape[1] > self.tables.nB:
+            raise ValueError(f"beta has {beta.shape[1]} columns but the model has {self.tables.nB} shape directions")
+        flags = dict(propagate_scaling=bool(propagate_scaling), allow_limb_scaling=bool(self.config.ALLOW_LIMB_SCALING))
+        verts, joints, Rs, v_shaped, new_J = _LbsFunction.apply(self._dm, flags, beta, theta, trans, betas_logscale, betas_trans,
+                                                                del_v, v_template)
+        self.J_transformed = new_J
+        if get_skin:
+            return verts, joints, Rs, v_shaped
+        return joints

@@ -254,10 +254,11 @@ def test_prior_joint_losses_and_adam():
     cu = lambda x: x.detach().to(DEV).contiguous()  # noqa: E731
     cfg = eng.fit_config(N, J, nB, W, weights, w_temp)
     objs = torch.zeros(10, device=DEV)
-    dg, dj, dt, db = (torch.zeros(N, 3, device=DEV), torch.zeros(N, J - 1, 3, device=DEV), torch.zeros(N, 3, device=DEV),
-                      torch.zeros(nB, device=DEV))
-    eng.prior_losses(cfg, cu(P["global_rotation"]), cu(P["joint_rotations"]), cu(P["trans"]), cu(P["betas"]), cu(mean_b), cu(prec),
-                     cu(gmask.reshape(3)), cu(rmask), objs, dg, dj, dt, db, accumulate=False)
+    pose = cu(torch.cat([P["global_rotation"][:, None], P["joint_rotations"]], 1))
+    mask = cu(torch.cat([gmask, rmask], 0))
+    dp, dt, db = torch.zeros(N, J, 3, device=DEV), torch.zeros(N, 3, device=DEV), torch.zeros(nB, device=DEV)
+    eng.prior_losses(cfg, pose, cu(P["trans"]), cu(P["betas"]), cu(mean_b), cu(prec), mask, objs, dp, dt, db, accumulate=False)
+    dg, dj = dp[:, 0], dp[:, 1:]
     o = objs.cpu().numpy()
     np.testing.assert_allclose(o[1:5], [objs_ref[k] for k in ("limit", "pose", "splay", "betas")], rtol=2e-5)
     np.testing.assert_allclose(o[6:9], [tj.item(), tg.item(), tt.item()], rtol=2e-5)
@@ -272,13 +273,11 @@ def test_prior_joint_losses_and_adam():
     for f0, n in ((0, split), (split, N - split)):
         c2 = eng.fit_config(n, J, nB, W, weights, w_temp, frame0=f0, N_total=N)
         sl = slice(f0, f0 + n)
-        a, b, c_, d = (torch.zeros(n, 3, device=DEV), torch.zeros(n, J - 1, 3, device=DEV), torch.zeros(n, 3, device=DEV),
-                       torch.zeros(nB, device=DEV))
-        eng.prior_losses(c2, cu(P["global_rotation"][sl]), cu(P["joint_rotations"][sl]), cu(P["trans"][sl]), cu(P["betas"]), cu(mean_b),
-                         cu(prec), cu(gmask.reshape(3)), cu(rmask), objs2, a, b, c_, d,
+        b, c_, d = torch.zeros(n, J, 3, device=DEV), torch.zeros(n, 3, device=DEV), torch.zeros(nB, device=DEV)
+        eng.prior_losses(c2, pose[sl].contiguous(), cu(P["trans"][sl]), cu(P["betas"]), cu(mean_b), cu(prec), mask, objs2, b, c_, d,
                          halo_prev=cu(rows[f0 - 1]) if f0 > 0 else None, halo_next=cu(rows[f0 + n]) if f0 + n < N else None,
                          accumulate=False)
-        parts.append((a, b, c_, d))
+        parts.append((None, b[:, 1:], c_, d))
     np.testing.assert_allclose(objs2.cpu().numpy(), o, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(torch.cat([p[1] for p in parts]).cpu().numpy(), dj.cpu().numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose((parts[0][3] + parts[1][3]).cpu().numpy(), db.cpu().numpy(), rtol=1e-5)

@@ -15,11 +15,14 @@
 //  * k_raster_tiles (persistent, one 64-lane wavefront = one 8x8 tile, lane = pixel): dequeues work
 //    items, compacts the face ids whose bbox meets the tile (ballot prefix -> order preserved), stages
 //    their vertices through LDS in chunks of 64 and streams them to all 64 pixels (LDS broadcast reads).
-//      pass 1: candidate count, product of all candidates and a per-pixel max-heap (in LDS, 4 B/entry)
-//              of the K smallest depths;  pixels with <= K candidates are done.
+//      pass 1: candidate count, product of all candidates and the K smallest depths of every pixel kept
+//              SORTED IN REGISTERS: inserting z is r[i] = med3(r[i-1], r[i], z) for all i - one
+//              v_med3_f32 per slot, branch-free, no LDS (an LDS heap capped occupancy at 1 wave/SIMD and
+//              its sift loops were dependent-LDS-latency chains).  Pixels with <= K candidates are done.
 //      pass 2: (only if some pixel has > K candidates) product over the K nearest: depth < t, plus the
 //              first r faces (ascending face id) with depth == t, t = K-th smallest depth.
-//      pass 3: (backward / fused) per-face gradient, wave-reduced with DPP, 6 atomics per face.
+//      pass 3: (backward / fused) per-pair gradient added to per-face LDS accumulators (ds_add_f32),
+//              flushed once per 64-face chunk with one global atomic per touched vertex component.
 //  * Deviation from the reference kept on purpose: ties at the K-th depth are resolved by face id, the
 //    reference's unsorted-queue eviction depends on visiting history (measured effect on the L1 loss:
 //    ~1e-5 relative, tests/test_raster_parity.py).
@@ -169,8 +172,7 @@ __device__ __forceinline__ bool eval_face(const FaceRec &f, float px, float py, 
     const float b1 = edge_fn(px, py, f.x2, f.y2, f.x0, f.y0) * f.rcp_area;
     const float b2 = edge_fn(px, py, f.x0, f.y0, f.x1, f.y1) * f.rcp_area;
     const float w0 = b0 * f.z12, w1 = b1 * f.z02, w2 = b2 * f.z01;
-    const float den = fmaxf(w0 + w1 + w2, K_EPS);
-    const bool inside = (w0 > 0.f) && (w1 > 0.f) && (w2 > 0.f);  // sign(w_i/den) = sign(w_i), den > 0
+    const bool inside = (w0 > 0.f) && (w1 > 0.f) && (w2 > 0.f);  // sign(w_i / den) = sign(w_i): den > 0
     const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
     const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
     const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
@@ -179,26 +181,38 @@ __device__ __forceinline__ bool eval_face(const FaceRec &f, float px, float py, 
     c.inside = inside;
     c.sd = inside ? -dist : dist;
     if (WANT_PZ) {
-        const float p0 = w0 / den, p1 = w1 / den, p2 = w2 / den;
-        float c0 = fmaxf(p0, 0.f), c1 = fmaxf(p1, 0.f), c2 = fmaxf(p2, 0.f);
-        const float cs = fmaxf(c0 + c1 + c2, 1e-5f);
-        c0 = c0 / cs; c1 = c1 / cs; c2 = c2 / cs;  // exact division: x/x == 1 keeps shared-vertex depth ties exact
-        c.pz = c0 * f.z0 + c1 * f.z1 + c2 * f.z2;
+        // clipped, renormalised perspective-correct barycentrics: c_i = max(p_i,0) / max(sum, 1e-5) with
+        // p_i = w_i / den; the common factor 1/den cancels: c_i = max(w_i,0) / max(sum max(w,0), 1e-5 den)
+        const float den = fmaxf(w0 + w1 + w2, K_EPS);
+        const float m0 = fmaxf(w0, 0.f), m1 = fmaxf(w1, 0.f), m2 = fmaxf(w2, 0.f);
+        const float cs = fmaxf(m0 + m1 + m2, 1e-5f * den);
+        // when only one weight survives the clip the depth is exactly that vertex's depth: faces sharing the
+        // vertex tie exactly (as with the reference's x / x == 1) and the tie rule stays well defined
+        float pz;
+        if (m1 == 0.f && m2 == 0.f && m0 >= cs) pz = f.z0;
+        else if (m0 == 0.f && m2 == 0.f && m1 >= cs) pz = f.z1;
+        else if (m0 == 0.f && m1 == 0.f && m2 >= cs) pz = f.z2;
+        else {
+            const float rc = __builtin_amdgcn_rcpf(cs);
+            pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
+        }
+        c.pz = pz;
     }
     return true;
 }
 
 __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
-    // sigmoid(-dist / sigma)
-    return 1.0f / (1.0f + expf(sd * inv_sigma));
+    // sigmoid(-dist / sigma) = 1 / (1 + e^{dist/sigma}); v_exp_f32 + v_rcp_f32 (1 ulp each)
+    return __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));
 }
 
 // ---------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------
-struct TileLds {
+struct alignas(16) TileLds {
     uint32_t list[LIST_CAP];
     float rec[FCHUNK * FREC];
+    float gacc[FCHUNK * 6];  // per staged face: d/d(x0,y0,x1,y1,x2,y2), pass 3
 };
 
 // Build the ordered list of faces of [seg0, seg1) whose tile box contains (tx,ty). Returns the count.
@@ -245,11 +259,10 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
     }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(64) k_raster_tiles(RasterArgs a) {
-    extern __shared__ float dyn[];          // heap: K * 64 floats, entry-major
+// KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD
+template <int MODE, int KT>
+__global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
     __shared__ TileLds lds;
-    float *heap = dyn;
     const int lane = threadIdx.x;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
@@ -270,9 +283,12 @@ __global__ void __launch_bounds__(64) k_raster_tiles(RasterArgs a) {
         const uint32_t *tbox_n = a.tbox + (size_t)n * a.F;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
-        // ---------------- pass 1: count, product of all, K-smallest-depth heap -----------------
+        // ---------------- pass 1: count, product of all, K smallest depths (sorted, in registers) ---------
         int cnt = 0;
         float prod_all = 1.0f;
+        float r[KT];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) r[i] = 3.0e38f;
         for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
             const int seg1 = min(a.F, seg0 + LIST_CAP);
             const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
@@ -281,37 +297,20 @@ __global__ void __launch_bounds__(64) k_raster_tiles(RasterArgs a) {
                 const int m = min(FCHUNK, ln - c0);
                 stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
                 __syncthreads();
-                if (in_img) {
-                    for (int i = 0; i < m; ++i) {
-                        const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                        Cand c;
-                        if (!eval_face<true>(f, px, py, a.blur, c)) continue;
+                for (int i = 0; i < m; ++i) {
+                    const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                    Cand c;
+                    float z = 3.0e38f;
+                    if (in_img && eval_face<true>(f, px, py, a.blur, c)) {
                         prod_all *= (1.0f - face_prob(c.sd, a.inv_sigma));
-                        const float z = c.pz;
-                        if (cnt < K) {  // sift-up insert
-                            int h = cnt;
-                            while (h > 0) {
-                                const int par = (h - 1) >> 1;
-                                const float zp = heap[par * WAVE + lane];
-                                if (zp < z) { heap[h * WAVE + lane] = zp; h = par; } else break;
-                            }
-                            heap[h * WAVE + lane] = z;
-                        } else if (z < heap[lane]) {  // replace the maximum, sift down
-                            int h = 0;
-                            while (true) {
-                                int ch = 2 * h + 1;
-                                if (ch >= K) break;
-                                float zc = heap[ch * WAVE + lane];
-                                if (ch + 1 < K) {
-                                    const float zr = heap[(ch + 1) * WAVE + lane];
-                                    if (zr > zc) { zc = zr; ch = ch + 1; }
-                                }
-                                if (zc > z) { heap[h * WAVE + lane] = zc; h = ch; } else break;
-                            }
-                            heap[h * WAVE + lane] = z;
-                        }
+                        z = c.pz;
                         ++cnt;
                     }
+                    if (__ballot(z < r[KT - 1]) == 0ull) continue;  // nobody's K-nearest set changes
+                    // sorted insert, dropping the largest: r'[i] = med3(r[i-1], r[i], z); r'[0] = min(r[0], z)
+#pragma unroll
+                    for (int s_ = KT - 1; s_ >= 1; --s_) r[s_] = __builtin_amdgcn_fmed3f(r[s_ - 1], r[s_], z);
+                    r[0] = fminf(r[0], z);
                 }
                 __syncthreads();
             }
@@ -321,10 +320,11 @@ __global__ void __launch_bounds__(64) k_raster_tiles(RasterArgs a) {
         float zt = 3.0e38f;  // depth threshold (K-th smallest)
         int r_ties = 0;
         if (__ballot(trunc) != 0ull) {
-            if (trunc) {
-                zt = heap[lane];
-                for (int e = 0; e < K; ++e) r_ties += (heap[e * WAVE + lane] == zt) ? 1 : 0;
-            }
+#pragma unroll
+            for (int i = 0; i < KT; ++i)
+                if (i == K - 1) zt = r[i];
+#pragma unroll
+            for (int i = 0; i < KT; ++i) r_ties += (i < K && r[i] == zt) ? 1 : 0;
             // ------------- pass 2: product over the K nearest for truncated pixels ---------------
             float prod = 1.0f;
             int ties = 0;
@@ -387,57 +387,52 @@ __global__ void __launch_bounds__(64) k_raster_tiles(RasterArgs a) {
             for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
                 const int m = min(FCHUNK, ln - c0);
                 stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
+                for (int i = lane; i < FCHUNK * 6; i += WAVE) lds.gacc[i] = 0.f;
                 __syncthreads();
-                for (int i = 0; i < m; ++i) {
-                    const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                    float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
-                    bool contrib = false;
-                    Cand c;
-                    if (active && eval_face<true>(f, px, py, a.blur, c)) {
-                        bool keep = true;
+                if (active) {
+                    for (int i = 0; i < m; ++i) {
+                        const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                        Cand c;
+                        if (!eval_face<true>(f, px, py, a.blur, c)) continue;
                         if (trunc) {
-                            keep = c.pz < zt;
+                            bool keep = c.pz < zt;
                             if (c.pz == zt && ties < r_ties) { keep = true; ++ties; }
+                            if (!keep) continue;
                         }
-                        if (keep) {
-                            const float pk = face_prob(c.sd, a.inv_sigma);
-                            float gd = coef * pk;          // d L / d (signed dist)
-                            gd = c.inside ? -gd : gd;       // d L / d (unsigned squared distance)
-                            if (gd != 0.f) {
-                                const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
-                                const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
-                                const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
-                                float ax, ay, bx, by;
-                                int e;
-                                if (d01 <= d02 && d01 <= d12) { ax = f.x0; ay = f.y0; bx = f.x1; by = f.y1; e = 0; }
-                                else if (d02 <= d01 && d02 <= d12) { ax = f.x0; ay = f.y0; bx = f.x2; by = f.y2; e = 1; }
-                                else { ax = f.x1; ay = f.y1; bx = f.x2; by = f.y2; e = 2; }
-                                const float bax = bx - ax, bay = by - ay;
-                                float t = (bax * (px - ax) + bay * (py - ay)) / (bax * bax + bay * bay);
-                                t = (t == t) ? fminf(fmaxf(t, 0.f), 1.f) : 0.f;
-                                const float qx = (1.0f - t) * ax + t * bx, qy = (1.0f - t) * ay + t * by;
-                                const float ex = 2.0f * (qx - px), ey = 2.0f * (qy - py);
-                                const float gax = gd * (1.0f - t) * ex, gay = gd * (1.0f - t) * ey;
-                                const float gbx = gd * t * ex, gby = gd * t * ey;
-                                if (e == 0) { g0x = gax; g0y = gay; g1x = gbx; g1y = gby; }
-                                else if (e == 1) { g0x = gax; g0y = gay; g2x = gbx; g2y = gby; }
-                                else { g1x = gax; g1y = gay; g2x = gbx; g2y = gby; }
-                                contrib = true;
-                            }
-                        }
+                        float gd = coef * face_prob(c.sd, a.inv_sigma);  // d L / d (signed dist)
+                        gd = c.inside ? -gd : gd;                          // d L / d (unsigned squared distance)
+                        if (gd == 0.f) continue;
+                        const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
+                        const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
+                        const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
+                        float ax, ay, bx, by, rl;
+                        int ia, ib;  // accumulator slots of the closest edge's end points
+                        if (d01 <= d02 && d01 <= d12) { ax = f.x0; ay = f.y0; bx = f.x1; by = f.y1; rl = f.rl01; ia = 0; ib = 2; }
+                        else if (d02 <= d01 && d02 <= d12) { ax = f.x0; ay = f.y0; bx = f.x2; by = f.y2; rl = f.rl02; ia = 0; ib = 4; }
+                        else { ax = f.x1; ay = f.y1; bx = f.x2; by = f.y2; rl = f.rl12; ia = 2; ib = 4; }
+                        const float bax = bx - ax, bay = by - ay;
+                        // t is treated as a constant by the reference backward; saturate(NaN) = 0 for a degenerate edge
+                        float t = rl < 0.f ? 0.f : fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) * rl, 0.f), 1.f);
+                        const float qx = (1.0f - t) * ax + t * bx, qy = (1.0f - t) * ay + t * by;
+                        const float ex = 2.0f * (qx - px) * gd, ey = 2.0f * (qy - py) * gd;
+                        float *acc = lds.gacc + i * 6;
+                        atomicAdd(acc + ia, (1.0f - t) * ex);
+                        atomicAdd(acc + ia + 1, (1.0f - t) * ey);
+                        atomicAdd(acc + ib, t * ex);
+                        atomicAdd(acc + ib + 1, t * ey);
                     }
-                    if (__ballot(contrib) == 0ull) continue;
-                    g0x = wave_sum(g0x); g0y = wave_sum(g0y);
-                    g1x = wave_sum(g1x); g1y = wave_sum(g1y);
-                    g2x = wave_sum(g2x); g2y = wave_sum(g2y);
-                    if (lane == 0) {
-                        if (g0x != 0.f) atomicAdd(&dn[2 * f.i0], g0x);
-                        if (g0y != 0.f) atomicAdd(&dn[2 * f.i0 + 1], g0y);
-                        if (g1x != 0.f) atomicAdd(&dn[2 * f.i1], g1x);
-                        if (g1y != 0.f) atomicAdd(&dn[2 * f.i1 + 1], g1y);
-                        if (g2x != 0.f) atomicAdd(&dn[2 * f.i2], g2x);
-                        if (g2y != 0.f) atomicAdd(&dn[2 * f.i2 + 1], g2y);
-                    }
+                }
+                __syncthreads();
+                // flush: lane = staged face, one global atomic per touched vertex component
+                if (lane < m) {
+                    const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FREC);
+                    const float *acc = lds.gacc + lane * 6;
+                    if (acc[0] != 0.f) atomicAdd(&dn[2 * f.i0], acc[0]);
+                    if (acc[1] != 0.f) atomicAdd(&dn[2 * f.i0 + 1], acc[1]);
+                    if (acc[2] != 0.f) atomicAdd(&dn[2 * f.i1], acc[2]);
+                    if (acc[3] != 0.f) atomicAdd(&dn[2 * f.i1 + 1], acc[3]);
+                    if (acc[4] != 0.f) atomicAdd(&dn[2 * f.i2], acc[4]);
+                    if (acc[5] != 0.f) atomicAdd(&dn[2 * f.i2 + 1], acc[5]);
                 }
                 __syncthreads();
             }
@@ -529,8 +524,16 @@ extern "C" int smil_profile_read(float *total_ms, int32_t *launches) {
 
 static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
-    const long long resident = 256LL * 5;  // 256 CUs x blocks per CU admitted by the LDS footprint
+    const long long resident = 256LL * 8;  // 256 CUs x 8 single-wave workgroups (2 waves per SIMD)
     return (int)(max_items < resident ? max_items : resident);
+}
+
+template <int MODE>
+static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
+    const dim3 grid(tile_grid(N, a.tiles_x)), block(64);
+    if (a.K <= 16) hipLaunchKernelGGL((k_raster_tiles<MODE, 16>), grid, block, 0, stream, a);
+    else if (a.K <= 104) hipLaunchKernelGGL((k_raster_tiles<MODE, 104>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_raster_tiles<MODE, SMIL_MAX_FACES_PER_PIXEL>), grid, block, 0, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
@@ -543,8 +546,7 @@ extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_nd
     SMIL_HIP(hipMemsetAsync(sil, 0, (size_t)N * S * S * sizeof(float), stream));
     a.sil = sil;
     PROF_BEGIN(stream);
-    hipLaunchKernelGGL(k_raster_tiles<MODE_FWD>, dim3(tile_grid(N, a.tiles_x)), dim3(64), (size_t)a.K * WAVE * sizeof(float),
-                       stream, a);
+    launch_tiles<MODE_FWD>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
@@ -561,8 +563,7 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
     SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
     a.grad_sil = grad_sil; a.d_ndc = d_ndc;
     PROF_BEGIN(stream);
-    hipLaunchKernelGGL(k_raster_tiles<MODE_BWD>, dim3(tile_grid(N, a.tiles_x)), dim3(64), (size_t)a.K * WAVE * sizeof(float),
-                       stream, a);
+    launch_tiles<MODE_BWD>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
@@ -582,8 +583,7 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
     a.target = target; a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
     PROF_BEGIN(stream);
-    hipLaunchKernelGGL(k_raster_tiles<MODE_FUSED>, dim3(tile_grid(N, a.tiles_x)), dim3(64),
-                       (size_t)a.K * WAVE * sizeof(float), stream, a);
+    launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;

@@ -1,0 +1,53 @@
+"""Run only the fused rasteriser on a bench workload (for rocprofv3 counter passes) and print work statistics."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from smilify_amd import engine, model_io, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="SMILy_STICK")
+ap.add_argument("--frames", type=int, default=512)
+ap.add_argument("--views", type=int, default=1)
+ap.add_argument("--S", type=int, default=256)
+ap.add_argument("--radius", type=float, default=2.7)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--mode", default="fused", choices=["fused", "fwd"])
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+tables = model_io.load_model(os.path.join(REPO, "data", "models", args.model + ".npz"))
+f = synthetic.make_problem(tables, args.frames, args.views, args.S, dev, radius=args.radius)
+f._refresh_targets()
+dm = f.device_model
+lbs = engine.lbs_forward(dm, f.betas.detach(), f._pose, trans=f.trans.detach().contiguous(), shared_beta=True, trans_after_joints=True)
+cam = f.renderer.cameras
+cams = engine.CameraSet(cam.R.contiguous(), cam.T.contiguous(), f.fov.detach(), None, args.views, args.S)
+ndc, _ = engine.project(cams, lbs["verts"], want_yx=False)
+N = ndc.shape[0]
+cfg = engine.fit_config(args.frames, dm.J, dm.nB, 10, synthetic.STAGE1_WEIGHTS)
+ps = engine.pix_scale(cfg, args.views, args.S, dev)
+for it in range(args.reps + 1):
+    if it == 1:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    if args.mode == "fused":
+        engine.silhouette_l1_fused(dm, ndc, args.S, f._sil_dev, f._sil_sum, ps)
+    else:
+        engine.silhouette_forward(dm, ndc, args.S)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.reps
+ws = dm._ws
+off = ((N * dm.F * 4 + 255) // 256) * 256
+ctr = ws[off:off + 8].view(torch.int32).cpu().numpy()
+tb = ws[: N * dm.F * 4].view(torch.int32).reshape(N, dm.F).cpu().numpy().astype(np.uint32)
+tx0, ty0, tx1, ty1 = tb & 255, (tb >> 8) & 255, (tb >> 16) & 255, tb >> 24
+valid = tx0 <= tx1
+tiles_per_face = np.where(valid, (tx1.astype(int) - tx0 + 1) * (ty1.astype(int) - ty0 + 1), 0)
+print(f"images {N}  time/launch {dt*1e3:.2f} ms  {dt/N*1e6:.1f} us/image  work items {ctr[0]} ({ctr[0]/N:.1f} tiles/image)  "
+      f"valid faces/image {valid.sum(1).mean():.0f}  (tile,face) pairs/image {tiles_per_face.sum(1).mean():.0f}  "
+      f"avg list length {tiles_per_face.sum()/max(ctr[0],1):.0f}")

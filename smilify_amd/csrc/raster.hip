@@ -31,7 +31,7 @@
 #define TILE 8
 #define LIST_CAP 1024       // face ids per list segment (LDS)
 #define FCHUNK 64           // faces staged per chunk
-#define FREC 24             // floats per staged face record
+#define FREC 32             // floats per staged face record
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
 
@@ -139,66 +139,69 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // per-(pixel, face) evaluation
 // ---------------------------------------------------------------------------------------------
-struct FaceRec {  // staged in LDS, FREC floats
-    float x0, y0, x1, y1;
-    float x2, y2, z0, z1;
-    float z2, rcp_area, rl01, rl02;
-    float rl12, xmin, xmax, ymin;
-    float ymax, z12, z02, z01;
-    int fid, i0, i1, i2;
+// Face record staged in LDS (32 floats = 8 x 16 B, read with ds_read_b128 broadcasts).  Everything that does
+// not depend on the pixel is folded in once per (tile, face): coordinates are relative to the tile centre
+// (cx, cy) so the affine forms below do not cancel catastrophically.
+//   w_i(p) = A_i dx + B_i dy + C_i  = b_i(p) * z_j z_k   (perspective-correct barycentric numerators; the
+//            common denominator is positive, so inside <=> all w_i > 0)
+struct alignas(16) FaceRec {
+    float xmin, xmax, ymin, ymax;   // blurred bbox (absolute NDC)
+    float A0, B0, C0, A1;
+    float B1, C1, A2, B2;
+    float C2, z0, z1, z2;
+    float x0c, y0c, x1c, y1c;       // v0, v1 relative to the tile centre
+    float e01x, e01y, rl01, e02x;   // edge vectors and 1/|e|^2 (0 for a degenerate edge)
+    float e02y, rl02, e12x, e12y;
+    float rl12;
+    int i0, i1, i2;
+};
+static_assert(sizeof(FaceRec) == FREC * sizeof(float), "FaceRec layout");
+
+struct PairEval {
+    bool cand, inside;
+    float sd;             // signed squared distance
+    float w0, w1, w2;
+    float d01, d02, d12;  // squared distances to the three edge segments
+    float t01, t02, t12;  // clamped projections
+    float r01x, r01y, r02x, r02y, r12x, r12y;  // closest point minus pixel, per edge
 };
 
-__device__ __forceinline__ float seg_d2(float px, float py, float ax, float ay, float bx, float by, float rl2) {
-    const float bax = bx - ax, bay = by - ay;
-    if (rl2 < 0.f) {  // degenerate edge (|b-a|^2 <= 1e-8): distance to b
-        const float dx = px - bx, dy = py - by;
-        return dx * dx + dy * dy;
-    }
-    float t = (bax * (px - ax) + bay * (py - ay)) * rl2;
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    const float dx = (ax + t * bax) - px, dy = (ay + t * bay) - py;
-    return dx * dx + dy * dy;
+// Branch-free: every lane computes everything; `cand` says whether the pair exists.
+__device__ __forceinline__ void eval_pair(const FaceRec &f, float px, float py, float dxp, float dyp, float blur, PairEval &e) {
+    const bool in_bb = !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin);
+    e.w0 = fmaf(f.A0, dxp, fmaf(f.B0, dyp, f.C0));
+    e.w1 = fmaf(f.A1, dxp, fmaf(f.B1, dyp, f.C1));
+    e.w2 = fmaf(f.A2, dxp, fmaf(f.B2, dyp, f.C2));
+    e.inside = (e.w0 > 0.f) && (e.w1 > 0.f) && (e.w2 > 0.f);
+    const float dx0 = dxp - f.x0c, dy0 = dyp - f.y0c, dx1 = dxp - f.x1c, dy1 = dyp - f.y1c;
+    e.t01 = __builtin_amdgcn_fmed3f((f.e01x * dx0 + f.e01y * dy0) * f.rl01, 0.f, 1.f);
+    e.t02 = __builtin_amdgcn_fmed3f((f.e02x * dx0 + f.e02y * dy0) * f.rl02, 0.f, 1.f);
+    e.t12 = __builtin_amdgcn_fmed3f((f.e12x * dx1 + f.e12y * dy1) * f.rl12, 0.f, 1.f);
+    e.r01x = fmaf(e.t01, f.e01x, -dx0); e.r01y = fmaf(e.t01, f.e01y, -dy0);
+    e.r02x = fmaf(e.t02, f.e02x, -dx0); e.r02y = fmaf(e.t02, f.e02y, -dy0);
+    e.r12x = fmaf(e.t12, f.e12x, -dx1); e.r12y = fmaf(e.t12, f.e12y, -dy1);
+    e.d01 = e.r01x * e.r01x + e.r01y * e.r01y;
+    e.d02 = e.r02x * e.r02x + e.r02y * e.r02y;
+    e.d12 = e.r12x * e.r12x + e.r12y * e.r12y;
+    const float dist = fminf(fminf(e.d01, e.d02), e.d12);
+    e.cand = in_bb && (e.inside || dist < blur);
+    e.sd = e.inside ? -dist : dist;
 }
 
-struct Cand {
-    float pz, sd;   // clipped-barycentric depth, signed squared distance
-    bool inside;
-};
-
-template <bool WANT_PZ>
-__device__ __forceinline__ bool eval_face(const FaceRec &f, float px, float py, float blur, Cand &c) {
-    if (px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin) return false;
-    const float b0 = edge_fn(px, py, f.x1, f.y1, f.x2, f.y2) * f.rcp_area;
-    const float b1 = edge_fn(px, py, f.x2, f.y2, f.x0, f.y0) * f.rcp_area;
-    const float b2 = edge_fn(px, py, f.x0, f.y0, f.x1, f.y1) * f.rcp_area;
-    const float w0 = b0 * f.z12, w1 = b1 * f.z02, w2 = b2 * f.z01;
-    const bool inside = (w0 > 0.f) && (w1 > 0.f) && (w2 > 0.f);  // sign(w_i / den) = sign(w_i): den > 0
-    const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
-    const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
-    const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
-    const float dist = fminf(fminf(d01, d02), d12);
-    if (!inside && dist >= blur) return false;
-    c.inside = inside;
-    c.sd = inside ? -dist : dist;
-    if (WANT_PZ) {
-        // clipped, renormalised perspective-correct barycentrics: c_i = max(p_i,0) / max(sum, 1e-5) with
-        // p_i = w_i / den; the common factor 1/den cancels: c_i = max(w_i,0) / max(sum max(w,0), 1e-5 den)
-        const float den = fmaxf(w0 + w1 + w2, K_EPS);
-        const float m0 = fmaxf(w0, 0.f), m1 = fmaxf(w1, 0.f), m2 = fmaxf(w2, 0.f);
-        const float cs = fmaxf(m0 + m1 + m2, 1e-5f * den);
-        // when only one weight survives the clip the depth is exactly that vertex's depth: faces sharing the
-        // vertex tie exactly (as with the reference's x / x == 1) and the tie rule stays well defined
-        float pz;
-        if (m1 == 0.f && m2 == 0.f && m0 >= cs) pz = f.z0;
-        else if (m0 == 0.f && m2 == 0.f && m1 >= cs) pz = f.z1;
-        else if (m0 == 0.f && m1 == 0.f && m2 >= cs) pz = f.z2;
-        else {
-            const float rc = __builtin_amdgcn_rcpf(cs);
-            pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
-        }
-        c.pz = pz;
-    }
-    return true;
+// depth at the clipped, renormalised perspective-correct barycentrics:
+// c_i = max(p_i,0) / max(sum, 1e-5), p_i = w_i / den; 1/den cancels: c_i = max(w_i,0) / max(sum max(w,0), 1e-5 den).
+// When a single weight survives the clip the depth is EXACTLY that vertex's depth, so faces sharing the vertex tie
+// exactly (as x / x == 1 does in the reference) and the (depth, face id) order stays well defined.
+__device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e) {
+    const float den = fmaxf(e.w0 + e.w1 + e.w2, K_EPS);
+    const float m0 = fmaxf(e.w0, 0.f), m1 = fmaxf(e.w1, 0.f), m2 = fmaxf(e.w2, 0.f);
+    const float cs = fmaxf(m0 + m1 + m2, 1e-5f * den);
+    const float rc = __builtin_amdgcn_rcpf(cs);
+    float pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
+    pz = (m1 == 0.f && m2 == 0.f && m0 >= cs) ? f.z0 : pz;
+    pz = (m0 == 0.f && m2 == 0.f && m1 >= cs) ? f.z1 : pz;
+    pz = (m0 == 0.f && m1 == 0.f && m2 >= cs) ? f.z2 : pz;
+    return pz;
 }
 
 __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
@@ -210,54 +213,81 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
 // tile kernel
 // ---------------------------------------------------------------------------------------------
 struct alignas(16) TileLds {
-    uint32_t list[LIST_CAP];
     float rec[FCHUNK * FREC];
     float gacc[FCHUNK * 6];  // per staged face: d/d(x0,y0,x1,y1,x2,y2), pass 3
+    uint32_t list[LIST_CAP];
 };
 
 // Build the ordered list of faces of [seg0, seg1) whose tile box contains (tx,ty). Returns the count.
 __device__ __forceinline__ int build_list(const uint32_t *__restrict__ tbox_n, int seg0, int seg1, int tx, int ty,
                                           uint32_t *list, int lane) {
     int cnt = 0;
-    for (int base = seg0; base < seg1; base += WAVE) {
-        const int f = base + lane;
-        bool hit = false;
-        if (f < seg1) {
-            const uint32_t b = tbox_n[f];
-            const int tx0 = b & 0xFF, ty0 = (b >> 8) & 0xFF, tx1 = (b >> 16) & 0xFF, ty1 = b >> 24;
-            hit = (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
+    for (int base = seg0; base < seg1; base += 4 * WAVE) {
+        // four independent loads in flight per lane
+        uint32_t b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = base + u * WAVE + lane;
+            b[u] = f < seg1 ? tbox_n[f] : 0x0000FFFFu;
         }
-        const unsigned long long mask = __ballot(hit);
-        if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)f;
-        cnt += __popcll(mask);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tx0 = b[u] & 0xFF, ty0 = (b[u] >> 8) & 0xFF, tx1 = (b[u] >> 16) & 0xFF, ty1 = b[u] >> 24;
+            const bool hit = (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
+            const unsigned long long mask = __ballot(hit);
+            if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)(base + u * WAVE + lane);
+            cnt += __popcll(mask);
+        }
     }
     return cnt;
 }
 
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list,
-                                            int c0, int m, float *rec, int lane) {
+                                            int c0, int m, float *rec, int lane, float cx, float cy) {
     if (lane < m) {
         const int f = (int)list[c0 + lane];
         const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
+        const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
+        const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
+        const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
         FaceRec r;
-        r.x0 = vn[3 * i0]; r.y0 = vn[3 * i0 + 1]; r.z0 = vn[3 * i0 + 2];
-        r.x1 = vn[3 * i1]; r.y1 = vn[3 * i1 + 1]; r.z1 = vn[3 * i1 + 2];
-        r.x2 = vn[3 * i2]; r.y2 = vn[3 * i2 + 1]; r.z2 = vn[3 * i2 + 2];
-        const float area = edge_fn(r.x2, r.y2, r.x0, r.y0, r.x1, r.y1) + K_EPS;
-        r.rcp_area = 1.0f / area;
-        const float l01 = (r.x1 - r.x0) * (r.x1 - r.x0) + (r.y1 - r.y0) * (r.y1 - r.y0);
-        const float l02 = (r.x2 - r.x0) * (r.x2 - r.x0) + (r.y2 - r.y0) * (r.y2 - r.y0);
-        const float l12 = (r.x2 - r.x1) * (r.x2 - r.x1) + (r.y2 - r.y1) * (r.y2 - r.y1);
-        r.rl01 = l01 <= K_EPS ? -1.f : 1.0f / l01;
-        r.rl02 = l02 <= K_EPS ? -1.f : 1.0f / l02;
-        r.rl12 = l12 <= K_EPS ? -1.f : 1.0f / l12;
-        r.xmin = fminf(fminf(r.x0, r.x1), r.x2) - a.sqrt_blur; r.xmax = fmaxf(fmaxf(r.x0, r.x1), r.x2) + a.sqrt_blur;
-        r.ymin = fminf(fminf(r.y0, r.y1), r.y2) - a.sqrt_blur; r.ymax = fmaxf(fmaxf(r.y0, r.y1), r.y2) + a.sqrt_blur;
-        r.z12 = r.z1 * r.z2; r.z02 = r.z0 * r.z2; r.z01 = r.z0 * r.z1;
-        r.fid = f; r.i0 = i0; r.i1 = i1; r.i2 = i2;
+        r.xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur; r.xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
+        r.ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur; r.ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
+        const float rcp_area = 1.0f / (edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
+        // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
+        const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
+        r.A0 = (y2 - y1) * s0; r.B0 = -(x2 - x1) * s0; r.C0 = edge_fn(cx, cy, x1, y1, x2, y2) * s0;
+        r.A1 = (y0 - y2) * s1; r.B1 = -(x0 - x2) * s1; r.C1 = edge_fn(cx, cy, x2, y2, x0, y0) * s1;
+        r.A2 = (y1 - y0) * s2; r.B2 = -(x1 - x0) * s2; r.C2 = edge_fn(cx, cy, x0, y0, x1, y1) * s2;
+        r.z0 = z0; r.z1 = z1; r.z2 = z2;
+        r.x0c = x0 - cx; r.y0c = y0 - cy; r.x1c = x1 - cx; r.y1c = y1 - cy;
+        r.e01x = x1 - x0; r.e01y = y1 - y0; r.e02x = x2 - x0; r.e02y = y2 - y0; r.e12x = x2 - x1; r.e12y = y2 - y1;
+        const float l01 = r.e01x * r.e01x + r.e01y * r.e01y, l02 = r.e02x * r.e02x + r.e02y * r.e02y,
+                    l12 = r.e12x * r.e12x + r.e12y * r.e12y;
+        r.rl01 = l01 <= K_EPS ? 0.f : 1.0f / l01;
+        r.rl02 = l02 <= K_EPS ? 0.f : 1.0f / l02;
+        r.rl12 = l12 <= K_EPS ? 0.f : 1.0f / l12;
+        r.i0 = i0; r.i1 = i1; r.i2 = i2;
         *reinterpret_cast<FaceRec *>(rec + lane * FREC) = r;
     }
 }
+
+// Loop skeleton shared by the three passes: ordered face list per 1024-face segment, 64-face chunks staged in LDS.
+#define CHUNK_LOOP_BEGIN(ZERO_GACC)                                                            \
+    for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {                                         \
+        const int seg1 = min(a.F, seg0 + LIST_CAP);                                            \
+        const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);                 \
+        __syncthreads();                                                                       \
+        for (int c0 = 0; c0 < ln; c0 += FCHUNK) {                                              \
+            const int m = min(FCHUNK, ln - c0);                                                \
+            stage_faces(a, vn, lds.list, c0, m, lds.rec, lane, cx, cy);                        \
+            if (ZERO_GACC)                                                                     \
+                for (int i_ = lane; i_ < FCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.f;           \
+            __syncthreads();
+#define CHUNK_LOOP_END                                                                         \
+            __syncthreads();                                                                   \
+        }                                                                                      \
+    }
 
 // KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD
 template <int MODE, int KT>
@@ -278,7 +308,10 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
         const bool in_img = xo < a.S && yo < a.S;
-        const float px = pix_to_ndc(a.S - 1 - xo, a.S), py = pix_to_ndc(a.S - 1 - yo, a.S);
+        // pixels outside the image get a position no bbox can contain
+        const float px = in_img ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
+        const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
+        const float dxp = px - cx, dyp = py - cy;
         const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
         const uint32_t *tbox_n = a.tbox + (size_t)n * a.F;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
@@ -289,32 +322,25 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         float r[KT];
 #pragma unroll
         for (int i = 0; i < KT; ++i) r[i] = 3.0e38f;
-        for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
-            const int seg1 = min(a.F, seg0 + LIST_CAP);
-            const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
-            __syncthreads();
-            for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
-                const int m = min(FCHUNK, ln - c0);
-                stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
-                __syncthreads();
-                for (int i = 0; i < m; ++i) {
-                    const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                    Cand c;
-                    float z = 3.0e38f;
-                    if (in_img && eval_face<true>(f, px, py, a.blur, c)) {
-                        prod_all *= (1.0f - face_prob(c.sd, a.inv_sigma));
-                        z = c.pz;
-                        ++cnt;
-                    }
-                    if (__ballot(z < r[KT - 1]) == 0ull) continue;  // nobody's K-nearest set changes
-                    // sorted insert, dropping the largest: r'[i] = med3(r[i-1], r[i], z); r'[0] = min(r[0], z)
+        CHUNK_LOOP_BEGIN(false)
+        {
+            for (int i = 0; i < m; ++i) {
+                const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                if (__ballot(!(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
+                PairEval e;
+                eval_pair(f, px, py, dxp, dyp, a.blur, e);
+                const float fac = 1.0f - face_prob(e.sd, a.inv_sigma);
+                prod_all *= e.cand ? fac : 1.0f;
+                cnt += e.cand ? 1 : 0;
+                const float z = e.cand ? pair_depth(f, e) : 3.0e38f;
+                if (__ballot(z < r[KT - 1]) == 0ull) continue;  // nobody's K-nearest set changes
+                // sorted insert, dropping the largest: r'[i] = med3(r[i-1], r[i], z); r'[0] = min(r[0], z)
 #pragma unroll
-                    for (int s_ = KT - 1; s_ >= 1; --s_) r[s_] = __builtin_amdgcn_fmed3f(r[s_ - 1], r[s_], z);
-                    r[0] = fminf(r[0], z);
-                }
-                __syncthreads();
+                for (int s_ = KT - 1; s_ >= 1; --s_) r[s_] = __builtin_amdgcn_fmed3f(r[s_ - 1], r[s_], z);
+                r[0] = fminf(r[0], z);
             }
         }
+        CHUNK_LOOP_END
         const bool trunc = cnt > K;
         float alpha = prod_all;
         float zt = 3.0e38f;  // depth threshold (K-th smallest)
@@ -328,27 +354,24 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             // ------------- pass 2: product over the K nearest for truncated pixels ---------------
             float prod = 1.0f;
             int ties = 0;
-            for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
-                const int seg1 = min(a.F, seg0 + LIST_CAP);
-                const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
-                __syncthreads();
-                for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
-                    const int m = min(FCHUNK, ln - c0);
-                    stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
-                    __syncthreads();
-                    if (trunc && prod != 0.0f) {
-                        for (int i = 0; i < m; ++i) {
-                            const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                            Cand c;
-                            if (!eval_face<true>(f, px, py, a.blur, c)) continue;
-                            bool keep = c.pz < zt;
-                            if (c.pz == zt && ties < r_ties) { keep = true; ++ties; }
-                            if (keep) prod *= (1.0f - face_prob(c.sd, a.inv_sigma));
-                        }
+            CHUNK_LOOP_BEGIN(false)
+            {
+                if (__ballot(trunc && prod != 0.0f) != 0ull) {
+                    for (int i = 0; i < m; ++i) {
+                        const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                        if (__ballot(trunc && !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
+                        PairEval e;
+                        eval_pair(f, px, py, dxp, dyp, a.blur, e);
+                        const float pz = pair_depth(f, e);
+                        const bool tie = e.cand && trunc && (pz == zt) && (ties < r_ties);
+                        const bool keep = e.cand && trunc && ((pz < zt) || tie);
+                        ties += tie ? 1 : 0;
+                        const float fac = 1.0f - face_prob(e.sd, a.inv_sigma);
+                        prod *= keep ? fac : 1.0f;
                     }
-                    __syncthreads();
                 }
             }
+            CHUNK_LOOP_END
             if (trunc) alpha = prod;
         }
 
@@ -379,64 +402,55 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         const bool active = in_img && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
         if (__ballot(active) == 0ull) continue;
         float *dn = a.d_ndc + (size_t)n * a.V * 2;
+        const bool any_trunc = __ballot(trunc && active) != 0ull;
         int ties = 0;
-        for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {
-            const int seg1 = min(a.F, seg0 + LIST_CAP);
-            const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);
+        CHUNK_LOOP_BEGIN(true)
+        {
+            for (int i = 0; i < m; ++i) {
+                const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
+                if (__ballot(active && !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
+                PairEval e;
+                eval_pair(f, px, py, dxp, dyp, a.blur, e);
+                bool keep = e.cand && active;
+                if (any_trunc) {
+                    const float pz = pair_depth(f, e);
+                    const bool tie = keep && trunc && (pz == zt) && (ties < r_ties);
+                    ties += tie ? 1 : 0;
+                    keep = keep && (!trunc || (pz < zt) || tie);
+                }
+                float gd = coef * face_prob(e.sd, a.inv_sigma);  // d L / d (signed dist)
+                gd = e.inside ? -gd : gd;                          // d L / d (unsigned squared distance)
+                keep = keep && (gd != 0.f);
+                if (__ballot(keep) == 0ull) continue;
+                // closest edge in the reference's order e01, e02, e12 with <= ties; t is a constant in its backward
+                const bool c01 = (e.d01 <= e.d02) && (e.d01 <= e.d12);
+                const bool c02 = !c01 && (e.d02 <= e.d01) && (e.d02 <= e.d12);
+                const float t = c01 ? e.t01 : (c02 ? e.t02 : e.t12);
+                const float rx = c01 ? e.r01x : (c02 ? e.r02x : e.r12x), ry = c01 ? e.r01y : (c02 ? e.r02y : e.r12y);
+                const int ia = (c01 || c02) ? 0 : 2, ib = c01 ? 2 : 4;  // accumulator slots of the edge's end points
+                const float ex = 2.0f * rx * gd, ey = 2.0f * ry * gd;
+                if (keep) {
+                    float *acc = lds.gacc + i * 6;
+                    atomicAdd(acc + ia, (1.0f - t) * ex);
+                    atomicAdd(acc + ia + 1, (1.0f - t) * ey);
+                    atomicAdd(acc + ib, t * ex);
+                    atomicAdd(acc + ib + 1, t * ey);
+                }
+            }
             __syncthreads();
-            for (int c0 = 0; c0 < ln; c0 += FCHUNK) {
-                const int m = min(FCHUNK, ln - c0);
-                stage_faces(a, vn, lds.list, c0, m, lds.rec, lane);
-                for (int i = lane; i < FCHUNK * 6; i += WAVE) lds.gacc[i] = 0.f;
-                __syncthreads();
-                if (active) {
-                    for (int i = 0; i < m; ++i) {
-                        const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                        Cand c;
-                        if (!eval_face<true>(f, px, py, a.blur, c)) continue;
-                        if (trunc) {
-                            bool keep = c.pz < zt;
-                            if (c.pz == zt && ties < r_ties) { keep = true; ++ties; }
-                            if (!keep) continue;
-                        }
-                        float gd = coef * face_prob(c.sd, a.inv_sigma);  // d L / d (signed dist)
-                        gd = c.inside ? -gd : gd;                          // d L / d (unsigned squared distance)
-                        if (gd == 0.f) continue;
-                        const float d01 = seg_d2(px, py, f.x0, f.y0, f.x1, f.y1, f.rl01);
-                        const float d02 = seg_d2(px, py, f.x0, f.y0, f.x2, f.y2, f.rl02);
-                        const float d12 = seg_d2(px, py, f.x1, f.y1, f.x2, f.y2, f.rl12);
-                        float ax, ay, bx, by, rl;
-                        int ia, ib;  // accumulator slots of the closest edge's end points
-                        if (d01 <= d02 && d01 <= d12) { ax = f.x0; ay = f.y0; bx = f.x1; by = f.y1; rl = f.rl01; ia = 0; ib = 2; }
-                        else if (d02 <= d01 && d02 <= d12) { ax = f.x0; ay = f.y0; bx = f.x2; by = f.y2; rl = f.rl02; ia = 0; ib = 4; }
-                        else { ax = f.x1; ay = f.y1; bx = f.x2; by = f.y2; rl = f.rl12; ia = 2; ib = 4; }
-                        const float bax = bx - ax, bay = by - ay;
-                        // t is treated as a constant by the reference backward; saturate(NaN) = 0 for a degenerate edge
-                        float t = rl < 0.f ? 0.f : fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) * rl, 0.f), 1.f);
-                        const float qx = (1.0f - t) * ax + t * bx, qy = (1.0f - t) * ay + t * by;
-                        const float ex = 2.0f * (qx - px) * gd, ey = 2.0f * (qy - py) * gd;
-                        float *acc = lds.gacc + i * 6;
-                        atomicAdd(acc + ia, (1.0f - t) * ex);
-                        atomicAdd(acc + ia + 1, (1.0f - t) * ey);
-                        atomicAdd(acc + ib, t * ex);
-                        atomicAdd(acc + ib + 1, t * ey);
-                    }
-                }
-                __syncthreads();
-                // flush: lane = staged face, one global atomic per touched vertex component
-                if (lane < m) {
-                    const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FREC);
-                    const float *acc = lds.gacc + lane * 6;
-                    if (acc[0] != 0.f) atomicAdd(&dn[2 * f.i0], acc[0]);
-                    if (acc[1] != 0.f) atomicAdd(&dn[2 * f.i0 + 1], acc[1]);
-                    if (acc[2] != 0.f) atomicAdd(&dn[2 * f.i1], acc[2]);
-                    if (acc[3] != 0.f) atomicAdd(&dn[2 * f.i1 + 1], acc[3]);
-                    if (acc[4] != 0.f) atomicAdd(&dn[2 * f.i2], acc[4]);
-                    if (acc[5] != 0.f) atomicAdd(&dn[2 * f.i2 + 1], acc[5]);
-                }
-                __syncthreads();
+            // flush: lane = staged face, one global atomic per touched vertex component
+            if (lane < m) {
+                const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FREC);
+                const float *acc = lds.gacc + lane * 6;
+                if (acc[0] != 0.f) atomicAdd(&dn[2 * f.i0], acc[0]);
+                if (acc[1] != 0.f) atomicAdd(&dn[2 * f.i0 + 1], acc[1]);
+                if (acc[2] != 0.f) atomicAdd(&dn[2 * f.i1], acc[2]);
+                if (acc[3] != 0.f) atomicAdd(&dn[2 * f.i1 + 1], acc[3]);
+                if (acc[4] != 0.f) atomicAdd(&dn[2 * f.i2], acc[4]);
+                if (acc[5] != 0.f) atomicAdd(&dn[2 * f.i2 + 1], acc[5]);
             }
         }
+        CHUNK_LOOP_END
     }
 }
 

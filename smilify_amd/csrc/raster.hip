@@ -93,9 +93,10 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
         if (finite && !(zmin < K_EPS) && !(area <= K_EPS && area >= -K_EPS)) {
             const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
             const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
-            // pixel index i (flipped axis) has centre -1 + (2i+1)/S ; widen by one pixel against rounding
-            int xi_lo = (int)floorf(((xlo + 1.0f) * fS - 1.0f) * 0.5f) - 1, xi_hi = (int)ceilf(((xhi + 1.0f) * fS - 1.0f) * 0.5f) + 1;
-            int yi_lo = (int)floorf(((ylo + 1.0f) * fS - 1.0f) * 0.5f) - 1, yi_hi = (int)ceilf(((yhi + 1.0f) * fS - 1.0f) * 0.5f) + 1;
+            // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
+            // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides
+            int xi_lo = (int)ceilf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+            int yi_lo = (int)ceilf(((ylo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((yhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
             xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
             if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
@@ -220,7 +221,7 @@ struct alignas(16) TileLds {
 
 // Build the ordered list of faces of [seg0, seg1) whose tile box contains (tx,ty). Returns the count.
 __device__ __forceinline__ int build_list(const uint32_t *__restrict__ tbox_n, int seg0, int seg1, int tx, int ty,
-                                          uint32_t *list, int lane) {
+                                          uint32_t *list, int lane, int cap = LIST_CAP) {
     int cnt = 0;
     for (int base = seg0; base < seg1; base += 4 * WAVE) {
         // four independent loads in flight per lane
@@ -235,7 +236,8 @@ __device__ __forceinline__ int build_list(const uint32_t *__restrict__ tbox_n, i
             const int tx0 = b[u] & 0xFF, ty0 = (b[u] >> 8) & 0xFF, tx1 = (b[u] >> 16) & 0xFF, ty1 = b[u] >> 24;
             const bool hit = (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
             const unsigned long long mask = __ballot(hit);
-            if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)(base + u * WAVE + lane);
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < cap) list[pos] = (uint32_t)(base + u * WAVE + lane);
             cnt += __popcll(mask);
         }
     }
@@ -273,10 +275,11 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
 }
 
 // Loop skeleton shared by the three passes: ordered face list per 1024-face segment, 64-face chunks staged in LDS.
+// When the whole tile list fits the LDS buffer it is built once (list_cached) and reused by every pass.
 #define CHUNK_LOOP_BEGIN(ZERO_GACC)                                                            \
-    for (int seg0 = 0; seg0 < a.F; seg0 += LIST_CAP) {                                         \
+    for (int seg0 = 0; seg0 < (list_cached ? 1 : a.F); seg0 += LIST_CAP) {                     \
         const int seg1 = min(a.F, seg0 + LIST_CAP);                                            \
-        const int ln = build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane);                 \
+        const int ln = list_cached ? list_total : build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane); \
         __syncthreads();                                                                       \
         for (int c0 = 0; c0 < ln; c0 += FCHUNK) {                                              \
             const int m = min(FCHUNK, ln - c0);                                                \
@@ -316,6 +319,10 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         const uint32_t *tbox_n = a.tbox + (size_t)n * a.F;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
+        const int list_total = build_list(tbox_n, 0, a.F, tx, ty, lds.list, lane);
+        const bool list_cached = list_total <= LIST_CAP;
+        const bool may_truncate = list_total > K;  // otherwise no pixel can see more than K faces
+
         // ---------------- pass 1: count, product of all, K smallest depths (sorted, in registers) ---------
         int cnt = 0;
         float prod_all = 1.0f;
@@ -329,9 +336,11 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
                 if (__ballot(!(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
                 PairEval e;
                 eval_pair(f, px, py, dxp, dyp, a.blur, e);
+                if (__ballot(e.cand) == 0ull) continue;
                 const float fac = 1.0f - face_prob(e.sd, a.inv_sigma);
                 prod_all *= e.cand ? fac : 1.0f;
                 cnt += e.cand ? 1 : 0;
+                if (!may_truncate) continue;
                 const float z = e.cand ? pair_depth(f, e) : 3.0e38f;
                 if (__ballot(z < r[KT - 1]) == 0ull) continue;  // nobody's K-nearest set changes
                 // sorted insert, dropping the largest: r'[i] = med3(r[i-1], r[i], z); r'[0] = min(r[0], z)
@@ -362,6 +371,7 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
                         if (__ballot(trunc && !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
                         PairEval e;
                         eval_pair(f, px, py, dxp, dyp, a.blur, e);
+                        if (__ballot(e.cand && trunc) == 0ull) continue;
                         const float pz = pair_depth(f, e);
                         const bool tie = e.cand && trunc && (pz == zt) && (ties < r_ties);
                         const bool keep = e.cand && trunc && ((pz < zt) || tie);
@@ -412,6 +422,7 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
                 PairEval e;
                 eval_pair(f, px, py, dxp, dyp, a.blur, e);
                 bool keep = e.cand && active;
+                if (__ballot(keep) == 0ull) continue;
                 if (any_trunc) {
                     const float pz = pair_depth(f, e);
                     const bool tie = keep && trunc && (pz == zt) && (ties < r_ties);

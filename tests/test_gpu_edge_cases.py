@@ -1,0 +1,182 @@
+"""Edge cases and size-independent properties of the HIP path (``pytest -m gpu``)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODEL_FILES, oracle_model
+from oracle import fitter_ref, lbs_ref, render_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _eng():
+    from smilify_amd import engine
+
+    return engine
+
+
+def _scene(t, N, S, dist, seed, scale=1.0):
+    m = oracle_model(t)
+    g = torch.Generator().manual_seed(seed)
+    theta = 0.15 * torch.randn(N, t.J, 3, generator=g)
+    theta[:, 0] = torch.from_numpy(fitter_ref.default_global_rotation()) + 0.1 * torch.randn(N, 3, generator=g)
+    verts = lbs_ref.smal_forward(m, torch.zeros(N, t.nB), theta)["verts"] * scale
+    R, T = render_ref.look_at_view_transform(dist, 15.0, torch.linspace(0, 300, N))
+    return render_ref.project_to_ndc(verts, R, T, torch.full((N,), 60.0)).contiguous()
+
+
+@pytest.mark.parametrize("S", [20, 60, 100])
+def test_image_side_not_multiple_of_tile(S, tables):
+    eng = _eng()
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    ndc = _scene(t, 2, S, 2.2, 1)
+    ref, _ = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    got = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-4
+
+
+def test_nothing_visible_and_behind_camera(tables):
+    eng = _eng()
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 32
+    ndc = _scene(t, 2, S, 2.2, 1)
+    behind = ndc.clone()
+    behind[..., 2] = -1.0                      # every face behind the camera
+    off = ndc.clone()
+    off[..., 0] += 5.0                         # everything outside the image
+    for v in (behind, off):
+        sil = eng.silhouette_forward(dm, v.to(DEV), S)
+        assert float(sil.abs().max()) == 0.0
+        target = (torch.rand(2, S, S) > 0.5).float().to(DEV)
+        tsum = eng.image_abs_sum(target)
+        li, dn, _ = eng.silhouette_l1_fused(dm, v.to(DEV), S, target, tsum, torch.ones(2, device=DEV))
+        np.testing.assert_allclose(li.cpu().numpy(), target.sum(dim=(1, 2)).cpu().numpy(), rtol=1e-6)
+        assert float(dn.abs().max()) == 0.0
+    # NaN vertices must not fault or poison other faces
+    bad = ndc.clone()
+    bad[0, 0] = float("nan")
+    sil = eng.silhouette_forward(dm, bad.to(DEV), S)
+    assert torch.isfinite(sil).all()
+
+
+@pytest.mark.parametrize("K", [1, 16, 17, 100, 128])
+def test_faces_per_pixel_variants(K, tables):
+    eng = _eng()
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 48
+    ndc = _scene(t, 2, S, 2.2, 3)
+    ref, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)
+    got = eng.silhouette_forward(dm, ndc.to(DEV), S, eng.raster_settings(K=K)).cpu().numpy()
+    d = np.abs(got - ref)
+    assert d[ncand <= K].max() < 2e-4
+    assert np.mean(d > 1e-3) < 0.02 and d.mean() < 2e-4, (np.mean(d > 1e-3), d.mean())
+    with pytest.raises(Exception):
+        eng.silhouette_forward(dm, ndc.to(DEV), S, eng.raster_settings(K=129))
+
+
+def test_dense_tile_exceeding_list_capacity(tables):
+    """A whole 6019-face mesh squeezed into ~2x2 tiles: the per-tile face list overflows the LDS buffer and the
+    kernel must fall back to rebuilding it segment by segment."""
+    eng = _eng()
+    t = tables("stick")
+    dm = eng.DeviceModel(t, DEV)
+    S = 32
+    ndc = _scene(t, 1, S, 14.0, 2)  # far away -> tiny on screen
+    ref, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    assert ncand.max() > 1024
+    got = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
+    d = np.abs(got - ref)
+    assert d.mean() < 5e-4 and np.mean(d > 1e-2) < 0.01, (d.mean(), d.max())
+    # gradient path through the same overflow code
+    gs = torch.ones(1, S, S)
+    want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
+    gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
+    cos = (gotg * want).sum() / (np.linalg.norm(gotg) * np.linalg.norm(want) + 1e-30)
+    assert cos > 0.995, cos
+
+
+def test_full_size_properties_cfg2(tables):
+    """BASELINE config 2 size (512 frames, 256^2, STICK): properties that need no oracle run."""
+    eng = _eng()
+    from smilify_amd import synthetic
+
+    t = tables("stick")
+    f = synthetic.make_problem(t, 512, 1, 256, DEV)
+    f._refresh_targets()
+    dm = f.device_model
+    lbs = eng.lbs_forward(dm, f.betas.detach(), f._pose, trans=f.trans.detach().contiguous(), shared_beta=True, trans_after_joints=True)
+    cam = f.renderer.cameras
+    cams = eng.CameraSet(cam.R.contiguous(), cam.T.contiguous(), f.fov.detach(), None, 1, 256)
+    ndc, _ = eng.project(cams, lbs["verts"], want_yx=False)
+    sil = eng.silhouette_forward(dm, ndc, 256)
+    assert float(sil.min()) >= 0.0 and float(sil.max()) <= 1.0
+    # (a) the fused kernel's loss equals the L1 distance computed from the materialised silhouette
+    scale = torch.full((512,), 1.0 / (256 * 256), device=DEV)
+    li, dn, sil2 = eng.silhouette_l1_fused(dm, ndc, 256, f._sil_dev, f._sil_sum, scale, want_sil=True)
+    want = (sil - f._sil_dev).abs().sum(dim=(1, 2))
+    np.testing.assert_allclose(li.cpu().numpy(), want.cpu().numpy(), rtol=2e-4)
+    assert torch.equal(sil, sil2)                        # (b) forward is deterministic and mode-independent
+    # (c) explicit backward with the same upstream gradient reproduces the fused gradient (atomics: order noise only)
+    gsil = torch.sign(sil - f._sil_dev) * scale[:, None, None]
+    dn2 = eng.silhouette_backward(dm, ndc, 256, gsil.contiguous())
+    num = (dn - dn2).norm().item() / (dn.norm().item() + 1e-30)
+    assert num < 1e-4, num
+    # (d) backward is linear in the upstream gradient
+    dn3 = eng.silhouette_backward(dm, ndc, 256, (2.0 * gsil).contiguous())
+    assert (dn3 - 2.0 * dn2).norm().item() / dn3.norm().item() < 1e-4
+    # (e) rendering the target pose itself gives a (much) lower loss than the perturbed start
+    objs0, _ = f._loss_and_grads(None, synthetic.STAGE1_WEIGHTS, 0.0, window=10)
+    assert torch.isfinite(objs0).all()
+    # (f) a few fused Adam steps reduce the objective
+    f.begin_stage(synthetic.STAGE1_LR)
+    first = f.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)[:9].sum().item()
+    for _ in range(4):
+        last = f.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)[:9].sum().item()
+    assert last < first, (first, last)
+
+
+def test_single_frame_reference_config(tables):
+    """BASELINE config 1: 1 frame, 1 view, 256^2 (the only shape the shipped reference fitter runs)."""
+    from smilify_amd import synthetic
+
+    t = tables("stick")
+    f = synthetic.make_problem(t, 1, 1, 256, DEV, window=1)
+    loss, objs = f([0], synthetic.STAGE1_WEIGHTS, 1)
+    loss.backward()
+    assert set(objs) == {"joint", "limit", "pose", "splay", "betas", "sil_reproj"}
+    assert f.global_rotation.grad is not None and f.joint_rotations.grad.shape == (1, t.J - 1, 3)
+    assert f.fov.grad.shape == (1,) and torch.isfinite(f.fov.grad).all()
+    # against the oracle
+    cpu = lambda x: x.detach().cpu().clone()  # noqa: E731
+    m = oracle_model(t)
+    params = dict(betas=cpu(f.betas), log_beta_scales=cpu(f.log_beta_scales), betas_trans=cpu(f.betas_trans), global_rotation=cpu(f.global_rotation),
+                  trans=cpu(f.trans), joint_rotations=cpu(f.joint_rotations), fov=cpu(f.fov))
+    targets = dict(sil=cpu(f.sil_imgs), joints=cpu(f.target_joints), visibility=cpu(f.target_visibility))
+    cams = dict(R=cpu(f.renderer.cameras.R), T=cpu(f.renderer.cameras.T))
+    tot, o, _ = fitter_ref.fit_losses(m, params, [0], synthetic.STAGE1_WEIGHTS, targets, cams, 256, f.mean_betas.cpu(), f.betas_prec.cpu())
+    assert abs(loss.item() - tot.item()) <= 1e-4 * abs(tot.item()), (loss.item(), tot.item())
+    for k in o:
+        assert abs(objs[k].item() - o[k].item()) <= 1e-4 * abs(o[k].item()) + 1e-7, k
+
+
+def test_renderer_with_foreign_mesh_topology():
+    """Renderer.forward on a mesh that does not come from a SMAL model (face table uploaded on first use)."""
+    from smilify_amd.p3d_renderer import Renderer
+
+    verts = torch.tensor([[[-0.5, -0.5, 0.0], [0.5, -0.5, 0.0], [0.0, 0.5, 0.0], [0.0, 0.0, 0.5]]], device=DEV, requires_grad=True)
+    faces = torch.tensor([[0, 1, 2], [0, 1, 3], [1, 2, 3], [2, 0, 3]], device=DEV)
+    r = Renderer(64, DEV)
+    sil, proj = r(verts, verts[:, :2], faces[None])
+    assert sil.shape == (1, 1, 64, 64) and 0.02 < sil.mean().item() < 0.5
+    sil.sum().backward()
+    assert torch.isfinite(verts.grad).all() and verts.grad.abs().sum() > 0
+    R, T = render_ref.look_at_view_transform(2.7, 0.0, 0.0)
+    ndc = render_ref.project_to_ndc(verts.detach().cpu(), R, T, torch.tensor([60.0]))
+    ref, _ = render_ref.silhouette_forward_np(ndc.numpy(), faces.cpu().numpy().astype(np.int32), 64)
+    assert np.abs(sil.detach().cpu().numpy()[0, 0] - ref[0]).max() < 2e-4
+    with pytest.raises(NotImplementedError):
+        r(verts, verts[:, :2], faces[None], render_texture=True)

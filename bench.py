@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --share-gpu rehearses the multi-rank path on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only; never for reported numbers)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,12 +101,17 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from smilify_amd import engine, model_io, optimize, synthetic
 
@@ -115,11 +123,12 @@ def main():
     fitter = synthetic.make_problem(tables, frames, views, S, dev, radius=wl["radius"], seed=1234 + rank, window=window,
                                     frame0=rank * frames, n_frames_total=world * frames)
     fitter.begin_stage(synthetic.STAGE1_LR, fov_lr=1.0)
-    hook = (lambda shared, objs: optimize.allreduce_shared(shared, objs)) if world > 1 else None
+    staged = args.backend == "gloo"  # gloo: stage the (tiny) collective payloads through host memory
+    hook = (lambda shared, objs: optimize.allreduce_shared(shared, objs, host_staged=staged)) if world > 1 else None
 
     def step():
         first, last = fitter.boundary_rows()
-        hp, hn = optimize.exchange_halos(first, last, rank, world)
+        hp, hn = optimize.exchange_halos(first, last, rank, world, host_staged=staged)
         return fitter.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=window, halo_prev=hp, halo_next=hn,
                                shared_grad_hook=hook)
 
@@ -138,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, kern_n = engine.profile_read()
     engine.profile_enable(False)
-    t = torch.tensor([dt], device=dev)
+    t = torch.tensor([dt], device="cpu" if staged else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -165,6 +174,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "rehearsal": bool(args.share_gpu or args.backend != "nccl"),
             "config": {"workload": wl["name"], "frames_per_gpu": frames, "views": views, "image": S, "window": window,
                        "weights": synthetic.STAGE1_WEIGHTS, "w_temporal": synthetic.STAGE1_TEMPORAL, "faces_per_pixel": 100,
                        "parallelism": f"frames sharded x{world}, all-reduce of shared-parameter gradients"},

@@ -29,7 +29,7 @@
 #include "common.h"
 
 #define TILE 8
-#define LIST_CAP 1024       // face ids per list segment (LDS)
+#define LIST_CAP 2048       // face ids per list segment (LDS)
 #define FCHUNK 64           // faces staged per chunk
 #define FREC 32             // floats per staged face record
 #define K_EPS 1e-8f

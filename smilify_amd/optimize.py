@@ -57,24 +57,33 @@ def plan_shards(n_total: int, world: int, window: int) -> List[ShardPlan]:
     return plans
 
 
-def exchange_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None
-                   ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """All-gather every shard's boundary rows; return (row before my first frame, row after my last frame)."""
+def exchange_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None,
+                   host_staged: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """All-gather every shard's boundary rows; return (row before my first frame, row after my last frame).
+    ``host_staged`` moves the payload through host memory (gloo rehearsals); RCCL runs keep it on the device."""
     if world == 1:
         return None, None
+    dev = first_row.device
     mine = torch.stack([first_row, last_row]).contiguous()
+    if host_staged:
+        mine = mine.cpu()
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
-    prev_row = gathered[rank - 1][1].contiguous() if rank > 0 else None
-    next_row = gathered[rank + 1][0].contiguous() if rank + 1 < world else None
+    prev_row = gathered[rank - 1][1].to(dev).contiguous() if rank > 0 else None
+    next_row = gathered[rank + 1][0].to(dev).contiguous() if rank + 1 < world else None
     return prev_row, next_row
 
 
-def allreduce_shared(shared: Dict[str, torch.Tensor], objs: torch.Tensor, group=None) -> None:
+def allreduce_shared(shared: Dict[str, torch.Tensor], objs: torch.Tensor, group=None, host_staged: bool = False) -> None:
     """One fused all-reduce(SUM) over [shared-parameter gradients..., loss terms]; results written back in place."""
     names = sorted(shared)
     flat = torch.cat([shared[k].reshape(-1) for k in names] + [objs.reshape(-1)])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if host_staged:
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     o = 0
     for k in names:
         n = shared[k].numel()

@@ -46,6 +46,7 @@ struct RasterArgs {
     const float *verts_ndc;  // (N,V,3)
     const int *faces;        // (F,3)
     const uint32_t *tbox;    // (N,F)
+    const float *fzmin;      // (N,F) nearest vertex depth of every face
     const uint32_t *items;   // work list
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
@@ -69,7 +70,8 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
-                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ items,
+                                                      uint32_t *__restrict__ tbox, float *__restrict__ fzmin,
+                                                      uint32_t *__restrict__ items,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x,
                                                       float sqrt_blur) {
     extern __shared__ uint32_t bitmap[];  // tiles_x*tiles_x bits, then 256 scan slots
@@ -112,6 +114,7 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
             }
         }
         tbox[(size_t)n * F + f] = box;
+        fzmin[(size_t)n * F + f] = zmin;
     }
     __syncthreads();
     // ordered compaction of touched tiles -> global work list
@@ -245,9 +248,9 @@ __device__ __forceinline__ int build_list(const uint32_t *__restrict__ tbox_n, i
 }
 
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list,
-                                            int c0, int m, float *rec, int lane, float cx, float cy) {
+                                            int c0, int m, float *rec, int lane, float cx, float cy, uint32_t id_mask) {
     if (lane < m) {
-        const int f = (int)list[c0 + lane];
+        const int f = (int)(list[c0 + lane] & id_mask);
         const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
         const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
         const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
@@ -274,16 +277,64 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
     }
 }
 
+// Sort the cached tile list front to back, in place.  Every entry becomes (16-bit quantised nearest-vertex depth
+// of the face << 16) | face id, and the u32 values are sorted with a bitonic network in LDS (ties: ascending face
+// id).  Needs F < 65536.  (lo, step) let a pass recover a LOWER BOUND of the depth of every remaining face from the
+// entry it is looking at: depth >= lo + (entry >> 16) * step, because a pair's depth is a convex combination of
+// the face's vertex depths.
+__device__ __forceinline__ void depth_sort_list(const float *__restrict__ fz_n, uint32_t *list, int n, int lane, float &zlo,
+                                                float &zstep) {
+    float mn = 3.0e38f, mx = 0.f;
+    for (int i = lane; i < n; i += WAVE) {
+        const float z = fz_n[list[i]];
+        mn = fminf(mn, z); mx = fmaxf(mx, z);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    zlo = mn;
+    zstep = fmaxf((mx - mn) * (1.0f / 65535.0f), 1e-30f);
+    const float inv = 1.0f / zstep;
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (int i = lane; i < np2; i += WAVE) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < n) {
+            const uint32_t f = list[i];
+            // floor minus one step of slack against rounding: lo + q*step must never exceed the true depth
+            int q = (int)((fz_n[f] - zlo) * inv) - 1;
+            q = min(max(q, 0), 65534);
+            key = ((uint32_t)q << 16) | f;
+        }
+        list[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (np2 >> 1); t += WAVE) {
+                const int lo_i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo_i | j;
+                const uint32_t x = list[lo_i], y = list[hi_i];
+                const bool asc = (lo_i & k) == 0;
+                if ((x > y) == asc) { list[lo_i] = y; list[hi_i] = x; }
+            }
+            __syncthreads();
+        }
+}
+
 // Loop skeleton shared by the three passes: ordered face list per 1024-face segment, 64-face chunks staged in LDS.
 // When the whole tile list fits the LDS buffer it is built once (list_cached) and reused by every pass.
-#define CHUNK_LOOP_BEGIN(ZERO_GACC)                                                            \
+// CUT_EXPR (evaluated once per chunk, wave-uniform float): when the list is depth sorted, every face from the chunk's
+// first entry on is at least `lo + q*step` deep; once that bound reaches CUT_EXPR nothing further can matter.
+#define CHUNK_LOOP_BEGIN(ZERO_GACC, CUT_EXPR)                                                  \
     for (int seg0 = 0; seg0 < (list_cached ? 1 : a.F); seg0 += LIST_CAP) {                     \
         const int seg1 = min(a.F, seg0 + LIST_CAP);                                            \
         const int ln = list_cached ? list_total : build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane); \
         __syncthreads();                                                                       \
         for (int c0 = 0; c0 < ln; c0 += FCHUNK) {                                              \
+            if (sorted) {                                                                      \
+                const float zlb = zlo + (float)(lds.list[c0] >> 16) * zstep;                   \
+                if (zlb >= (CUT_EXPR)) break;                                                  \
+            }                                                                                  \
             const int m = min(FCHUNK, ln - c0);                                                \
-            stage_faces(a, vn, lds.list, c0, m, lds.rec, lane, cx, cy);                        \
+            stage_faces(a, vn, lds.list, c0, m, lds.rec, lane, cx, cy, id_mask);               \
             if (ZERO_GACC)                                                                     \
                 for (int i_ = lane; i_ < FCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.f;           \
             __syncthreads();
@@ -291,6 +342,15 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             __syncthreads();                                                                   \
         }                                                                                      \
     }
+
+template <int KT>
+__device__ __forceinline__ float kth_smallest(const float (&r)[KT], int K) {
+    float v = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+        if (i == K - 1) v = r[i];
+    return v;
+}
 
 // KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD
 template <int MODE, int KT>
@@ -322,6 +382,12 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         const int list_total = build_list(tbox_n, 0, a.F, tx, ty, lds.list, lane);
         const bool list_cached = list_total <= LIST_CAP;
         const bool may_truncate = list_total > K;  // otherwise no pixel can see more than K faces
+        // depth ordering pays only where truncation can happen; it needs the whole list in LDS and 16-bit face ids
+        const bool sorted = list_cached && may_truncate && a.F < 65536 && list_total > FCHUNK;
+        float zlo = 0.f, zstep = 0.f;
+        __syncthreads();
+        if (sorted) depth_sort_list(a.fzmin + (size_t)n * a.F, lds.list, list_total, lane, zlo, zstep);
+        const uint32_t id_mask = sorted ? 0xFFFFu : 0xFFFFFFFFu;
 
         // ---------------- pass 1: count, product of all, K smallest depths (sorted, in registers) ---------
         int cnt = 0;
@@ -329,7 +395,9 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         float r[KT];
 #pragma unroll
         for (int i = 0; i < KT; ++i) r[i] = 3.0e38f;
-        CHUNK_LOOP_BEGIN(false)
+        // a pixel is settled once it holds K depths and its K-th smallest is not beyond the next face; the pass may
+        // stop when every pixel of the tile is settled (pixels with fewer than K candidates never are)
+        CHUNK_LOOP_BEGIN(false, wave_max(!in_img ? -3.0e38f : (cnt < K ? 3.0e38f : kth_smallest<KT>(r, K))))
         {
             for (int i = 0; i < m; ++i) {
                 const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
@@ -350,20 +418,22 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             }
         }
         CHUNK_LOOP_END
-        const bool trunc = cnt > K;
+        // cnt may have stopped early at >= K: then "all candidates" and "the K nearest" only coincide when cnt == K,
+        // and pass 2 computes the right product in both cases
+        const bool trunc = sorted ? (cnt >= K) : (cnt > K);
         float alpha = prod_all;
         float zt = 3.0e38f;  // depth threshold (K-th smallest)
         int r_ties = 0;
         if (__ballot(trunc) != 0ull) {
-#pragma unroll
-            for (int i = 0; i < KT; ++i)
-                if (i == K - 1) zt = r[i];
+            zt = kth_smallest<KT>(r, K);
 #pragma unroll
             for (int i = 0; i < KT; ++i) r_ties += (i < K && r[i] == zt) ? 1 : 0;
             // ------------- pass 2: product over the K nearest for truncated pixels ---------------
             float prod = 1.0f;
             int ties = 0;
-            CHUNK_LOOP_BEGIN(false)
+            // faces whose nearest vertex is beyond every truncated pixel's threshold cannot be among its K nearest
+            const float cut2 = wave_max(trunc ? zt : -3.0e38f);
+            CHUNK_LOOP_BEGIN(false, nextafterf(cut2, 3.0e38f))
             {
                 if (__ballot(trunc && prod != 0.0f) != 0ull) {
                     for (int i = 0; i < m; ++i) {
@@ -414,7 +484,8 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         float *dn = a.d_ndc + (size_t)n * a.V * 2;
         const bool any_trunc = __ballot(trunc && active) != 0ull;
         int ties = 0;
-        CHUNK_LOOP_BEGIN(true)
+        const float cut3 = wave_max(active ? (trunc ? zt : 3.0e38f) : -3.0e38f);
+        CHUNK_LOOP_BEGIN(true, nextafterf(cut3, 3.0e38f))
         {
             for (int i = 0; i < m; ++i) {
                 const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
@@ -473,7 +544,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t));
+    return 2 * align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t));
 }
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
@@ -488,16 +559,17 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     char *ws = (char *)workspace;
     uint32_t *tbox = (uint32_t *)ws;
     ws += align256((size_t)N * m->F * sizeof(uint32_t));
-    RasterCounters *ctr = (RasterCounters *)ws;
+    RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
+    float *fzmin = (float *)(ws + 256 + align256((size_t)N * tiles_x * tiles_x * sizeof(uint32_t)));
     ws += 256;
     uint32_t *items = (uint32_t *)ws;
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_words = (tiles_x * tiles_x + 31) / 32;
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), (size_t)(n_words + 256) * sizeof(uint32_t), stream, verts_ndc,
-                       m->faces, tbox, items, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+                       m->faces, tbox, fzmin, items, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
     SMIL_LAUNCH_CHECK();
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.items = items; a.ctr = ctr;
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.fzmin = fzmin; a.items = items; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr; a.d_ndc = nullptr;

@@ -78,7 +78,12 @@ def cpu_baseline(tables, wl, n_frames):
     (total + jl + gl + tl).backward()
     opt.step()
     dt = time.perf_counter() - t0
-    return dict(value=n_frames / dt, unit="frame-iters/s", cores=render_ref.num_threads(), kind="port",
+    try:
+        cores = min(render_ref.num_threads(), len(os.sched_getaffinity(0)))
+    except AttributeError:
+        cores = render_ref.num_threads()
+    return dict(value=n_frames / dt, unit="frame-iters/s", cores=cores, omp_threads=render_ref.num_threads(),
+                torch_threads=torch.get_num_threads(), kind="port",
                 sample=f"{n_frames} frames x {views} view(s) @ {S}^2 of the same workload, 1 fit iteration "
                        f"(oracle: torch-CPU LBS/losses + OpenMP C naive rasteriser), {dt:.1f} s")
 
@@ -160,6 +165,12 @@ def main():
         kern_avg_ms = kern_ms / max(kern_n, 1)
         achieved = (n_img * per_view) / (kern_avg_ms * 1e-3) / 1e9 if kern_n else 0.0
         iter_bytes = frames * (per_frame + views * per_view)
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r1d_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath)).get(args.workload)
+            if tj and tj["images_per_launch"] == n_img:
+                traffic = (tj["FETCH_SIZE_KB"] * tj["fetch_correction"] + tj["WRITE_SIZE_KB"]) * 1024.0
         out = {
             "metric": "SMIL fit-iters/sec (LBS+render+loss)",
             "value": world * frames / (dt / args.steps),
@@ -181,13 +192,14 @@ def main():
             "final_loss": loss,
             "roofline": {"bound": "hbm", "kernel": "k_raster_tiles<FUSED> (soft silhouette fwd + L1 + bwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
+                         "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1d_traffic.json" if traffic else None,
+                         "algorithmic_bytes_per_launch": n_img * per_view, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_image": per_view,
                          "iteration_frac": (iter_bytes / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
                          "note": "VALU-bound (K=100 nearest-depth selection per pixel), not HBM-bound: see DESIGN.md"},
         }
         if world == 1 and args.cpu_frames != 0:
-            n_cpu = args.cpu_frames if args.cpu_frames > 0 else max(1, min(8, 16 // views))
+            n_cpu = args.cpu_frames if args.cpu_frames > 0 else max(1, 32 // views)
             out["cpu_baseline"] = cpu_baseline(tables, wl, n_cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -16,29 +16,29 @@ import numpy as np
 import torch
 
 
-def _normalize(v: np.ndarray, eps: float = 1e-5) -> np.ndarray:
-    n = np.maximum(np.linalg.norm(v, axis=1, keepdims=True), eps)
-    return v / n
+def _unit(v: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    return v / v.norm(dim=1, keepdim=True).clamp_min(eps)
 
 
 def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees: bool = True, device="cpu") -> Tuple[torch.Tensor, torch.Tensor]:
     """World->view rotation R (n,3,3) and translation T (n,3) of cameras on a sphere around the origin,
-    looking at it with +y up; row-vector convention X_view = X_world @ R + T."""
-    d, e, a = np.broadcast_arrays(np.atleast_1d(np.asarray(dist, np.float64)), np.atleast_1d(np.asarray(elev, np.float64)),
-                                  np.atleast_1d(np.asarray(azim, np.float64)))
+    looking at it with +y up; row-vector convention X_view = X_world @ R + T.  Computed in fp32 like the
+    pytorch3d function it replaces, so degenerate set-ups (camera on the up axis) resolve the same way."""
+    f32 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).reshape(-1)  # noqa: E731
+    d, e, a = torch.broadcast_tensors(f32(dist), f32(elev), f32(azim))
     if degrees:
-        e, a = np.deg2rad(e), np.deg2rad(a)
-    C = np.stack([d * np.cos(e) * np.sin(a), d * np.sin(e), d * np.cos(e) * np.cos(a)], axis=1)
-    up = np.tile(np.array([[0.0, 1.0, 0.0]]), (C.shape[0], 1))
-    z_axis = _normalize(-C)
-    x_axis = _normalize(np.cross(up, z_axis))
-    y_axis = _normalize(np.cross(z_axis, x_axis))
-    degenerate = np.all(np.isclose(x_axis, 0.0, atol=5e-3), axis=1)
-    if degenerate.any():
-        x_axis[degenerate] = _normalize(np.cross(y_axis, z_axis))[degenerate]
-    R = np.stack([x_axis, y_axis, z_axis], axis=2)  # columns are the camera axes
-    T = -np.einsum("nij,ni->nj", R, C)
-    return (torch.tensor(R, dtype=torch.float32, device=device), torch.tensor(T, dtype=torch.float32, device=device))
+        e, a = e * (math.pi / 180.0), a * (math.pi / 180.0)
+    C = torch.stack([d * torch.cos(e) * torch.sin(a), d * torch.sin(e), d * torch.cos(e) * torch.cos(a)], dim=1)
+    up = torch.tensor([[0.0, 1.0, 0.0]]).expand_as(C)
+    z_axis = _unit(-C)
+    x_axis = _unit(torch.cross(up, z_axis, dim=1))
+    y_axis = _unit(torch.cross(z_axis, x_axis, dim=1))
+    degenerate = torch.isclose(x_axis, torch.zeros(()), atol=5e-3).all(dim=1, keepdim=True)
+    if bool(degenerate.any()):
+        x_axis = torch.where(degenerate, _unit(torch.cross(y_axis, z_axis, dim=1)), x_axis)
+    R = torch.stack([x_axis, y_axis, z_axis], dim=2)  # columns are the camera axes
+    T = -torch.einsum("nij,ni->nj", R, C)
+    return R.contiguous().to(device), T.contiguous().to(device)
 
 
 class FoVCameras:

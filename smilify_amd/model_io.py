@@ -42,6 +42,9 @@ _NUMPY_GLOBALS = {
     ("numpy.core.multiarray", "scalar"),
     ("numpy._core.multiarray", "scalar"),
 }
+# protocol-2 pickles written under Python 3 wrap array bytes in _codecs.encode(str, 'latin1'): a pure function
+_BENIGN_GLOBALS = {("_codecs", "encode"), ("builtins", "bytearray"), ("builtins", "bytes"), ("__builtin__", "bytes"),
+                   ("__builtin__", "bytearray"), ("collections", "OrderedDict")}
 _SCIPY_GLOBALS = {
     ("scipy.sparse.csc", "csc_matrix"),
     ("scipy.sparse._csc", "csc_matrix"),
@@ -77,6 +80,8 @@ class _ModelUnpickler(pickle.Unpickler):
         if (module, name) in _NUMPY_GLOBALS:
             module = module.replace("numpy.core", "numpy._core") if np.__version__ >= "2" else module
             return getattr(importlib.import_module(module), name)
+        if (module, name) in _BENIGN_GLOBALS:
+            return getattr(importlib.import_module("builtins" if module == "__builtin__" else module), name)
         if (module, name) in _SCIPY_GLOBALS:
             import scipy.sparse as sp
 

@@ -1,0 +1,66 @@
+"""Stage scheduler and checkpoint format on the GPU (``pytest -m gpu``)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_staged_optimisation_freezes_and_converges(tables):
+    from smilify_amd import optimize, synthetic
+
+    t = tables("synthetic")
+    f = synthetic.make_problem(t, 6, 1, 40, DEV, radius=2.2, seed=11, window=3)
+    f.config.TORSO_JOINTS = [0, 1, 5]
+    f.config.OPT_WEIGHTS = [[25.0, 10.0], [0.0, 500.0], [0.0, 1.0], [0.0, 1.0], [0.0, 100.0], [0.0, 0.1], [500.0, 100.0], [6, 8], [2e-2, 5e-3]]
+    f.log_beta_scales.requires_grad = False
+    joints0, betas0, fov0 = f.joint_rotations.detach().clone(), f.betas.detach().clone(), f.fov.detach().clone()
+    seen = []
+    stages = optimize.stages_from_config(f.config)
+    assert len(stages) == 2 and stages[0].epochs == 6
+
+    def on_epoch(stage, epoch, objs):
+        seen.append((stage, epoch, float(objs[:9].sum())))
+        if stage == 0 and epoch == stages[0].epochs - 1:
+            # stage 0 (optimize_to_joints.py:129-138): joint rotations / betas frozen, visibility masked to the torso
+            assert torch.equal(f.joint_rotations.detach(), joints0) and torch.equal(f.betas.detach(), betas0)
+            assert not torch.equal(f.fov.detach(), fov0)
+            assert int(f.target_visibility.sum()) == 6 * 3
+
+    optimize.optimize(f, stages, on_epoch=on_epoch)
+    assert [s for s, _, _ in seen] == [0] * 6 + [1] * 8
+    assert not torch.equal(f.joint_rotations.detach(), joints0) and not torch.equal(f.betas.detach(), betas0)
+    assert int(f.target_visibility.sum()) == 6 * t.J
+    s0 = [l for s, _, l in seen if s == 0]
+    s1 = [l for s, _, l in seen if s == 1]
+    assert s0[-1] < s0[0] and s1[-1] < s1[0], (s0, s1)
+
+
+def test_checkpoint_roundtrip(tables, tmp_path):
+    """Per-frame parameter dicts as the reference pickles them (optimize_to_joints.py:48-63) -> load_checkpoint."""
+    from smilify_amd import synthetic
+
+    t = tables("synthetic")
+    f = synthetic.make_problem(t, 3, 1, 32, DEV, radius=2.2, seed=2)
+    for i in range(3):
+        d = tmp_path / "{0:04}".format(i)
+        os.makedirs(d)
+        p = f.export_parameters(i)
+        assert set(p) >= {"global_rotation", "joint_rotations", "betas", "trans", "fov", "log_betascale"}
+        with open(d / "st1_ep0.pkl", "wb") as fh:
+            pickle.dump(p, fh)
+    g = synthetic.make_problem(t, 3, 1, 32, DEV, radius=2.2, seed=99)
+    g.load_checkpoint(str(tmp_path), "st1_ep0")
+    np.testing.assert_allclose(g.global_rotation.detach().cpu().numpy(), f.global_rotation.detach().cpu().numpy(), atol=1e-7)
+    np.testing.assert_allclose(g.joint_rotations.detach().cpu().numpy(), f.joint_rotations.detach().cpu().numpy(), atol=1e-7)
+    np.testing.assert_allclose(g.trans.detach().cpu().numpy(), f.trans.detach().cpu().numpy(), atol=1e-7)
+    np.testing.assert_allclose(g.betas.detach().cpu().numpy(), f.betas.detach().cpu().numpy(), atol=1e-6)
+    # scales are averaged over frames like the reference does (fitter.py:371)
+    np.testing.assert_allclose(g.log_beta_scales.detach().cpu().numpy()[0], f.log_beta_scales.detach().cpu().numpy().mean(0), atol=1e-6)
+    # the loaded fitter is usable: shared (1,J,3) scale table
+    loss, _ = g([0, 1, 2], synthetic.STAGE1_WEIGHTS, 1)
+    assert torch.isfinite(loss)

@@ -164,11 +164,12 @@ int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t
 /* Fused forward + L1 against a target + backward, no silhouette materialised (SMALFitter path,
  * fitter.py:332-333): loss_img[n] = sum_px |sil - target|, d_ndc (N,V,2) = d(sum_n pix_scale[n] *
  * loss_img[n]) / d ndc.  target_sum[n] = sum_px target (constant, computed once by the caller) lets
- * untouched tiles skip their target read.  sil_out may be NULL. */
+ * untouched tiles skip their target read.  target is (N,S,S) fp32, or uint8 holding binary {0,1} masks when
+ * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL. */
 int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
-                             const SmilRasterSettings *rs, const float *target, const float *target_sum,
-                             const float *pix_scale, float *loss_img, float *d_ndc, float *sil_out,
-                             void *workspace, void *stream);
+                             const SmilRasterSettings *rs, const void *target, int32_t target_is_u8,
+                             const float *target_sum, const float *pix_scale, float *loss_img, float *d_ndc,
+                             float *sil_out, void *workspace, void *stream);
 
 /* Measurement hook (bench.py): when enabled, every launch of the tile kernel is bracketed by HIP events on its
  * launch stream; smil_profile_read synchronises those events and returns their summed duration + count. */
@@ -222,7 +223,7 @@ int smil_joint_loss(const SmilFitConfig *cfg, int32_t views, int32_t Jc, const i
 /* Helpers of the fused silhouette term: pix_scale[n] = w_reproj / (b_w views S^2); target_sum[n] =
  * sum_px |target[n]| (once per fit); objs[5] += sum_n pix_scale[n] loss_img[n]. */
 int smil_pix_scale(const SmilFitConfig *cfg, int32_t views, int32_t S, float *pix_scale, void *stream);
-int smil_image_abs_sum(const float *images, int32_t N, int32_t pixels, float *out, void *stream);
+int smil_image_abs_sum(const void *images, int32_t is_u8, int32_t N, int32_t pixels, float *out, void *stream);
 int smil_sil_objective(const float *loss_img, const float *pix_scale, int32_t N, float *objs, void *stream);
 
 /* torch.optim.Adam semantics (no amsgrad, no weight decay). step = 1-based step count. */

@@ -99,14 +99,14 @@ def load():
                                             c_void_p, c_void_p]
     lib.smil_silhouette_backward.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,
                                              c_void_p, c_void_p, c_void_p]
-    lib.smil_silhouette_l1_fused.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,
+    lib.smil_silhouette_l1_fused.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p, c_int32,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.smil_prior_losses.argtypes = [POINTER(FitConfig)] + [c_void_p] * 12 + [c_int32, c_void_p]
     lib.smil_mask_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
     lib.smil_joint_loss.argtypes = [POINTER(FitConfig), c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]
     lib.smil_pix_scale.argtypes = [POINTER(FitConfig), c_int32, c_int32, c_void_p, c_void_p]
-    lib.smil_image_abs_sum.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p]
+    lib.smil_image_abs_sum.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.smil_sil_objective.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
     lib.smil_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                    c_int32, c_void_p]

@@ -238,18 +238,20 @@ extern "C" int smil_pix_scale(const SmilFitConfig *cfg, int32_t views, int32_t S
 }
 
 // target_sum[n] = sum_px |target[n]|  (constant over the fit; computed once)
-__global__ void __launch_bounds__(256) k_image_abs_sum(const float *__restrict__ img, int pixels, float *__restrict__ out) {
+template <typename T>
+__global__ void __launch_bounds__(256) k_image_abs_sum(const T *__restrict__ img, int pixels, float *__restrict__ out) {
     __shared__ float red[16];
-    const float *p = img + (size_t)blockIdx.x * pixels;
+    const T *p = img + (size_t)blockIdx.x * pixels;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < pixels; i += blockDim.x) acc += fabsf(p[i]);
+    for (int i = threadIdx.x; i < pixels; i += blockDim.x) acc += fabsf((float)p[i]);
     const float v = block_sum(acc, red);
     if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
-extern "C" int smil_image_abs_sum(const float *images, int32_t N, int32_t pixels, float *out, void *stream_) {
+extern "C" int smil_image_abs_sum(const void *images, int32_t is_u8, int32_t N, int32_t pixels, float *out, void *stream_) {
     SMIL_REQUIRE(images && out && N > 0 && pixels > 0, "smil_image_abs_sum: bad argument");
-    hipLaunchKernelGGL(k_image_abs_sum, dim3(N), dim3(256), 0, (hipStream_t)stream_, images, pixels, out);
+    if (is_u8) hipLaunchKernelGGL(k_image_abs_sum<uint8_t>, dim3(N), dim3(256), 0, (hipStream_t)stream_, (const uint8_t *)images, pixels, out);
+    else hipLaunchKernelGGL(k_image_abs_sum<float>, dim3(N), dim3(256), 0, (hipStream_t)stream_, (const float *)images, pixels, out);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }

@@ -54,7 +54,8 @@ struct RasterArgs {
     // outputs / inputs per mode
     float *sil;              // (N,S,S) FWD (or optional in FUSED)
     const float *grad_sil;   // BWD
-    const float *target;     // FUSED
+    const float *target;     // FUSED (fp32 targets) ...
+    const uint8_t *target_u8; // ... or binary {0,1} targets stored as bytes
     const float *pix_scale;  // FUSED (N,)
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         } else {
             float lsum = 0.f;
             if (in_img) {
-                const float tg = a.target[pix];
+                const float tg = a.target_u8 ? (float)a.target_u8[pix] : a.target[pix];
                 const float diff = silv - tg;
                 lsum = fabsf(diff) - fabsf(tg);  // loss_img starts at sum |0 - target|
                 g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
@@ -572,7 +573,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.fzmin = fzmin; a.items = items; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
-    a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr; a.d_ndc = nullptr;
+    a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.target_u8 = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr;
+    a.d_ndc = nullptr;
     return SMIL_OK;
 }
 
@@ -667,9 +669,9 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
 }
 
 extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
-                                        const SmilRasterSettings *rs, const float *target, const float *target_sum,
-                                        const float *pix_scale, float *loss_img, float *d_ndc, float *sil_out,
-                                        void *workspace, void *stream_) {
+                                        const SmilRasterSettings *rs, const void *target, int32_t target_is_u8,
+                                        const float *target_sum, const float *pix_scale, float *loss_img, float *d_ndc,
+                                        float *sil_out, void *workspace, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     RasterArgs a;
     int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a);
@@ -678,7 +680,8 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
     SMIL_HIP(hipMemcpyAsync(loss_img, target_sum, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
-    a.target = target; a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
+    if (target_is_u8) a.target_u8 = (const uint8_t *)target; else a.target = (const float *)target;
+    a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
     PROF_BEGIN(stream);
     launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);

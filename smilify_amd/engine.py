@@ -269,9 +269,12 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
         d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=dev)
     sil = torch.empty(N, S, S, dtype=torch.float32, device=dev) if want_sil else None
     ws = model.workspace(N, S)
+    if target.dtype not in (torch.float32, torch.uint8):
+        raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
     _lib.check(_lib.load().smil_silhouette_l1_fused(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(target),
-                                                    _ptr(target_sum), _ptr(pix_scale), _ptr(loss_img), _ptr(d_ndc), _ptr(sil),
-                                                    _ptr(ws), _stream()), "smil_silhouette_l1_fused")
+                                                    int(target.dtype == torch.uint8), _ptr(target_sum), _ptr(pix_scale),
+                                                    _ptr(loss_img), _ptr(d_ndc), _ptr(sil), _ptr(ws), _stream()),
+               "smil_silhouette_l1_fused")
     return loss_img, d_ndc, sil
 
 
@@ -279,7 +282,8 @@ def image_abs_sum(images: torch.Tensor) -> torch.Tensor:
     N = images.shape[0]
     pixels = images[0].numel()
     out = torch.empty(N, dtype=torch.float32, device=images.device)
-    _lib.check(_lib.load().smil_image_abs_sum(_ptr(images), N, pixels, _ptr(out), _stream()), "smil_image_abs_sum")
+    _lib.check(_lib.load().smil_image_abs_sum(_ptr(images), int(images.dtype == torch.uint8), N, pixels, _ptr(out), _stream()),
+               "smil_image_abs_sum")
     return out
 
 

@@ -171,7 +171,13 @@ class SMALFitter(nn.Module):
         dev = self.device
         n_img = self.num_images * self.views
         if self.sil_imgs is not None:
-            self._sil_dev = self.sil_imgs.to(dev).float().reshape(n_img, self.image_size, self.image_size).contiguous()
+            sil = self.sil_imgs.to(dev).reshape(n_img, self.image_size, self.image_size)
+            if sil.dtype != torch.uint8:
+                sil = sil.float()
+                # binary masks (the usual case) are kept as bytes: a quarter of the memory and of the read traffic
+                if bool(((sil == 0) | (sil == 1)).all()):
+                    sil = sil.to(torch.uint8)
+            self._sil_dev = sil.contiguous()
             self._sil_sum = engine.image_abs_sum(self._sil_dev)
         else:
             self._sil_dev = self._sil_sum = None

@@ -180,3 +180,22 @@ def test_renderer_with_foreign_mesh_topology():
     assert np.abs(sil.detach().cpu().numpy()[0, 0] - ref[0]).max() < 2e-4
     with pytest.raises(NotImplementedError):
         r(verts, verts[:, :2], faces[None], render_texture=True)
+
+
+def test_uint8_targets_equal_float_targets(tables):
+    eng = _eng()
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 48
+    ndc = _scene(t, 3, S, 2.2, 4).to(DEV)
+    tgt_f = (torch.rand(3, S, S) > 0.6).float().to(DEV)
+    tgt_b = tgt_f.to(torch.uint8)
+    scale = torch.tensor([1.0, 0.5, 2.0], device=DEV) / (S * S)
+    sum_f, sum_b = eng.image_abs_sum(tgt_f), eng.image_abs_sum(tgt_b)
+    assert torch.equal(sum_f, sum_b)
+    lf, gf, _ = eng.silhouette_l1_fused(dm, ndc, S, tgt_f, sum_f, scale)
+    lb, gb, _ = eng.silhouette_l1_fused(dm, ndc, S, tgt_b, sum_b, scale)
+    np.testing.assert_allclose(lb.cpu().numpy(), lf.cpu().numpy(), rtol=1e-6)
+    assert (gb - gf).norm().item() <= 1e-5 * gf.norm().item()
+    with pytest.raises(Exception):
+        eng.silhouette_l1_fused(dm, ndc, S, tgt_f.double(), sum_f, scale)

@@ -46,6 +46,7 @@ typedef struct {
     const float *jreg_val;      /* (nnz,) */
     int32_t static_joints;      /* config.STATIC_JOINT_LOCATIONS (smal_torch.py:175,257,343) */
     const float *J_static;      /* (J,3) when static_joints */
+    const float *posedirs;      /* (9(J-1),3V) pose blend shapes (smal_torch.py:178-190) or NULL when empty / all zero */
 } SmilModelDesc;
 
 int smil_model_create(const SmilModelDesc *desc, SmilModel **out);
@@ -88,6 +89,7 @@ typedef struct {
     float *new_J;    /* (B,J,3) = SMAL.J_transformed */
     float *verts;    /* (B,V,3) */
     float *joints;   /* (B,J,3) */
+    float *v_posed;  /* (B,V,3) v_shaped + pose blend shapes; required iff the model has posedirs, else NULL */
 } SmilLbsOutputs;
 
 int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, void *stream);
@@ -104,6 +106,8 @@ typedef struct {
     float *d_A;            /* (B,J,3,4) */
     float *d_Jrest;        /* (B,J,3) */
     float *d_Rs;           /* (B,J,3,3) */
+    float *d_vposed;       /* (B,V,3): required iff the model has posedirs */
+    float *d_posefeat;     /* (B,9(J-1)): required iff the model has posedirs */
 } SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
                               logscale_shared, btrans_shared) receive the sum over frames */
 

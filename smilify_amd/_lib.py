@@ -31,7 +31,7 @@ class ModelDesc(Structure):
     _fields_ = [("V", c_int32), ("F", c_int32), ("J", c_int32), ("nB", c_int32),
                 ("v_template", c_void_p), ("shapedirs", c_void_p), ("faces", c_void_p), ("parents", c_void_p),
                 ("skin_idx", c_void_p), ("skin_w", c_void_p), ("jreg_rowptr", c_void_p), ("jreg_col", c_void_p),
-                ("jreg_val", c_void_p), ("static_joints", c_int32), ("J_static", c_void_p)]
+                ("jreg_val", c_void_p), ("static_joints", c_int32), ("J_static", c_void_p), ("posedirs", c_void_p)]
 
 
 class LbsInputs(Structure):
@@ -43,12 +43,12 @@ class LbsInputs(Structure):
 
 
 class LbsOutputs(Structure):
-    _fields_ = [(n, c_void_p) for n in ("v_shaped", "J_rest", "Rs", "G", "A", "new_J", "verts", "joints")]
+    _fields_ = [(n, c_void_p) for n in ("v_shaped", "J_rest", "Rs", "G", "A", "new_J", "verts", "joints", "v_posed")]
 
 
 class LbsGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("d_verts", "d_joints", "d_beta", "d_theta", "d_logscale", "d_btrans",
-                                        "d_trans", "d_A", "d_Jrest", "d_Rs")]
+                                        "d_trans", "d_A", "d_Jrest", "d_Rs", "d_vposed", "d_posefeat")]
 
 
 class Cameras(Structure):

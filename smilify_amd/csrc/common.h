@@ -62,6 +62,7 @@ struct SmilModel {
     int *bone_vid = nullptr;
     float *bone_w = nullptr;
     float *J_static = nullptr;    // (J,3)
+    float *posedirs = nullptr;    // (9(J-1),3V) or null
     std::vector<void *> allocations;
 };
 

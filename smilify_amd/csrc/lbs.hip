@@ -12,6 +12,10 @@
 
 #define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels
 
+__device__ __forceinline__ void vertex_upstream(const float *__restrict__ d_verts_b, const float *sDJ,
+                                                const int *__restrict__ colptr, const int *__restrict__ row,
+                                                const float *__restrict__ cval, int v, bool regress, float dv[3]);
+
 struct Mat34 {
     float r[9];
     float t[3];
@@ -189,6 +193,95 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// pose blend shapes (legacy SMAL / SMPL models): v_posed = v_shaped + vec(Rs[1:] - I) @ posedirs   (smal_torch.py:294-301)
+// A (frames x 9(J-1)) x (9(J-1) x 3V) product; every posedirs element is loaded once per PB_FRAMES frames.
+// ---------------------------------------------------------------------------------------------
+#define PB_FRAMES 8
+__global__ void __launch_bounds__(256) k_pose_blend_fwd(const float *__restrict__ Rs, const float *__restrict__ pd,
+                                                        const float *__restrict__ v_shaped, float *__restrict__ v_posed, int B,
+                                                        int J, int V3, int nS) {
+    extern __shared__ float sfeat[];  // (PB_FRAMES, 9(J-1))
+    const int K9 = 9 * (J - 1);
+    const int b0 = blockIdx.y * PB_FRAMES;
+    for (int i = threadIdx.x; i < PB_FRAMES * K9; i += blockDim.x) {
+        const int fb = i / K9, k = i - fb * K9;
+        const int b = b0 + fb;
+        float v = 0.f;
+        if (b < B) v = Rs[((size_t)b * J + 1) * 9 + k] - ((k % 9) % 4 == 0 ? 1.0f : 0.0f);  // Rs[:,1:] - I
+        sfeat[i] = v;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= V3) return;
+    float acc[PB_FRAMES];
+#pragma unroll
+    for (int f = 0; f < PB_FRAMES; ++f) acc[f] = 0.f;
+    for (int k = 0; k < K9; ++k) {
+        const float p = pd[(size_t)k * V3 + e];
+#pragma unroll
+        for (int f = 0; f < PB_FRAMES; ++f) acc[f] += sfeat[f * K9 + k] * p;
+    }
+#pragma unroll
+    for (int f = 0; f < PB_FRAMES; ++f) {
+        const int b = b0 + f;
+        if (b < B) v_posed[(size_t)b * V3 + e] = acc[f] + v_shaped[(size_t)(nS == 1 ? 0 : b) * V3 + e];
+    }
+}
+
+// d_feat[b][k] = sum_e posedirs[k][e] d_vposed[b][e]; grid (ceil(K9/8), B)
+__global__ void __launch_bounds__(256) k_pose_blend_bwd(const float *__restrict__ pd, const float *__restrict__ d_vposed,
+                                                        float *__restrict__ d_feat, int K9, int V3) {
+    __shared__ float red[16];
+    const int b = blockIdx.y, k0 = blockIdx.x * 8;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    const float *dv = d_vposed + (size_t)b * V3;
+    for (int e = threadIdx.x; e < V3; e += blockDim.x) {
+        const float g = dv[e];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (k0 + q < K9) acc[q] += pd[(size_t)(k0 + q) * V3 + e] * g;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float r = block_sum(acc[q], red);
+        if (threadIdx.x == 0 && k0 + q < K9) d_feat[(size_t)b * K9 + k0 + q] = r;
+    }
+}
+
+// d_vposed[b][v] = (sum_k w_k A_k[:3,:3])^T dv  - the part of k_shape_bwd that the pose-blend backward needs first
+__global__ void __launch_bounds__(256) k_vposed_bwd(const float *__restrict__ d_verts, const float *__restrict__ d_joints,
+                                                    const float *__restrict__ A, const uint32_t *__restrict__ skin_idx,
+                                                    const float4 *__restrict__ skin_w, const int *__restrict__ colptr,
+                                                    const int *__restrict__ row, const float *__restrict__ cval,
+                                                    float *__restrict__ d_vposed, int V, int J, int regress) {
+    extern __shared__ float smem[];
+    float *sA = smem, *sDJ = smem + J * 12;
+    const int b = blockIdx.y;
+    const bool reg = regress && d_joints;
+    for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = A[(size_t)b * J * 12 + i];
+    for (int i = threadIdx.x; i < J * 3; i += blockDim.x) sDJ[i] = reg ? d_joints[(size_t)b * J * 3 + i] : 0.f;
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float dv[3];
+    vertex_upstream(d_verts ? d_verts + (size_t)b * V * 3 : nullptr, sDJ, colptr, row, cval, v, reg, dv);
+    const uint32_t ids = skin_idx[v];
+    const float4 w4 = skin_w[v];
+    const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+    float T[9];
+    for (int i = 0; i < 9; ++i) T[i] = 0.f;
+    for (int k = 0; k < SMIL_MAX_BONES; ++k) {
+        if (w[k] == 0.f) continue;
+        const float *Ak = sA + 12 * ((ids >> (8 * k)) & 0xFF);
+        for (int m = 0; m < 3; ++m) { T[3 * m] += w[k] * Ak[4 * m]; T[3 * m + 1] += w[k] * Ak[4 * m + 1]; T[3 * m + 2] += w[k] * Ak[4 * m + 2]; }
+    }
+    float *o = d_vposed + ((size_t)b * V + v) * 3;
+    for (int n = 0; n < 3; ++n) o[n] = T[n] * dv[0] + T[3 + n] * dv[1] + T[6 + n] * dv[2];
+}
+
+// ---------------------------------------------------------------------------------------------
 // skinning: verts = (sum_k w_k A_k) [v;1] + trans                               (smal_torch.py:320-340)
 // grid (ceil(V/256), B); the frame's J transforms are staged in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -278,10 +371,21 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
         hipLaunchKernelGGL(k_pose_fwd, dim3(ceil_div(B, FRAMES_PER_BLOCK)), dim3(64 * FRAMES_PER_BLOCK), lds, stream, a);
         SMIL_LAUNCH_CHECK();
     }
+    const float *v_skin = out->v_shaped;
+    int nS_skin = nS;
+    if (m->posedirs) {
+        SMIL_REQUIRE(out->v_posed && out->Rs, "smil_lbs_forward: this model has pose blend shapes: v_posed and Rs outputs required");
+        dim3 grid(ceil_div(3 * V, 256), ceil_div(B, PB_FRAMES));
+        hipLaunchKernelGGL(k_pose_blend_fwd, grid, dim3(256), (size_t)PB_FRAMES * 9 * (J - 1) * sizeof(float), stream, out->Rs,
+                           m->posedirs, out->v_shaped, out->v_posed, B, J, 3 * V, nS);
+        SMIL_LAUNCH_CHECK();
+        v_skin = out->v_posed;
+        nS_skin = B;
+    }
     {
         dim3 grid(ceil_div(V, 256), B);
-        hipLaunchKernelGGL(k_skin_fwd, grid, dim3(256), (size_t)J * 12 * sizeof(float), stream, out->A, out->v_shaped,
-                           m->skin_idx, m->skin_w, in->trans, out->verts, V, J, nS);
+        hipLaunchKernelGGL(k_skin_fwd, grid, dim3(256), (size_t)J * 12 * sizeof(float), stream, out->A, v_skin,
+                           m->skin_idx, m->skin_w, in->trans, out->verts, V, J, nS_skin);
         SMIL_LAUNCH_CHECK();
     }
     if (!m->static_joints) {
@@ -349,6 +453,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd_transforms(
 
 struct ChainBwdArgs {
     const float *theta, *Rs, *logscale, *btrans, *J_rest, *G, *d_A, *d_newJ;
+    const float *d_posefeat;  // (B,9(J-1)) gradient on vec(Rs[1:] - I) from the pose blend shapes, or NULL
     const int *parents, *depth;
     float *d_theta, *d_logscale, *d_btrans, *d_Jrest;
     int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
@@ -466,6 +571,8 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                         }
                     }
                 }
+                if (a.d_posefeat && j > 0)
+                    for (int i = 0; i < 9; ++i) dR[i] += a.d_posefeat[fb * 9 * (J - 1) + (size_t)(j - 1) * 9 + i];
                 if (a.d_theta && a.theta) {
                     const float *th = a.theta + o * 3;
                     float dth[3];
@@ -609,10 +716,28 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     const int regress = m->static_joints ? 0 : 1;
     const int use_scale = (in->logscale && in->allow_limb_scaling) ? 1 : 0;
 
+    const float *v_skin = m->posedirs ? sv->v_posed : sv->v_shaped;
+    const int nS_skin = m->posedirs ? B : nS;
+    SMIL_REQUIRE(!m->posedirs || (sv->v_posed && g->d_vposed), "smil_lbs_backward: pose blend shapes need v_posed and d_vposed");
     hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(256), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
-                       g->d_joints, sv->v_shaped, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
-                       m->jreg_cval, g->d_A, V, J, nS, regress);
+                       g->d_joints, v_skin, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
+                       m->jreg_cval, g->d_A, V, J, nS_skin, regress);
     SMIL_LAUNCH_CHECK();
+    const float *d_posefeat = nullptr;
+    if (m->posedirs && g->d_theta && !in->Rs_in) {
+        // gradient through v_posed -> vec(Rs[1:] - I): d_vposed, then the transposed product with posedirs;
+        // the (B,9(J-1)) result lives in the d_Rs scratch behind the per-frame scale / translation gradients
+        const int K9 = 9 * (J - 1);
+        dim3 gridv(ceil_div(V, 256), B);
+        hipLaunchKernelGGL(k_vposed_bwd, gridv, dim3(256), (size_t)J * 15 * sizeof(float), stream, g->d_verts, g->d_joints, sv->A,
+                           m->skin_idx, m->skin_w, m->jreg_colptr, m->jreg_row, m->jreg_cval, g->d_vposed, V, J, regress);
+        SMIL_LAUNCH_CHECK();
+        SMIL_REQUIRE(g->d_posefeat, "smil_lbs_backward: pose blend shapes need the d_posefeat scratch");
+        dim3 gridf(ceil_div(K9, 8), B);
+        hipLaunchKernelGGL(k_pose_blend_bwd, gridf, dim3(256), 0, stream, m->posedirs, g->d_vposed, g->d_posefeat, K9, 3 * V);
+        SMIL_LAUNCH_CHECK();
+        d_posefeat = g->d_posefeat;
+    }
 
     // per-frame scale / translation gradients go to the output directly, or to scratch (d_Rs) when the
     // table is shared by all frames and has to be reduced over frames afterwards
@@ -625,6 +750,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         a.theta = in->Rs_in ? nullptr : in->theta; a.Rs = sv->Rs;
         a.logscale = in->logscale; a.btrans = in->btrans; a.J_rest = sv->J_rest; a.G = sv->G; a.d_A = g->d_A;
         a.d_newJ = m->static_joints ? g->d_joints : nullptr;
+        a.d_posefeat = d_posefeat;
         a.parents = m->parents; a.depth = m->depth;
         a.d_theta = g->d_theta; a.d_logscale = dls_frame; a.d_btrans = dbt_frame; a.d_Jrest = g->d_Jrest;
         a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;

@@ -130,6 +130,7 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
     UP(bone_vid, bone_vid.data(), bone_nnz);
     UP(bone_w, bone_w.data(), bone_nnz);
     UP(J_static, d->static_joints ? d->J_static : (const float *)nullptr, 3 * J);
+    if (d->posedirs) { UP(posedirs, d->posedirs, (size_t)9 * (J - 1) * 3 * V); }
 #undef UP
     *out = m;
     return SMIL_OK;

@@ -66,6 +66,10 @@ class DeviceModel:
         )
         if t.static_joints:
             arrs["J_static"] = np.ascontiguousarray(t.J_static, np.float32)
+        if t.posedirs is not None:
+            if t.posedirs.shape != (9 * (t.J - 1), 3 * t.V):
+                raise _lib.SmilError(f"posedirs shape {t.posedirs.shape} != ({9 * (t.J - 1)}, {3 * t.V})")
+            arrs["posedirs"] = np.ascontiguousarray(t.posedirs, np.float32)
         d = _lib.ModelDesc()
         d.V, d.F, d.J, d.nB = t.V, t.F, t.J, t.nB
         for k, a in arrs.items():
@@ -77,6 +81,7 @@ class DeviceModel:
         self.handle = handle
         self.V, self.F, self.J, self.nB = t.V, t.F, t.J, t.nB
         self.static_joints = bool(t.static_joints)
+        self.has_posedirs = t.posedirs is not None
         self._ws: Optional[torch.Tensor] = None
 
     def __del__(self):
@@ -141,6 +146,8 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     out = dict(v_shaped=f(nS, V, 3), J_rest=f(nS, J, 3), Rs=f(B, J, 3, 3), G=f(B, J, 3, 4), A=f(B, J, 3, 4),
                new_J=f(B, J, 3), verts=f(B, V, 3), joints=f(B, J, 3))
+    if model.has_posedirs:
+        out["v_posed"] = f(B, V, 3)
     inp = dict(beta=beta, theta=theta, Rs_in=Rs_in, logscale=logscale, btrans=btrans, trans=trans, del_v=del_v,
                v_template=v_template)
     i = _lib.LbsInputs()
@@ -189,6 +196,10 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
     o = _lib.LbsOutputs()
     for k in ("v_shaped", "J_rest", "Rs", "G", "A", "new_J", "verts", "joints"):
         setattr(o, k, saved[k].data_ptr())
+    if model.has_posedirs:
+        o.v_posed = saved["v_posed"].data_ptr()
+        scratch["d_vposed"] = f(B, model.V, 3)
+        scratch["d_posefeat"] = f(B, 9 * (J - 1))
     gs = _lib.LbsGrads()
     gs.d_verts = None if d_verts is None else d_verts.data_ptr()
     gs.d_joints = None if d_joints is None else d_joints.data_ptr()

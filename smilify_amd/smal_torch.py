@@ -9,8 +9,8 @@ Differences that are deliberate and documented:
 * gradients flow to ``beta, theta (axis-angle), trans, betas_logscale, betas_trans`` through ``verts`` and
   ``joints``; ``Rs`` and ``v_shaped`` are returned without gradient, and ``del_v`` / rotation-matrix ``theta``
   receive none;
-* non-empty pose blend shapes (legacy SMAL ``posedirs``) are not supported: every SMIL model ships an empty
-  table (reference :182-190) - a model with real posedirs raises ``NotImplementedError``.
+* pose blend shapes (legacy SMAL ``posedirs``) are applied when the model has a non-zero table; every SMIL
+  model ships an empty one (reference :182-190) and skips that product entirely.
 """
 from __future__ import annotations
 
@@ -68,8 +68,6 @@ class SMAL(nn.Module):
             if path is None:
                 raise ValueError("SMAL needs model_path=, tables= or smilify_amd.config.current.SMAL_FILE")
             tables = model_io.load_model(path)
-        if tables.posedirs is not None:
-            raise NotImplementedError("non-empty pose blend shapes are not supported by the HIP path")
         self.tables = tables
         self.config = config or _config.current or _config.FitterConfig.from_tables(tables, model_path)
         self.device = engine.require_gpu(device)
@@ -106,7 +104,8 @@ class SMAL(nn.Module):
 
     @property
     def posedirs(self):
-        return self._lazy("posedirs", lambda: np.zeros(((self.tables.J - 1) * 9, self.tables.V * 3), np.float32))
+        t = self.tables
+        return self._lazy("posedirs", lambda: t.posedirs if t.posedirs is not None else np.zeros(((t.J - 1) * 9, t.V * 3), np.float32))
 
     @property
     def device_model(self) -> engine.DeviceModel:

@@ -226,8 +226,43 @@ def fitter_goldens(key, pkl_path, S=64, N=3):
     print(f"fitter_{key}: loss={loss.item():.6f}", {k: round(v.item(), 6) for k, v in objs.items()})
 
 
+def posedirs_golden():
+    """Pose blend shapes: no SMIL model ships a non-empty table, so a small synthetic model is pickled in the
+    reference's schema, loaded by the REAL reference SMAL, and given a random posedirs table."""
+    import pickle
+    import tempfile
+
+    t = model_io.synthetic_model(seed=4)
+    JR = t.dense_J_regressor().T.copy()
+    dd = dict(f=t.faces.astype(np.int32), J_regressor=JR, kintree_table=np.stack([t.parents.astype(np.int64), np.arange(t.J)]),
+              J=np.zeros((t.J, 3), np.float32), weights=t.dense_weights(), posedirs=np.zeros(0), v_template=t.v_template.astype(np.float64),
+              shapedirs=t.shapedirs.T.reshape(t.V, 3, t.nB).astype(np.float64), J_names=list(t.joint_names), bs_style="lbs", bs_type="lrotmin")
+    path = os.path.join(tempfile.mkdtemp(), "synthetic_tube.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump(dd, fh, protocol=2)
+    install_stubs(path)
+    from smal_model.smal_torch import SMAL
+
+    smal = SMAL("cpu")
+    g = torch.Generator().manual_seed(99)
+    pd = 0.02 * torch.randn(9 * (t.J - 1), 3 * t.V, generator=g)
+    smal.posedirs = pd
+    B = 3
+    beta = (0.5 * torch.randn(B, t.nB, generator=g)).requires_grad_()
+    theta = (0.4 * torch.randn(B, t.J, 3, generator=g)).requires_grad_()
+    trans = (0.1 * torch.randn(B, 3, generator=g)).requires_grad_()
+    verts, joints, Rs, v_shaped = smal(beta, theta, trans=trans)
+    loss = (verts * vertex_probe(verts.shape, 0)).sum() + (joints * vertex_probe(joints.shape, 1)).sum()
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "lbs_posedirs.npz"), posedirs=pd.numpy(), beta=beta.detach().numpy(), theta=theta.detach().numpy(),
+                        trans=trans.detach().numpy(), verts=verts.detach().numpy(), joints=joints.detach().numpy(),
+                        grad_beta=beta.grad.numpy(), grad_theta=theta.grad.numpy(), grad_trans=trans.grad.numpy(), seed=np.int32(4))
+    print("lbs_posedirs: loss", loss.item())
+
+
 def main():
     os.makedirs(os.path.join(REPO, "data", "models"), exist_ok=True)
+    posedirs_golden()
     for key, p in MODELS.items():
         t = model_io.load_model(p)
         t.save_npz(os.path.join(REPO, "data", "models", os.path.basename(p).replace(".pkl", ".npz")))

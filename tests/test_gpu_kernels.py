@@ -313,3 +313,24 @@ def test_prior_joint_losses_and_adam():
         opt.step()
         eng.adam_step(pg, grad.to(DEV), m_, v_, 5e-3, step)
     np.testing.assert_allclose(pg.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_pose_blend_shapes_forward_backward(golden):
+    """Legacy-SMAL pose blend shapes against the real reference (golden) and the SMAL drop-in API."""
+    from smilify_amd import model_io
+    from smilify_amd.smal_torch import SMAL
+
+    g = golden("lbs_posedirs")
+    t = model_io.synthetic_model(seed=int(g["seed"]))
+    t.posedirs = g["posedirs"].astype(np.float32)
+    smal = SMAL(DEV, tables=t)
+    leaves = {n: torch.from_numpy(g[n]).to(DEV).requires_grad_() for n in ("beta", "theta", "trans")}
+    verts, joints, Rs, v_shaped = smal(leaves["beta"], leaves["theta"], trans=leaves["trans"])
+    np.testing.assert_allclose(verts.detach().cpu().numpy(), g["verts"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(joints.detach().cpu().numpy(), g["joints"], rtol=1e-4, atol=5e-6)
+    ((verts * vertex_probe(verts.shape, 0).to(DEV)).sum() + (joints * vertex_probe(joints.shape, 1).to(DEV)).sum()).backward()
+    for n in leaves:
+        ref = g[f"grad_{n}"]
+        sc = np.abs(ref).max()
+        np.testing.assert_allclose(leaves[n].grad.cpu().numpy() / sc, ref / sc, atol=3e-4, err_msg=n)
+    assert tuple(smal.posedirs.shape) == (9 * (t.J - 1), 3 * t.V)

@@ -75,3 +75,23 @@ def test_plain_call_shared_betas(key, golden, tables):
     out = lbs_ref.smal_forward(m, beta, torch.from_numpy(g["smal_theta"][1:3]))
     np.testing.assert_allclose(out["verts"].numpy(), g["plain_verts"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(out["joints"].numpy(), g["plain_joints"], rtol=1e-4, atol=2e-6)
+
+
+def test_pose_blend_shapes_match_reference(golden):
+    """posedirs path (smal_torch.py:294-301): the real reference SMAL loaded a pickled synthetic model and was given
+    a random posedirs table (no shipped SMIL model has one)."""
+    from smilify_amd import model_io
+
+    g = golden("lbs_posedirs")
+    t = model_io.synthetic_model(seed=int(g["seed"]))
+    m = oracle_model(t)
+    m["posedirs"] = torch.from_numpy(g["posedirs"])
+    leaves = {n: torch.from_numpy(g[n]).clone().requires_grad_() for n in ("beta", "theta", "trans")}
+    out = lbs_ref.smal_forward(m, leaves["beta"], leaves["theta"], trans=leaves["trans"])
+    np.testing.assert_allclose(out["verts"].detach().numpy(), g["verts"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(out["joints"].detach().numpy(), g["joints"], rtol=1e-4, atol=2e-6)
+    ((out["verts"] * vertex_probe(out["verts"].shape, 0)).sum() + (out["joints"] * vertex_probe(out["joints"].shape, 1)).sum()).backward()
+    for n in leaves:
+        ref = g[f"grad_{n}"]
+        sc = np.abs(ref).max()
+        np.testing.assert_allclose(leaves[n].grad.numpy() / sc, ref / sc, atol=2e-4, err_msg=n)

@@ -187,9 +187,19 @@ class SMALFitter(nn.Module):
         self._canon_identity = canon == list(range(self.smal_model.tables.J))
         self._canon_dev = torch.tensor(canon, dtype=torch.int32, device=dev)
         self._targets_dirty = False
+        self._target_signature = self._signature()
+
+    def _signature(self):
+        """(identity, in-place version) of every target tensor: the reference driver edits ``target_visibility`` in
+        place (optimize_to_joints.py:135-138), which no attribute hook can see; torch's version counter can."""
+        sig = []
+        for t_ in (self.target_visibility, self.target_joints, self.sil_imgs):
+            sig.append(None if t_ is None else (id(t_), t_._version))
+        sig.append(tuple(self.config.CANONICAL_MODEL_JOINTS))
+        return tuple(sig)
 
     def invalidate_targets(self):
-        """Call after editing ``target_joints`` / ``target_visibility`` / ``sil_imgs`` in place."""
+        """Force a re-upload of the targets (in-place edits and re-assignments are detected automatically)."""
         self._targets_dirty = True
 
     def __setattr__(self, name, value):
@@ -218,7 +228,7 @@ class SMALFitter(nn.Module):
         Returns ``(objs (10,), grads)`` with full-size gradient tensors (zero rows outside ``frames``).
         ``window``: frames per loss window; None = the selected frames form one window (``forward`` semantics).
         """
-        if self._targets_dirty:
+        if self._targets_dirty or self._signature() != self._target_signature:
             self._refresh_targets()
         dev, dm, cfg = self.device, self.device_model, self.config
         J, nB, V, views, S = dm.J, dm.nB, dm.V, self.views, self.image_size

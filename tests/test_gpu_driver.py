@@ -64,3 +64,55 @@ def test_checkpoint_roundtrip(tables, tmp_path):
     # the loaded fitter is usable: shared (1,J,3) scale table
     loss, _ = g([0, 1, 2], synthetic.STAGE1_WEIGHTS, 1)
     assert torch.isfinite(loss)
+
+
+def test_reference_style_driver_loop(tables):
+    """The reference's own loop shape (optimize_to_joints.py:110-178): torch.optim.Adam over named_parameters with fov in
+    its own group, in-place visibility masking, forward per window + get_temporal, one backward, one step."""
+    from smilify_amd import synthetic
+
+    t = tables("synthetic")
+    N, W = 6, 2
+    model = synthetic.make_problem(t, N, 1, 40, DEV, radius=2.2, seed=21, window=W)
+    model.log_beta_scales.requires_grad = False
+    torso = [0, 1, 5]
+    full_vis = model.target_visibility.clone()
+    losses = {}
+    for stage_id, (weights, w_temp, epochs, lr) in enumerate([([25.0, 0, 0, 0, 0, 0], 500.0, 4, 2e-2), ([10.0, 500.0, 1, 1, 100.0, 0.1], 100.0, 4, 5e-3)]):
+        optimizer = torch.optim.Adam([{"params": [p for n, p in model.named_parameters() if n != "fov"], "lr": lr},
+                                      {"params": [model.fov], "lr": 1}], lr=lr, betas=(0.5, 0.999))
+        if stage_id == 0:
+            model.joint_rotations.requires_grad = False
+            model.betas.requires_grad = False
+            target_visibility = model.target_visibility.clone()
+            model.target_visibility *= 0
+            model.target_visibility[:, torso] = target_visibility[:, torso]      # in-place edit, as the reference does
+        else:
+            model.joint_rotations.requires_grad = True
+            model.betas.requires_grad = True
+            model.target_visibility = full_vis.clone()
+        for epoch in range(epochs):
+            acc_loss = 0
+            optimizer.zero_grad()
+            for j in range(0, N, W):
+                loss, objs = model(list(range(j, min(N, j + W))), weights, stage_id)
+                acc_loss += loss.mean()
+            jl, gl, tl = model.get_temporal(w_temp)
+            acc_loss = acc_loss + jl + gl + tl
+            acc_loss.backward()
+            optimizer.step()
+            losses.setdefault(stage_id, []).append(float(acc_loss))
+        if stage_id == 0:
+            assert int(model._vis_dev.sum()) == N * len(torso), "in-place visibility mask was not picked up"
+    assert losses[0][-1] < losses[0][0] and losses[1][-1] < losses[1][0], losses
+    # the same two stages through the fused driver give the same first-epoch loss of stage 0
+    ref = synthetic.make_problem(t, N, 1, 40, DEV, radius=2.2, seed=21, window=W)
+    ref.log_beta_scales.requires_grad = False
+    vis = torch.zeros_like(ref.target_visibility)
+    vis[:, torso] = ref.target_visibility[:, torso]
+    ref.target_visibility = vis
+    ref.joint_rotations.requires_grad = False
+    ref.betas.requires_grad = False
+    ref.begin_stage(2e-2)
+    objs = ref.fit_step([25.0, 0, 0, 0, 0, 0], 500.0, window=W)
+    assert abs(float(objs[:9].sum()) - losses[0][0]) <= 1e-4 * abs(losses[0][0])

@@ -166,7 +166,7 @@ def main():
         achieved = (n_img * per_view) / (kern_avg_ms * 1e-3) / 1e9 if kern_n else 0.0
         iter_bytes = frames * (per_frame + views * per_view)
         traffic = None
-        tpath = os.path.join(REPO, "profiles", "r1d_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r1e_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath)).get(args.workload)
             if tj and tj["images_per_launch"] == n_img:
@@ -192,7 +192,7 @@ def main():
             "final_loss": loss,
             "roofline": {"bound": "hbm", "kernel": "k_raster_tiles<FUSED> (soft silhouette fwd + L1 + bwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1d_traffic.json" if traffic else None,
+                         "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1e_traffic.json" if traffic else None,
                          "algorithmic_bytes_per_launch": n_img * per_view, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_image": per_view,
                          "iteration_frac": (iter_bytes / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,

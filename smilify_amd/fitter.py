@@ -390,6 +390,12 @@ class SMALFitter(nn.Module):
         scales = torch.from_numpy(np.mean(scale_list, axis=0)).float().to(self.device).reshape(1, -1, 3)
         self.log_beta_scales = nn.Parameter(scales, requires_grad=self.log_beta_scales.requires_grad)
 
+    def generate_visualization(self, image_exporter, *args, **kwargs):
+        """Collage / mesh export of the reference (fitter.py:373-517) is image I/O and out of scope for this build;
+        ``export_parameters`` provides the per-frame parameter dict it writes next to the images."""
+        raise NotImplementedError("generate_visualization (png/ply export) is not part of the MI355X fitting path; "
+                                  "use export_parameters(frame_id) for the per-frame parameter dict")
+
     def export_parameters(self, frame_id: int) -> Dict[str, np.ndarray]:
         """The per-frame dict the reference pickles (optimize_to_joints.py:48-63, fitter.py:241-261,507)."""
         ls = self.log_beta_scales.detach()

@@ -118,6 +118,15 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    from smilify_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):  # fresh checkout: build once (rank 0), everybody else waits
+        if rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     from smilify_amd import engine, model_io, optimize, synthetic
 
     wl = WORKLOADS[args.workload]

@@ -20,6 +20,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_built():
+    """The HIP library is built in-tree by __graft_entry__.build(); build it here if a fresh checkout lacks it
+    (hipcc cross-compiles gfx950 without a GPU).  The product itself never falls back: a missing .so raises."""
+    from smilify_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+
+
 def oracle_model(tables):
     """Dense fp32 torch tables for the oracle from the product's flat tables (test-side densify)."""
     m = dict(

@@ -344,8 +344,11 @@ __device__ __forceinline__ void depth_sort_list(const float *__restrict__ fz_n, 
         }                                                                                      \
     }
 
-template <int KT>
+// EXACT: K == KT is known at compile time (the common K = 100 case): the K-th smallest is simply the last slot.
+// Otherwise the slot is picked with a chain of selects, which costs ~KT scalar lane masks - kept off the hot path.
+template <int KT, bool EXACT>
 __device__ __forceinline__ float kth_smallest(const float (&r)[KT], int K) {
+    if (EXACT) return r[KT - 1];
     float v = 3.0e38f;
 #pragma unroll
     for (int i = 0; i < KT; ++i)
@@ -354,11 +357,11 @@ __device__ __forceinline__ float kth_smallest(const float (&r)[KT], int K) {
 }
 
 // KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD
-template <int MODE, int KT>
+template <int MODE, int KT, bool EXACT>
 __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
     __shared__ TileLds lds;
     const int lane = threadIdx.x;
-    const int K = a.K;
+    const int K = EXACT ? KT : a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
     const unsigned int n_items = a.ctr->n_items;
 
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         for (int i = 0; i < KT; ++i) r[i] = 3.0e38f;
         // a pixel is settled once it holds K depths and its K-th smallest is not beyond the next face; the pass may
         // stop when every pixel of the tile is settled (pixels with fewer than K candidates never are)
-        CHUNK_LOOP_BEGIN(false, wave_max(!in_img ? -3.0e38f : (cnt < K ? 3.0e38f : kth_smallest<KT>(r, K))))
+        CHUNK_LOOP_BEGIN(false, wave_max(!in_img ? -3.0e38f : (cnt < K ? 3.0e38f : kth_smallest<KT, EXACT>(r, K))))
         {
             for (int i = 0; i < m; ++i) {
                 const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
@@ -426,9 +429,9 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         float zt = 3.0e38f;  // depth threshold (K-th smallest)
         int r_ties = 0;
         if (__ballot(trunc) != 0ull) {
-            zt = kth_smallest<KT>(r, K);
+            zt = kth_smallest<KT, EXACT>(r, K);
 #pragma unroll
-            for (int i = 0; i < KT; ++i) r_ties += (i < K && r[i] == zt) ? 1 : 0;
+            for (int i = 0; i < KT; ++i) r_ties += ((EXACT || i < K) && r[i] == zt) ? 1 : 0;
             // ------------- pass 2: product over the K nearest for truncated pixels ---------------
             float prod = 1.0f;
             int ties = 0;
@@ -630,9 +633,9 @@ static int tile_grid(int N, int tiles_x) {
 template <int MODE>
 static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
     const dim3 grid(tile_grid(N, a.tiles_x)), block(64);
-    if (a.K <= 16) hipLaunchKernelGGL((k_raster_tiles<MODE, 16>), grid, block, 0, stream, a);
-    else if (a.K <= 104) hipLaunchKernelGGL((k_raster_tiles<MODE, 104>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_raster_tiles<MODE, SMIL_MAX_FACES_PER_PIXEL>), grid, block, 0, stream, a);
+    if (a.K == 100) hipLaunchKernelGGL((k_raster_tiles<MODE, 100, true>), grid, block, 0, stream, a);  // the reference's K
+    else if (a.K <= 16) hipLaunchKernelGGL((k_raster_tiles<MODE, 16, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_raster_tiles<MODE, SMIL_MAX_FACES_PER_PIXEL, false>), grid, block, 0, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

@@ -30,6 +30,11 @@ WORKLOADS = {
     "cfg3": dict(model="SMILy_Mouse_static_joints", frames=256, views=18, S=256, radius=4.0,
                  name="cfg3: Mouse_static_joints (Falkner stand-in) B=256 x 18 views @256^2"),
     "cfg4": dict(model="SMILy_STICK", frames=256, views=4, S=512, radius=2.7, name="cfg4: STICK B=256/GPU x 4 views @512^2"),
+    # BASELINE.json configs[4] is 8192 frames/GPU of this shape (weak scaling); cfg5s is the same shape at 128 frames
+    "cfg5": dict(model="SMILy_Mouse_static_joints", frames=8192, views=18, S=512, radius=4.0,
+                 name="cfg5: Mouse_static_joints (Falkner stand-in) 8192 frames/GPU x 18 views @512^2"),
+    "cfg5s": dict(model="SMILy_Mouse_static_joints", frames=128, views=18, S=512, radius=4.0,
+                  name="cfg5s: Mouse_static_joints 128 frames x 18 views @512^2 (cfg5 shape, reduced frame count)"),
     "tiny": dict(model="SMILy_STICK", frames=16, views=1, S=128, radius=2.7, name="tiny: STICK B=16 @128^2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec

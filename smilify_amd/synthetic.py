@@ -33,7 +33,7 @@ def random_pose(n: int, J: int, gen: torch.Generator, amp: float = 0.15):
 
 def make_problem(tables: model_io.SmilModelTables, frames: int, views: int, S: int, device, radius: float = 2.7,
                  seed: int = 1234, window: int = 10, frame0: int = 0, n_frames_total: Optional[int] = None,
-                 target_chunk: int = 256) -> SMALFitter:
+                 target_chunk: int = 0) -> SMALFitter:
     """A ``SMALFitter`` on ``device`` holding ``frames`` synthetic frames x ``views`` cameras of side ``S``.
 
     Targets: hard silhouettes (threshold 0.5) and projected joints (+ N(0,1 px)) of a second random pose
@@ -53,8 +53,10 @@ def make_problem(tables: model_io.SmilModelTables, frames: int, views: int, S: i
 
     dm = engine.DeviceModel(tables, dev)
     cams = engine.CameraSet(R.contiguous(), T.contiguous(), fov, None, views, S)
-    sil = torch.empty(frames * views, 1, S, S, dtype=torch.float32, device=dev)
+    sil = torch.empty(frames * views, 1, S, S, dtype=torch.uint8, device=dev)  # binary masks
     tj = torch.empty(frames * views, J, 2, dtype=torch.float32, device=dev)
+    if target_chunk <= 0:  # keep the temporary (chunk*views, S, S) fp32 render around 1 GiB
+        target_chunk = max(1, (1 << 28) // (views * S * S))
     for f0 in range(0, frames, target_chunk):
         f1 = min(frames, f0 + target_chunk)
         out = engine.lbs_forward(dm, betas1.to(dev), pose1[f0:f1].to(dev).contiguous(), trans=trans1[f0:f1].to(dev).contiguous(),
@@ -62,7 +64,7 @@ def make_problem(tables: model_io.SmilModelTables, frames: int, views: int, S: i
         ndc, _ = engine.project(cams, out["verts"], want_yx=False)
         _, yx = engine.project(cams, out["joints"], want_ndc=False)
         s = engine.silhouette_forward(dm, ndc, S)
-        sil[f0 * views:f1 * views, 0] = (s > 0.5).float()
+        sil[f0 * views:f1 * views, 0] = (s > 0.5).to(torch.uint8)
         tj[f0 * views:f1 * views] = yx
     noise = torch.randn(frames * views, J, 2, generator=gen_t).to(dev)
     tj = tj + noise

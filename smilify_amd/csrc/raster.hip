@@ -435,11 +435,12 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             // ------------- pass 2: product over the K nearest for truncated pixels ---------------
             float prod = 1.0f;
             int ties = 0;
-            // faces whose nearest vertex is beyond every truncated pixel's threshold cannot be among its K nearest
-            const float cut2 = wave_max(trunc ? zt : -3.0e38f);
-            CHUNK_LOOP_BEGIN(false, nextafterf(cut2, 3.0e38f))
+            // faces whose nearest vertex is beyond every unfinished truncated pixel's threshold cannot be among its K
+            // nearest.  A pixel is finished once its product is below ALPHA_GRAD_EPS: 1 - alpha already rounds to 1.0f
+            // and the pixel is below the gradient threshold, so no output can change any more.
+            CHUNK_LOOP_BEGIN(false, nextafterf(wave_max((trunc && prod > ALPHA_GRAD_EPS) ? zt : -3.0e38f), 3.0e38f))
             {
-                if (__ballot(trunc && prod != 0.0f) != 0ull) {
+                if (__ballot(trunc && prod > ALPHA_GRAD_EPS) != 0ull) {
                     for (int i = 0; i < m; ++i) {
                         const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
                         if (__ballot(trunc && !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;

@@ -23,9 +23,11 @@
 //              first r faces (ascending face id) with depth == t, t = K-th smallest depth.
 //      pass 3: (backward / fused) per-pair gradient added to per-face LDS accumulators (ds_add_f32),
 //              flushed once per 64-face chunk with one global atomic per touched vertex component.
-//  * Deviation from the reference kept on purpose: ties at the K-th depth are resolved by face id, the
-//    reference's unsorted-queue eviction depends on visiting history (measured effect on the L1 loss:
-//    ~1e-5 relative, tests/test_raster_parity.py).
+//  * Tile lists that can truncate are sorted front to back (16-bit quantised nearest-vertex depth | face id, bitonic
+//    sort in LDS), so every pass stops at the first 64-face chunk that lies wholly beyond what any pixel still needs.
+//  * Deviation from the reference kept on purpose: ties at the K-th depth are resolved by visiting order (depth
+//    bucket, then face id); the reference's unsorted-queue eviction depends on visiting history (measured effect on
+//    the L1 loss: ~1e-5 relative; tests/test_gpu_kernels.py::test_silhouette_forward).
 #include "common.h"
 
 #define TILE 8

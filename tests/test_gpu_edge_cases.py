@@ -199,3 +199,32 @@ def test_uint8_targets_equal_float_targets(tables):
     assert (gb - gf).norm().item() <= 1e-5 * gf.norm().item()
     with pytest.raises(Exception):
         eng.silhouette_l1_fused(dm, ndc, S, tgt_f.double(), sum_f, scale)
+
+
+@pytest.mark.parametrize("key,dist", [("stick", 2.7), ("mouse", 4.0)])
+def test_full_resolution_against_oracle(key, dist, tables):
+    """256^2 (the BASELINE resolution) on the real models, two frames: silhouette, fused loss and gradient against the
+    CPU oracle (naive rasteriser with the faithful K = 100 queue)."""
+    eng = _eng()
+    t = tables(key)
+    dm = eng.DeviceModel(t, DEV)
+    S = 256
+    ndc = _scene(t, 2, S, dist, 31)
+    tgt = _scene(t, 2, S, dist, 32)
+    ref, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    target = (torch.from_numpy(render_ref.silhouette_forward_np(tgt.numpy(), t.faces, S)[0]) > 0.5).float()
+    assert (ncand > 100).mean() > 0.01
+    scale = torch.full((2,), 500.0 / (2 * S * S))
+    gsil = torch.sign(torch.from_numpy(ref) - target) * scale[:, None, None]
+    want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gsil.numpy())[..., :2]
+    li, dn, sil = eng.silhouette_l1_fused(dm, ndc.to(DEV), S, target.to(torch.uint8).to(DEV), eng.image_abs_sum(target.to(DEV)),
+                                          scale.to(DEV), want_sil=True)
+    got = sil.cpu().numpy()
+    d = np.abs(got - ref)
+    assert d.mean() < 1e-6 and np.mean(d > 1e-4) < 1e-3, (d.mean(), np.mean(d > 1e-4))
+    loss_ref = np.abs(ref - target.numpy()).sum(axis=(1, 2))
+    np.testing.assert_allclose(li.cpu().numpy(), loss_ref, rtol=1e-4)     # the north-star tolerance
+    g = dn.cpu().numpy()
+    cos = (g * want).sum() / (np.linalg.norm(g) * np.linalg.norm(want))
+    rel = np.linalg.norm(g - want) / np.linalg.norm(want)
+    assert cos > 0.9999 and rel < 2e-2, (cos, rel)

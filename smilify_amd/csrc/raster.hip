@@ -36,6 +36,9 @@
 #define FREC 32             // floats per staged face record
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
+#define DGROUP 4            // 64-record rows in flight in the dense pass 3
+#define SGROUP 8            // stream records in flight per lane in passes 2 and 3
+#define VAL_CAP 65536       // pair records (16 B) a workgroup can carry from pass 1 to passes 2 and 3
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
@@ -61,6 +64,11 @@ struct RasterArgs {
     const float *pix_scale;  // FUSED (N,)
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
+    // pair stream (STREAM kernels): per resident workgroup LIST_CAP headers + VAL_CAP records
+    uint4 *shdr;
+    float4 *sval;
+    uint32_t *smeta;         // per record: pixel (lane) | list position << 6
+    unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
 };
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
@@ -168,10 +176,15 @@ struct PairEval {
     bool cand, inside;
     float sd;             // signed squared distance
     float w0, w1, w2;
-    float d01, d02, d12;  // squared distances to the three edge segments
-    float t01, t02, t12;  // clamped projections
-    float r01x, r01y, r02x, r02y, r12x, r12y;  // closest point minus pixel, per edge
+    // closest edge in the reference's order e01, e02, e12 with <= ties (its backward treats t as a constant):
+    // edge 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2); t = clamped projection; (rx, ry) = closest point minus pixel,
+    // sq2(rx, ry) == |sd| bit for bit
+    int edge;
+    float t, rx, ry;
 };
+
+// |r|^2 with one fixed rounding sequence, so that a distance recomputed from a stored (rx, ry) is bit-identical
+__device__ __forceinline__ float sq2(float x, float y) { return __fmaf_rn(x, x, y * y); }
 
 // Branch-free: every lane computes everything; `cand` says whether the pair exists.
 __device__ __forceinline__ void eval_pair(const FaceRec &f, float px, float py, float dxp, float dyp, float blur, PairEval &e) {
@@ -181,18 +194,22 @@ __device__ __forceinline__ void eval_pair(const FaceRec &f, float px, float py, 
     e.w2 = fmaf(f.A2, dxp, fmaf(f.B2, dyp, f.C2));
     e.inside = (e.w0 > 0.f) && (e.w1 > 0.f) && (e.w2 > 0.f);
     const float dx0 = dxp - f.x0c, dy0 = dyp - f.y0c, dx1 = dxp - f.x1c, dy1 = dyp - f.y1c;
-    e.t01 = __builtin_amdgcn_fmed3f((f.e01x * dx0 + f.e01y * dy0) * f.rl01, 0.f, 1.f);
-    e.t02 = __builtin_amdgcn_fmed3f((f.e02x * dx0 + f.e02y * dy0) * f.rl02, 0.f, 1.f);
-    e.t12 = __builtin_amdgcn_fmed3f((f.e12x * dx1 + f.e12y * dy1) * f.rl12, 0.f, 1.f);
-    e.r01x = fmaf(e.t01, f.e01x, -dx0); e.r01y = fmaf(e.t01, f.e01y, -dy0);
-    e.r02x = fmaf(e.t02, f.e02x, -dx0); e.r02y = fmaf(e.t02, f.e02y, -dy0);
-    e.r12x = fmaf(e.t12, f.e12x, -dx1); e.r12y = fmaf(e.t12, f.e12y, -dy1);
-    e.d01 = e.r01x * e.r01x + e.r01y * e.r01y;
-    e.d02 = e.r02x * e.r02x + e.r02y * e.r02y;
-    e.d12 = e.r12x * e.r12x + e.r12y * e.r12y;
-    const float dist = fminf(fminf(e.d01, e.d02), e.d12);
+    const float t01 = __builtin_amdgcn_fmed3f((f.e01x * dx0 + f.e01y * dy0) * f.rl01, 0.f, 1.f);
+    const float t02 = __builtin_amdgcn_fmed3f((f.e02x * dx0 + f.e02y * dy0) * f.rl02, 0.f, 1.f);
+    const float t12 = __builtin_amdgcn_fmed3f((f.e12x * dx1 + f.e12y * dy1) * f.rl12, 0.f, 1.f);
+    const float r01x = fmaf(t01, f.e01x, -dx0), r01y = fmaf(t01, f.e01y, -dy0);
+    const float r02x = fmaf(t02, f.e02x, -dx0), r02y = fmaf(t02, f.e02y, -dy0);
+    const float r12x = fmaf(t12, f.e12x, -dx1), r12y = fmaf(t12, f.e12y, -dy1);
+    const float d01 = sq2(r01x, r01y), d02 = sq2(r02x, r02y), d12 = sq2(r12x, r12y);
+    const float dist = fminf(fminf(d01, d02), d12);
     e.cand = in_bb && (e.inside || dist < blur);
     e.sd = e.inside ? -dist : dist;
+    const bool c01 = (d01 <= d02) && (d01 <= d12);
+    const bool c02 = !c01 && (d02 <= d01) && (d02 <= d12);
+    e.edge = c01 ? 0 : (c02 ? 1 : 2);
+    e.t = c01 ? t01 : (c02 ? t02 : t12);
+    e.rx = c01 ? r01x : (c02 ? r02x : r12x);
+    e.ry = c01 ? r01y : (c02 ? r02y : r12y);
 }
 
 // depth at the clipped, renormalised perspective-correct barycentrics:
@@ -223,6 +240,11 @@ struct alignas(16) TileLds {
     float rec[FCHUNK * FREC];
     float gacc[FCHUNK * 6];  // per staged face: d/d(x0,y0,x1,y1,x2,y2), pass 3
     uint32_t list[LIST_CAP];
+    // stream form of pass 3: per-pixel state (gathered by the lane that owns a record) and, per 64-face chunk of the
+    // list, the index of its first record
+    float pcoef[WAVE], pzt[WAVE];
+    int ptie[WAVE];
+    uint32_t cfirst[LIST_CAP / FCHUNK + 1];
 };
 
 // Build the ordered list of faces of [seg0, seg1) whose tile box contains (tx,ty). Returns the count.
@@ -346,6 +368,26 @@ __device__ __forceinline__ void depth_sort_list(const float *__restrict__ fz_n, 
         }                                                                                      \
     }
 
+// Pass 3 (stream form): add the LDS accumulators of list chunk `chunk` to the vertex gradients, one global atomic per
+// touched vertex component.  Lane = face of the chunk.
+__device__ __forceinline__ void flush_gacc(const RasterArgs &a, TileLds &lds, float *dn, int chunk, int list_total,
+                                           uint32_t id_mask, int lane) {
+    __syncthreads();
+    const int c0 = chunk * FCHUNK;
+    if (c0 + lane < list_total) {
+        const int f = (int)(lds.list[c0 + lane] & id_mask);
+        const float *acc = lds.gacc + lane * 6;
+        const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
+        if (acc[0] != 0.f) atomicAdd(&dn[2 * i0], acc[0]);
+        if (acc[1] != 0.f) atomicAdd(&dn[2 * i0 + 1], acc[1]);
+        if (acc[2] != 0.f) atomicAdd(&dn[2 * i1], acc[2]);
+        if (acc[3] != 0.f) atomicAdd(&dn[2 * i1 + 1], acc[3]);
+        if (acc[4] != 0.f) atomicAdd(&dn[2 * i2], acc[4]);
+        if (acc[5] != 0.f) atomicAdd(&dn[2 * i2 + 1], acc[5]);
+    }
+    __syncthreads();
+}
+
 // EXACT: K == KT is known at compile time (the common K = 100 case): the K-th smallest is simply the last slot.
 // Otherwise the slot is picked with a chain of selects, which costs ~KT scalar lane masks - kept off the hot path.
 template <int KT, bool EXACT>
@@ -358,15 +400,31 @@ __device__ __forceinline__ float kth_smallest(const float (&r)[KT], int K) {
     return v;
 }
 
-// KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD
-template <int MODE, int KT, bool EXACT>
+// KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD.
+// STREAM: pass 1 appends, for every (face, pixel) pair it accepts, a 16-byte record {depth, rx, ry, t|code} to a
+// per-workgroup stream in global memory (ballot-compacted: one contiguous store per face, plus a 16-byte header
+// {pixel mask, list position, first record}); passes 2 and 3 then walk that stream instead of re-evaluating every
+// face against every pixel.  The region is reused for every tile the workgroup processes, so it lives in L2 / MALL.
+// A tile whose pairs do not fit (VAL_CAP) or whose list is not cached falls back to the re-evaluating passes.
+template <int MODE, int KT, bool EXACT, bool STREAM>
 __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
     __shared__ TileLds lds;
     const int lane = threadIdx.x;
+    uint4 *const shdr = STREAM ? a.shdr + (size_t)blockIdx.x * LIST_CAP : nullptr;
+    float4 *const sval = STREAM ? a.sval + (size_t)blockIdx.x * VAL_CAP : nullptr;
+    uint32_t *const smeta = STREAM ? a.smeta + (size_t)blockIdx.x * VAL_CAP : nullptr;
+    const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = EXACT ? KT : a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
     const unsigned int n_items = a.ctr->n_items;
 
+#ifdef DBG_TIMERS
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
+#else
+#define TMARK(k)
+#endif
     while (true) {
         unsigned int item = 0;
         if (lane == 0) item = atomicAdd(&a.ctr->next, 1u);
@@ -395,27 +453,53 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         if (sorted) depth_sort_list(a.fzmin + (size_t)n * a.F, lds.list, list_total, lane, zlo, zstep);
         const uint32_t id_mask = sorted ? 0xFFFFu : 0xFFFFFFFFu;
 
+        TMARK(0)
         // ---------------- pass 1: count, product of all, K smallest depths (sorted, in registers) ---------
         int cnt = 0;
         float prod_all = 1.0f;
+        int n_emit = 0, vbase = 0;            // headers / records written so far (wave-uniform)
+        bool stream_ok = STREAM && list_cached;
         float r[KT];
 #pragma unroll
         for (int i = 0; i < KT; ++i) r[i] = 3.0e38f;
         // a pixel is settled once it holds K depths and its K-th smallest is not beyond the next face; the pass may
         // stop when every pixel of the tile is settled (pixels with fewer than K candidates never are)
+        int n_chunks = 0;  // 64-face chunks pass 1 visited (it may stop early on a depth-sorted list)
         CHUNK_LOOP_BEGIN(false, wave_max(!in_img ? -3.0e38f : (cnt < K ? 3.0e38f : kth_smallest<KT, EXACT>(r, K))))
         {
+            if (STREAM && stream_ok) {
+                if (lane == 0) lds.cfirst[c0 >> 6] = (uint32_t)vbase;
+                n_chunks = (c0 >> 6) + 1;
+            }
             for (int i = 0; i < m; ++i) {
                 const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
                 if (__ballot(!(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
                 PairEval e;
                 eval_pair(f, px, py, dxp, dyp, a.blur, e);
-                if (__ballot(e.cand) == 0ull) continue;
+                const unsigned long long cm = __ballot(e.cand);
+                if (cm == 0ull) continue;
                 const float fac = 1.0f - face_prob(e.sd, a.inv_sigma);
                 prod_all *= e.cand ? fac : 1.0f;
                 cnt += e.cand ? 1 : 0;
+                const float z = (may_truncate && e.cand) ? pair_depth(f, e) : 3.0e38f;
+                if (STREAM && stream_ok) {
+                    const int nc = __popcll(cm);
+                    if (vbase + nc > VAL_CAP) {
+                        stream_ok = false;  // wave-uniform: this tile re-evaluates in passes 2 and 3
+                    } else {
+                        // 3 code bits (inside, edge) replace the low mantissa bits of t in [0,1] (<= 4e-7 relative)
+                        const uint32_t tb = (__float_as_uint(e.t) & ~7u) | (e.inside ? 1u : 0u) | ((uint32_t)e.edge << 1);
+                        const int slot = vbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                        if (e.cand) {
+                            sval[slot] = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
+                            smeta[slot] = (uint32_t)lane | ((uint32_t)(c0 + i) << 6);
+                        }
+                        if (lane == 0) shdr[n_emit] = make_uint4((uint32_t)cm, (uint32_t)(cm >> 32), (uint32_t)(c0 + i), (uint32_t)vbase);
+                        ++n_emit;
+                        vbase += nc;
+                    }
+                }
                 if (!may_truncate) continue;
-                const float z = e.cand ? pair_depth(f, e) : 3.0e38f;
                 if (__ballot(z < r[KT - 1]) == 0ull) continue;  // nobody's K-nearest set changes
                 // sorted insert, dropping the largest: r'[i] = med3(r[i-1], r[i], z); r'[0] = min(r[0], z)
 #pragma unroll
@@ -424,12 +508,15 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             }
         }
         CHUNK_LOOP_END
+        if (STREAM && stream_ok && lane == 0) lds.cfirst[n_chunks] = (uint32_t)vbase;
+        TMARK(1)
         // cnt may have stopped early at >= K: then "all candidates" and "the K nearest" only coincide when cnt == K,
         // and pass 2 computes the right product in both cases
         const bool trunc = sorted ? (cnt >= K) : (cnt > K);
         float alpha = prod_all;
         float zt = 3.0e38f;  // depth threshold (K-th smallest)
         int r_ties = 0;
+        int tie_cut = -1;    // list position of the last face kept among those exactly at the threshold (stream form)
         if (__ballot(trunc) != 0ull) {
             zt = kth_smallest<KT, EXACT>(r, K);
 #pragma unroll
@@ -440,6 +527,49 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             // faces whose nearest vertex is beyond every unfinished truncated pixel's threshold cannot be among its K
             // nearest.  A pixel is finished once its product is below ALPHA_GRAD_EPS: 1 - alpha already rounds to 1.0f
             // and the pixel is below the gradient threshold, so no output can change any more.
+            if (STREAM && stream_ok) {
+                __syncthreads();  // the records were written by other lanes of this workgroup
+                uint4 hn = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < n_emit) hn = shdr[lane];
+                for (int e0 = 0; e0 < n_emit; e0 += WAVE) {
+                    const bool live = trunc && prod > ALPHA_GRAD_EPS;
+                    if (__ballot(live) == 0ull) break;
+                    const int mm = min(WAVE, n_emit - e0);
+                    const uint4 h = hn;  // headers of this batch; the next batch is requested right away
+                    hn = make_uint4(0u, 0u, 0u, 0u);
+                    if (e0 + WAVE + lane < n_emit) hn = shdr[e0 + WAVE + lane];
+                    if (sorted) {
+                        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.z);
+                        const float zlb = zlo + (float)(lds.list[p0] >> 16) * zstep;
+                        if (zlb >= nextafterf(wave_max(live ? zt : -3.0e38f), 3.0e38f)) break;
+                    }
+                    // SGROUP records are requested before the first is consumed (the stream lives in L2 / MALL: hundreds
+                    // of ns per access, and only two waves per SIMD to hide it).  Lanes >= mm hold all-zero headers.
+                    for (int j0 = 0; j0 < mm; j0 += SGROUP) {
+                        float4 v[SGROUP];
+                        bool mine[SGROUP];
+#pragma unroll
+                        for (int u = 0; u < SGROUP; ++u) {
+                            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)h.x, j0 + u), mhi = (uint32_t)__builtin_amdgcn_readlane((int)h.y, j0 + u);
+                            const int first = __builtin_amdgcn_readlane((int)h.w, j0 + u);
+                            mine[u] = ((mlo & lane_lo) | (mhi & lane_hi)) != 0u;
+                            v[u] = sval[first + (mine[u] ? (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) : 0)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < SGROUP; ++u) {
+                            const bool c = mine[u] && trunc;
+                            const bool tie = c && (v[u].x == zt) && (ties < r_ties);
+                            const bool keep = c && ((v[u].x < zt) || tie);
+                            ties += tie ? 1 : 0;
+                            tie_cut = tie ? __builtin_amdgcn_readlane((int)h.z, j0 + u) : tie_cut;
+                            const float dist = sq2(v[u].y, v[u].z);
+                            const float sd = (__float_as_uint(v[u].w) & 1u) ? -dist : dist;
+                            const float fac = 1.0f - face_prob(sd, a.inv_sigma);
+                            prod *= keep ? fac : 1.0f;
+                        }
+                    }
+                }
+            } else
             CHUNK_LOOP_BEGIN(false, nextafterf(wave_max((trunc && prod > ALPHA_GRAD_EPS) ? zt : -3.0e38f), 3.0e38f))
             {
                 if (__ballot(trunc && prod > ALPHA_GRAD_EPS) != 0ull) {
@@ -462,6 +592,7 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             if (trunc) alpha = prod;
         }
 
+        TMARK(2)
         // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
         const float silv = 1.0f - alpha;
         float g = 0.f;
@@ -483,6 +614,7 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         }
         if (MODE == MODE_FWD) continue;
 
+        TMARK(3)
         // ---------------- pass 3: gradients ------------------------------------------------------
         // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
         const float coef = -g * alpha * a.inv_sigma;
@@ -492,6 +624,57 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         const bool any_trunc = __ballot(trunc && active) != 0ull;
         int ties = 0;
         const float cut3 = wave_max(active ? (trunc ? zt : 3.0e38f) : -3.0e38f);
+        if (STREAM && stream_ok) {
+            // Dense walk: lane = record, not pixel.  Every lane fetches the state of the pixel its record belongs to from
+            // LDS; a record at the threshold depth is kept iff its face comes no later than the pixel's last kept tie.
+            lds.pcoef[lane] = active ? coef : 0.f;
+            lds.pzt[lane] = trunc ? zt : __builtin_inff();
+            lds.ptie[lane] = tie_cut;
+            __syncthreads();  // also orders pass 1's record stores before the loads below
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                const int c0 = ch * FCHUNK;
+                if (sorted && zlo + (float)(lds.list[c0] >> 16) * zstep >= nextafterf(cut3, 3.0e38f)) break;
+                const int i_beg = (int)lds.cfirst[ch], i_end = (int)lds.cfirst[ch + 1];
+                if (i_beg == i_end) continue;
+                for (int i_ = lane; i_ < FCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.f;
+                __syncthreads();
+                for (int g0 = i_beg; g0 < i_end; g0 += DGROUP * WAVE) {
+                    float4 v[DGROUP];
+                    uint32_t mt[DGROUP];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const int idx = min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
+                        v[u] = sval[idx];
+                        mt[u] = smeta[idx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const bool valid = g0 + u * WAVE + lane < i_end;
+                        const int pxl = (int)(mt[u] & 63u), pos = (int)(mt[u] >> 6);
+                        const float pc = lds.pcoef[pxl], pz = lds.pzt[pxl];
+                        const int pt = lds.ptie[pxl];
+                        const uint32_t tb = __float_as_uint(v[u].w);
+                        const bool inside = (tb & 1u) != 0u;
+                        const float dist = sq2(v[u].y, v[u].z);
+                        float gd = pc * face_prob(inside ? -dist : dist, a.inv_sigma);
+                        gd = inside ? -gd : gd;
+                        const bool keep = valid && (gd != 0.f) && ((v[u].x < pz) || (v[u].x == pz && pos <= pt));
+                        const float t = __uint_as_float(tb & ~7u);
+                        const int edge = (int)((tb >> 1) & 3u);
+                        const int ia = edge == 2 ? 2 : 0, ib = edge == 0 ? 2 : 4;
+                        const float ex = 2.0f * v[u].y * gd, ey = 2.0f * v[u].z * gd;
+                        if (keep) {
+                            float *acc = lds.gacc + (pos & 63) * 6;
+                            atomicAdd(acc + ia, (1.0f - t) * ex);
+                            atomicAdd(acc + ia + 1, (1.0f - t) * ey);
+                            atomicAdd(acc + ib, t * ex);
+                            atomicAdd(acc + ib + 1, t * ey);
+                        }
+                    }
+                }
+                flush_gacc(a, lds, dn, ch, list_total, id_mask, lane);
+            }
+        } else
         CHUNK_LOOP_BEGIN(true, nextafterf(cut3, 3.0e38f))
         {
             for (int i = 0; i < m; ++i) {
@@ -511,13 +694,9 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
                 gd = e.inside ? -gd : gd;                          // d L / d (unsigned squared distance)
                 keep = keep && (gd != 0.f);
                 if (__ballot(keep) == 0ull) continue;
-                // closest edge in the reference's order e01, e02, e12 with <= ties; t is a constant in its backward
-                const bool c01 = (e.d01 <= e.d02) && (e.d01 <= e.d12);
-                const bool c02 = !c01 && (e.d02 <= e.d01) && (e.d02 <= e.d12);
-                const float t = c01 ? e.t01 : (c02 ? e.t02 : e.t12);
-                const float rx = c01 ? e.r01x : (c02 ? e.r02x : e.r12x), ry = c01 ? e.r01y : (c02 ? e.r02y : e.r12y);
-                const int ia = (c01 || c02) ? 0 : 2, ib = c01 ? 2 : 4;  // accumulator slots of the edge's end points
-                const float ex = 2.0f * rx * gd, ey = 2.0f * ry * gd;
+                const float t = e.t;
+                const int ia = e.edge == 2 ? 2 : 0, ib = e.edge == 0 ? 2 : 4;  // accumulator slots of the edge's end points
+                const float ex = 2.0f * e.rx * gd, ey = 2.0f * e.ry * gd;
                 if (keep) {
                     float *acc = lds.gacc + i * 6;
                     atomicAdd(acc + ia, (1.0f - t) * ex);
@@ -540,7 +719,12 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
             }
         }
         CHUNK_LOOP_END
+        TMARK(4)
     }
+#ifdef DBG_TIMERS
+    if (a.dbg && lane == 0)
+        for (int k = 0; k < 5; ++k) atomicAdd(&a.dbg[k], tph[k]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,10 +732,22 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
 // ---------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+static int tile_grid(int N, int tiles_x) {
+    const long long max_items = (long long)N * tiles_x * tiles_x;
+    const long long resident = 256LL * 8;  // 256 CUs x 8 single-wave workgroups (2 waves per SIMD)
+    return (int)(max_items < resident ? max_items : resident);
+}
+
+// per resident workgroup: LIST_CAP stream headers + VAL_CAP pair records
+static inline size_t stream_bytes(int grid) {
+    return (size_t)grid * ((size_t)LIST_CAP * sizeof(uint4) + (size_t)VAL_CAP * (sizeof(float4) + sizeof(uint32_t)));
+}
+
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    return 2 * align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t));
+    return 2 * align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) +
+           256 + stream_bytes(tile_grid(N, ceil_div(S, TILE)));
 }
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
@@ -579,6 +775,26 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.fzmin = fzmin; a.items = items; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
+    {
+        char *sp = (char *)fzmin + align256((size_t)N * m->F * sizeof(float));
+        const int grid = tile_grid(N, tiles_x);
+        a.shdr = (uint4 *)sp;
+        a.sval = (float4 *)(sp + (size_t)grid * LIST_CAP * sizeof(uint4));
+        a.smeta = (uint32_t *)((char *)a.sval + (size_t)grid * VAL_CAP * sizeof(float4));
+    }
+    a.dbg = nullptr;
+#ifdef DBG_TIMERS
+    {
+        static unsigned long long *dbg_dev = nullptr;
+        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 64); (void)hipMemset(dbg_dev, 0, 64); }
+        unsigned long long h[8];
+        (void)hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost);  // totals of the launches so far
+        fprintf(stderr, "[dbg timers] setup+list %.3e  p1 %.3e  p2 %.3e  epi %.3e  p3 %.3e cycles\n", (double)h[0], (double)h[1],
+                (double)h[2], (double)h[3], (double)h[4]);
+        (void)hipMemset(dbg_dev, 0, 64);
+        a.dbg = dbg_dev;
+    }
+#endif
     a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.target_u8 = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr;
     a.d_ndc = nullptr;
     return SMIL_OK;
@@ -627,18 +843,13 @@ extern "C" int smil_profile_read(float *total_ms, int32_t *launches) {
 #define PROF_END(stream) \
     if (_slot >= 0) (void)hipEventRecord(g_prof_ev[_slot][1], stream)
 
-static int tile_grid(int N, int tiles_x) {
-    const long long max_items = (long long)N * tiles_x * tiles_x;
-    const long long resident = 256LL * 8;  // 256 CUs x 8 single-wave workgroups (2 waves per SIMD)
-    return (int)(max_items < resident ? max_items : resident);
-}
-
 template <int MODE>
 static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
     const dim3 grid(tile_grid(N, a.tiles_x)), block(64);
-    if (a.K == 100) hipLaunchKernelGGL((k_raster_tiles<MODE, 100, true>), grid, block, 0, stream, a);  // the reference's K
-    else if (a.K <= 16) hipLaunchKernelGGL((k_raster_tiles<MODE, 16, false>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_raster_tiles<MODE, SMIL_MAX_FACES_PER_PIXEL, false>), grid, block, 0, stream, a);
+    constexpr bool ST = MODE != MODE_FWD;  // backward passes read pass 1's pair stream instead of re-evaluating
+    if (a.K == 100) hipLaunchKernelGGL((k_raster_tiles<MODE, 100, true, ST>), grid, block, 0, stream, a);  // the reference's K
+    else if (a.K <= 16) hipLaunchKernelGGL((k_raster_tiles<MODE, 16, false, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_raster_tiles<MODE, SMIL_MAX_FACES_PER_PIXEL, false, false>), grid, block, 0, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

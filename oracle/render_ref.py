@@ -53,6 +53,22 @@ def _lib():
     return _LIB
 
 
+class select_mode:
+    """Context manager: which K faces survive truncation.  0 (default) = the reference's sequential queue (faithful);
+    1 = the K smallest by (depth, face id), the order-independent rule the HIP rasteriser implements."""
+
+    def __init__(self, mode: int):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        _lib().oracle_set_select_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib().oracle_set_select_mode(0)
+        return False
+
+
 def num_threads() -> int:
     return int(_lib().oracle_num_threads())
 

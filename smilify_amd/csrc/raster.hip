@@ -7,40 +7,61 @@
 // pytorch3d 0.7.x (un-vendored): CheckPixelInsideFace / RasterizeMeshesBackward / geometry_utils.
 //
 // Design (see DESIGN.md "raster"):
-//  * The reference visits all F faces for all S^2 pixels and stores (S,S,K) fragments in HBM
-//    (157 MB / image at 256^2).  Here nothing per-fragment ever reaches HBM.
-//  * k_raster_setup (one workgroup per image): per-face validity + blurred bbox in 8x8-pixel tile
-//    units (4 x u8 packed), a tile-occupancy bitmap in LDS, and the compacted list of touched tiles
-//    appended to a global work list.  Untouched tiles are never visited (their silhouette is 0).
-//  * k_raster_tiles (persistent, one 64-lane wavefront = one 8x8 tile, lane = pixel): dequeues work
-//    items, compacts the face ids whose bbox meets the tile (ballot prefix -> order preserved), stages
-//    their vertices through LDS in chunks of 64 and streams them to all 64 pixels (LDS broadcast reads).
-//      pass 1: candidate count, product of all candidates and the K smallest depths of every pixel kept
-//              SORTED IN REGISTERS: inserting z is r[i] = med3(r[i-1], r[i], z) for all i - one
-//              v_med3_f32 per slot, branch-free, no LDS (an LDS heap capped occupancy at 1 wave/SIMD and
-//              its sift loops were dependent-LDS-latency chains).  Pixels with <= K candidates are done.
-//      pass 2: (only if some pixel has > K candidates) product over the K nearest: depth < t, plus the
-//              first r faces (ascending face id) with depth == t, t = K-th smallest depth.
-//      pass 3: (backward / fused) per-pair gradient added to per-face LDS accumulators (ds_add_f32),
-//              flushed once per 64-face chunk with one global atomic per touched vertex component.
-//  * Tile lists that can truncate are sorted front to back (16-bit quantised nearest-vertex depth | face id, bitonic
-//    sort in LDS), so every pass stops at the first 64-face chunk that lies wholly beyond what any pixel still needs.
-//  * Deviation from the reference kept on purpose: ties at the K-th depth are resolved by visiting order (depth
-//    bucket, then face id); the reference's unsorted-queue eviction depends on visiting history (measured effect on
-//    the L1 loss: ~1e-5 relative; tests/test_gpu_kernels.py::test_silhouette_forward).
+//  * The reference visits all F faces for all S^2 pixels and stores (S,S,K) fragments in HBM (157 MB / image at 256^2).
+//  * k_raster_setup (one workgroup per image): per-face validity + blurred bbox in 8x8-pixel tile units (4 x u8 packed),
+//    a tile-occupancy bitmap in LDS, and the compacted list of touched tiles appended to a global work list.  Untouched
+//    tiles are never visited (their silhouette is 0).
+//  * k_raster_dense (persistent single-wave workgroups, work item = one 8x8 tile).  Every (face, pixel) pair is
+//    evaluated ONCE, by a lane that exists only for pairs inside the face's pixel box; every later step is a dense sweep
+//    (lane = record) over the records that pass produced.  An earlier design (lane = pixel, each face broadcast to the 64
+//    pixels of the tile, three re-evaluating passes, K smallest depths in a sorted register array) spent ~75 % of its
+//    lanes on pairs that do not exist and 100 v_med3 per face on the selection; it is gone.
+//      pass 1  lane = pair.  Per DCHUNK-face chunk: lane = face computes its pixel box inside the tile, a prefix sum lays
+//              the boxes end to end, and the wave sweeps that pair list 64 at a time (face found with a scatter + max-scan,
+//              face record and pixel coordinates gathered from LDS).  Accepted pairs are ballot-compacted into the
+//              workgroup's record stream {depth, rx, ry, t|code}, {pixel | list position << 6}, {depth bits} in global
+//              memory (reused for every tile, so it lives in L2 / MALL).  The first radix digit of every depth is
+//              histogrammed on the way (the tile's depth range is known from the face list).
+//      select  (only if the tile lists more than K faces) K-th smallest depth of every pixel by radix select on the depth
+//              bits, SEL_BITS per sweep, per-pixel histograms in LDS.  After the first digit the records that can still
+//              matter are compacted, so the remaining sweeps touch a few rows.  Exact, including the number of faces tied
+//              at the threshold; when a tie group straddles K, further sweeps select on the list position (= face id).
+//      pass 2  log2 of every kept factor added to its pixel's LDS accumulator; alpha = exp2(sum) (the fp32 product and the
+//              fp64-accumulated log-sum are both ~1e-6 relative from the exact product).
+//      pass 3  gradient of every kept record into per-face LDS accumulators, flushed per chunk.
+//    LDS accumulators are fp64: ds_add_f64 runs at full rate on gfx950 while ds_add_f32 costs ~3 cycles per active lane.
+//  * A tile whose records would not fit the stream (REC_CAP) is processed in sub-tiles: power-of-two runs of its 64 pixels,
+//    halved until pass 1 fits.  A single pixel always fits because F <= REC_CAP is required on the host.
+//  * Deviation from the reference kept on purpose: the K faces a truncated pixel keeps are the K smallest by (depth, face
+//    id).  The reference's unsorted-queue eviction picks among equal depths by visiting history (measured effect on the
+//    L1 loss: ~1e-5 relative at K = 100; tests/test_gpu_kernels.py checks this rule exactly against the oracle's
+//    select_mode(1) and the faithful queue within the documented tolerance).
 #include "common.h"
 
 #define TILE 8
-#define LIST_CAP 2048       // face ids per list segment (LDS)
-#define FCHUNK 64           // faces staged per chunk
+#define DCHUNK 32           // faces staged per chunk
 #define FREC 32             // floats per staged face record
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
-#define DGROUP 4            // 64-record rows in flight in the dense pass 3
-#define SGROUP 8            // stream records in flight per lane in passes 2 and 3
-#define VAL_CAP 65536       // pair records (16 B) a workgroup can carry from pass 1 to passes 2 and 3
+#define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
+#define DGROUP 4            // 64-record rows per buffer in the dense walks (two buffers)
+#define KGROUP 8            // 64-key rows per buffer in the selection sweeps (two buffers)
+#define REC_CAP 65536       // pair records one (sub-)tile may produce
+#define REC_PAD 64          // slack so that a clamped read stays inside the allocation
+#define RESIDENT_PER_CU 12  // single-wave workgroups per CU (3 waves per SIMD: 168 VGPRs, 13 KB LDS)
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
+
+// -DDBG_TIMERS: per-phase cycle sums of the tile kernel (printed by the next launch); off in normal builds
+#ifdef DBG_TIMERS
+#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter();
+#define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
+#define TIMERS_FLUSH if (a.dbg && lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.dbg[k_], tph[k_]);
+#else
+#define TIMERS_INIT
+#define TMARK(k)
+#define TIMERS_FLUSH
+#endif
 
 struct RasterCounters {
     unsigned int n_items;
@@ -51,7 +72,6 @@ struct RasterArgs {
     const float *verts_ndc;  // (N,V,3)
     const int *faces;        // (F,3)
     const uint32_t *tbox;    // (N,F)
-    const float *fzmin;      // (N,F) nearest vertex depth of every face
     const uint32_t *items;   // work list
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
@@ -64,10 +84,14 @@ struct RasterArgs {
     const float *pix_scale;  // FUSED (N,)
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
-    // pair stream (STREAM kernels): per resident workgroup LIST_CAP headers + VAL_CAP records
-    uint4 *shdr;
-    float4 *sval;
-    uint32_t *smeta;         // per record: pixel (lane) | list position << 6
+    // scratch per resident workgroup
+    uint32_t *slist;         // F face ids of the current tile
+    uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
+    float4 *sval;            // REC_CAP + REC_PAD records {depth, rx, ry, t | code}
+    uint32_t *smeta;         // pixel | list position << 6
+    uint32_t *skey;          // depth bits (the selection sweeps read 8 instead of 20 bytes per record)
+    uint32_t *scmeta;        // meta of the records that survive the first selection digit (keys are compacted in place)
+    int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
 };
 
@@ -81,8 +105,7 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
-                                                      uint32_t *__restrict__ tbox, float *__restrict__ fzmin,
-                                                      uint32_t *__restrict__ items,
+                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ items,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x,
                                                       float sqrt_blur) {
     extern __shared__ uint32_t bitmap[];  // tiles_x*tiles_x bits, then 256 scan slots
@@ -125,7 +148,6 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
             }
         }
         tbox[(size_t)n * F + f] = box;
-        fzmin[(size_t)n * F + f] = zmin;
     }
     __syncthreads();
     // ordered compaction of touched tiles -> global work list
@@ -154,9 +176,9 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // per-(pixel, face) evaluation
 // ---------------------------------------------------------------------------------------------
-// Face record staged in LDS (32 floats = 8 x 16 B, read with ds_read_b128 broadcasts).  Everything that does
-// not depend on the pixel is folded in once per (tile, face): coordinates are relative to the tile centre
-// (cx, cy) so the affine forms below do not cancel catastrophically.
+// Face record staged in LDS (32 floats = 8 x 16 B).  Everything that does not depend on the pixel is folded in once
+// per (tile, face): coordinates are relative to the tile centre (cx, cy) so the affine forms below do not cancel
+// catastrophically.
 //   w_i(p) = A_i dx + B_i dy + C_i  = b_i(p) * z_j z_k   (perspective-correct barycentric numerators; the
 //            common denominator is positive, so inside <=> all w_i > 0)
 struct alignas(16) FaceRec {
@@ -236,46 +258,77 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
 // ---------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------
-struct alignas(16) TileLds {
-    float rec[FCHUNK * FREC];
-    float gacc[FCHUNK * 6];  // per staged face: d/d(x0,y0,x1,y1,x2,y2), pass 3
-    uint32_t list[LIST_CAP];
-    // stream form of pass 3: per-pixel state (gathered by the lane that owns a record) and, per 64-face chunk of the
-    // list, the index of its first record
-    float pcoef[WAVE], pzt[WAVE];
-    int ptie[WAVE];
-    uint32_t cfirst[LIST_CAP / FCHUNK + 1];
+struct alignas(16) DenseLds {
+    union {
+        float rec[DCHUNK * FREC];                   // pass 1: staged face records
+        uint32_t hist2[(1 << SEL_BITS) / 2 * WAVE];  // select, later digits: [bucket / 2][pixel], two 16-bit counts per word
+    };
+    uint32_t hist1[(1 << SEL_BITS) / 2 * WAVE];      // select, first digit: filled by pass 1
+    double gacc[DCHUNK * 6];         // fp64: ds_add_f64 runs at full rate on gfx950, ds_add_f32 at ~3 cycles per lane
+    double plog[WAVE];               // pass 2: sum of log2(1 - p_k)
+    float4 pixt[WAVE];               // px, py, px - cx, py - cy
+    float4 pgrad[WAVE];              // passes 2/3: {gradient coefficient, threshold depth bits, last kept list position, -}
+    uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
+    int start[WAVE];                 // pair -> face mapping scratch
 };
 
-// Build the ordered list of faces of [seg0, seg1) whose tile box contains (tx,ty). Returns the count.
-__device__ __forceinline__ int build_list(const uint32_t *__restrict__ tbox_n, int seg0, int seg1, int tx, int ty,
-                                          uint32_t *list, int lane, int cap = LIST_CAP) {
+// inclusive wave64 scans in DPP (row_shr within 16-lane rows, then row_bcast across rows)
+template <bool IS_MAX>
+__device__ __forceinline__ int wave_scan(int x) {
+#define SCAN_STEP(ctrl, rows) { const int t_ = __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); x = IS_MAX ? max(x, t_) : x + t_; }
+    SCAN_STEP(0x111, 0xF) SCAN_STEP(0x112, 0xF) SCAN_STEP(0x114, 0xF) SCAN_STEP(0x118, 0xF)
+    SCAN_STEP(0x142, 0xA) SCAN_STEP(0x143, 0xC)
+#undef SCAN_STEP
+    return x;  // IS_MAX assumes non-negative inputs (identity 0)
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, WAVE));
+    return v;
+}
+
+// Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the
+// nearest / farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's
+// vertex depths), which fixes the radix-select digits before pass 1 starts.
+__device__ __forceinline__ int build_list(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *__restrict__ tbox_n,
+                                          int tx, int ty, uint32_t *list, int lane, uint32_t &kmin, uint32_t &kmax) {
     int cnt = 0;
-    for (int base = seg0; base < seg1; base += 4 * WAVE) {
-        // four independent loads in flight per lane
-        uint32_t b[4];
+    float zlo = 3.0e38f, zhi = 0.f;
+    for (int base = 0; base < a.F; base += 4 * WAVE) {
+        uint32_t b[4];  // four independent loads in flight per lane
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int f = base + u * WAVE + lane;
-            b[u] = f < seg1 ? tbox_n[f] : 0x0000FFFFu;
+            b[u] = f < a.F ? tbox_n[f] : 0x0000FFFFu;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int tx0 = b[u] & 0xFF, ty0 = (b[u] >> 8) & 0xFF, tx1 = (b[u] >> 16) & 0xFF, ty1 = b[u] >> 24;
             const bool hit = (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
             const unsigned long long mask = __ballot(hit);
-            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < cap) list[pos] = (uint32_t)(base + u * WAVE + lane);
+            if (hit) {
+                const int f = base + u * WAVE + lane;
+                list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)f;
+                const float z0 = vn[3 * a.faces[3 * f] + 2], z1 = vn[3 * a.faces[3 * f + 1] + 2], z2 = vn[3 * a.faces[3 * f + 2] + 2];
+                zlo = fminf(zlo, fminf(fminf(z0, z1), z2));
+                zhi = fmaxf(zhi, fmaxf(fmaxf(z0, z1), z2));
+            }
             cnt += __popcll(mask);
         }
     }
+    kmin = wave_min_u32(__float_as_uint(zlo));  // depths are positive: the bit patterns order like the values
+    kmax = wave_max_u32(__float_as_uint(zhi));
     return cnt;
 }
 
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list,
-                                            int c0, int m, float *rec, int lane, float cx, float cy, uint32_t id_mask) {
+                                            int c0, int m, float *rec, int lane, float cx, float cy) {
     if (lane < m) {
-        const int f = (int)(list[c0 + lane] & id_mask);
+        const int f = (int)list[c0 + lane];
         const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
         const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
         const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
@@ -302,129 +355,90 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
     }
 }
 
-// Sort the cached tile list front to back, in place.  Every entry becomes (16-bit quantised nearest-vertex depth
-// of the face << 16) | face id, and the u32 values are sorted with a bitonic network in LDS (ties: ascending face
-// id).  Needs F < 65536.  (lo, step) let a pass recover a LOWER BOUND of the depth of every remaining face from the
-// entry it is looking at: depth >= lo + (entry >> 16) * step, because a pair's depth is a convex combination of
-// the face's vertex depths.
-__device__ __forceinline__ void depth_sort_list(const float *__restrict__ fz_n, uint32_t *list, int n, int lane, float &zlo,
-                                                float &zstep) {
-    float mn = 3.0e38f, mx = 0.f;
-    for (int i = lane; i < n; i += WAVE) {
-        const float z = fz_n[list[i]];
-        mn = fminf(mn, z); mx = fmaxf(mx, z);
-    }
-    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
-    zlo = mn;
-    zstep = fmaxf((mx - mn) * (1.0f / 65535.0f), 1e-30f);
-    const float inv = 1.0f / zstep;
-    int np2 = 64;
-    while (np2 < n) np2 <<= 1;
-    for (int i = lane; i < np2; i += WAVE) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (i < n) {
-            const uint32_t f = list[i];
-            // floor minus one step of slack against rounding: lo + q*step must never exceed the true depth
-            int q = (int)((fz_n[f] - zlo) * inv) - 1;
-            q = min(max(q, 0), 65534);
-            key = ((uint32_t)q << 16) | f;
-        }
-        list[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < (np2 >> 1); t += WAVE) {
-                const int lo_i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo_i | j;
-                const uint32_t x = list[lo_i], y = list[hi_i];
-                const bool asc = (lo_i & k) == 0;
-                if ((x > y) == asc) { list[lo_i] = y; list[hi_i] = x; }
-            }
-            __syncthreads();
-        }
-}
-
-// Loop skeleton shared by the three passes: ordered face list per 1024-face segment, 64-face chunks staged in LDS.
-// When the whole tile list fits the LDS buffer it is built once (list_cached) and reused by every pass.
-// CUT_EXPR (evaluated once per chunk, wave-uniform float): when the list is depth sorted, every face from the chunk's
-// first entry on is at least `lo + q*step` deep; once that bound reaches CUT_EXPR nothing further can matter.
-#define CHUNK_LOOP_BEGIN(ZERO_GACC, CUT_EXPR)                                                  \
-    for (int seg0 = 0; seg0 < (list_cached ? 1 : a.F); seg0 += LIST_CAP) {                     \
-        const int seg1 = min(a.F, seg0 + LIST_CAP);                                            \
-        const int ln = list_cached ? list_total : build_list(tbox_n, seg0, seg1, tx, ty, lds.list, lane); \
-        __syncthreads();                                                                       \
-        for (int c0 = 0; c0 < ln; c0 += FCHUNK) {                                              \
-            if (sorted) {                                                                      \
-                const float zlb = zlo + (float)(lds.list[c0] >> 16) * zstep;                   \
-                if (zlb >= (CUT_EXPR)) break;                                                  \
-            }                                                                                  \
-            const int m = min(FCHUNK, ln - c0);                                                \
-            stage_faces(a, vn, lds.list, c0, m, lds.rec, lane, cx, cy, id_mask);               \
-            if (ZERO_GACC)                                                                     \
-                for (int i_ = lane; i_ < FCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.f;           \
-            __syncthreads();
-#define CHUNK_LOOP_END                                                                         \
-            __syncthreads();                                                                   \
-        }                                                                                      \
-    }
-
-// Pass 3 (stream form): add the LDS accumulators of list chunk `chunk` to the vertex gradients, one global atomic per
-// touched vertex component.  Lane = face of the chunk.
-__device__ __forceinline__ void flush_gacc(const RasterArgs &a, TileLds &lds, float *dn, int chunk, int list_total,
-                                           uint32_t id_mask, int lane) {
-    __syncthreads();
-    const int c0 = chunk * FCHUNK;
-    if (c0 + lane < list_total) {
-        const int f = (int)(lds.list[c0 + lane] & id_mask);
-        const float *acc = lds.gacc + lane * 6;
-        const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
-        if (acc[0] != 0.f) atomicAdd(&dn[2 * i0], acc[0]);
-        if (acc[1] != 0.f) atomicAdd(&dn[2 * i0 + 1], acc[1]);
-        if (acc[2] != 0.f) atomicAdd(&dn[2 * i1], acc[2]);
-        if (acc[3] != 0.f) atomicAdd(&dn[2 * i1 + 1], acc[3]);
-        if (acc[4] != 0.f) atomicAdd(&dn[2 * i2], acc[4]);
-        if (acc[5] != 0.f) atomicAdd(&dn[2 * i2 + 1], acc[5]);
-    }
-    __syncthreads();
-}
-
-// EXACT: K == KT is known at compile time (the common K = 100 case): the K-th smallest is simply the last slot.
-// Otherwise the slot is picked with a chain of selects, which costs ~KT scalar lane masks - kept off the hot path.
-template <int KT, bool EXACT>
-__device__ __forceinline__ float kth_smallest(const float (&r)[KT], int K) {
-    if (EXACT) return r[KT - 1];
-    float v = 3.0e38f;
+// lane = pixel: in the histogram `hist` ([bucket / 2][pixel]) find the digit that holds the `need`-th smallest key.
+// Returns the number of keys counted for this pixel; updates (pre, need) and reports the count of the chosen digit.
+__device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b, uint32_t &pre, int &need, int &n_eq) {
+    int cum = 0, sel = 0, cnt_sel = 0, all = 0;
+    bool found = false;
 #pragma unroll
-    for (int i = 0; i < KT; ++i)
-        if (i == K - 1) v = r[i];
-    return v;
+    for (int w_ = 0; w_ < (1 << SEL_BITS) / 2; ++w_) {
+        const uint32_t hw = hist[w_ * WAVE + lane];
+        const int h0 = (int)(hw & 0xFFFFu), h1 = (int)(hw >> 16);
+        all += h0 + h1;
+        if (!found && cum + h0 >= need) { sel = 2 * w_; cnt_sel = h0; found = true; }
+        cum += found ? 0 : h0;
+        if (!found && cum + h1 >= need) { sel = 2 * w_ + 1; cnt_sel = h1; found = true; }
+        cum += found ? 0 : h1;
+    }
+    if (need > 0 && found) {
+        pre = (pre << b) | (uint32_t)sel;
+        need -= cum;
+        n_eq = cnt_sel;
+    } else {
+        need = 0;  // fewer keys than the rank asked for: this pixel keeps everything
+        n_eq = 0;
+    }
+    return all;
 }
 
-// KT = number of register slots holding the smallest depths (>= K); 2 waves per SIMD.
-// STREAM: pass 1 appends, for every (face, pixel) pair it accepts, a 16-byte record {depth, rx, ry, t|code} to a
-// per-workgroup stream in global memory (ballot-compacted: one contiguous store per face, plus a 16-byte header
-// {pixel mask, list position, first record}); passes 2 and 3 then walk that stream instead of re-evaluating every
-// face against every pixel.  The region is reused for every tile the workgroup processes, so it lives in L2 / MALL.
-// A tile whose pairs do not fit (VAL_CAP) or whose list is not cached falls back to the re-evaluating passes.
-template <int MODE, int KT, bool EXACT, bool STREAM>
-__global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
-    __shared__ TileLds lds;
+// One radix-select sweep over `n_rec` (key, meta) pairs: among the keys of pixel p whose bits above `nbits` equal
+// psel[p].x, histogram the next `b` bits (psel[p].y == 0: pixel not taking part; key 0xFFFFFFFF: record not taking part).
+template <typename KeyFn>
+__device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__restrict__ meta, int n_rec, int nbits, int b,
+                                             int lane, uint32_t pre, int need, KeyFn key_of) {
+    const int shift = nbits - b;
+    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist2[i_] = 0u;
+    __syncthreads();
+    auto load_keys = [&](uint32_t (&kk)[KGROUP], uint32_t (&mt)[KGROUP], int g0) {
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const int idx = min(g0 + u * WAVE + lane, n_rec - 1);
+            mt[u] = meta[idx];
+            kk[u] = key_of(idx, mt[u]);
+        }
+    };
+    auto count_keys = [&](const uint32_t (&kk)[KGROUP], const uint32_t (&mt)[KGROUP], int g0) {
+        uint2 ps[KGROUP];  // all LDS gathers first: one latency, not one per row
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) ps[u] = lds.psel[mt[u] & 63u];
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t pxl = mt[u] & 63u;
+            const bool hit = (g0 + u * WAVE + lane < n_rec) & (ps[u].y > 0u) & ((kk[u] >> nbits) == ps[u].x) & (kk[u] != 0xFFFFFFFFu);
+            const uint32_t bucket = (kk[u] >> shift) & ((1u << b) - 1u);
+            if (hit) atomicAdd(&lds.hist2[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+        }
+    };
+    if (n_rec > 0) {  // double-buffered: the next KGROUP rows are in flight while this one is counted
+        uint32_t ka[KGROUP], ma[KGROUP], kb[KGROUP], mb[KGROUP];
+        load_keys(ka, ma, 0);
+        for (int g0 = 0; g0 < n_rec; g0 += 2 * KGROUP * WAVE) {
+            load_keys(kb, mb, g0 + KGROUP * WAVE);
+            count_keys(ka, ma, g0);
+            load_keys(ka, ma, g0 + 2 * KGROUP * WAVE);
+            count_keys(kb, mb, g0 + KGROUP * WAVE);
+        }
+    }
+    __syncthreads();
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
+    __shared__ DenseLds lds;
     const int lane = threadIdx.x;
-    uint4 *const shdr = STREAM ? a.shdr + (size_t)blockIdx.x * LIST_CAP : nullptr;
-    float4 *const sval = STREAM ? a.sval + (size_t)blockIdx.x * VAL_CAP : nullptr;
-    uint32_t *const smeta = STREAM ? a.smeta + (size_t)blockIdx.x * VAL_CAP : nullptr;
-    const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
-    const int K = EXACT ? KT : a.K;
+    uint32_t *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
+    uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
+    float4 *const sval = a.sval + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    uint32_t *const smeta = a.smeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    uint32_t *const skey = a.skey + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    uint32_t *const scmeta = a.scmeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
     const unsigned int n_items = a.ctr->n_items;
+    const float fS = (float)a.S;
 
-#ifdef DBG_TIMERS
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_readcyclecounter();
-#define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
-#else
-#define TMARK(k)
-#endif
+    TIMERS_INIT
     while (true) {
         unsigned int item = 0;
         if (lane == 0) item = atomicAdd(&a.ctr->next, 1u);
@@ -435,296 +449,348 @@ __global__ void __launch_bounds__(64, 2) k_raster_tiles(RasterArgs a) {
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
         const bool in_img = xo < a.S && yo < a.S;
-        // pixels outside the image get a position no bbox can contain
-        const float px = in_img ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
         const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
-        const float dxp = px - cx, dyp = py - cy;
         const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
-        const uint32_t *tbox_n = a.tbox + (size_t)n * a.F;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
-        const int list_total = build_list(tbox_n, 0, a.F, tx, ty, lds.list, lane);
-        const bool list_cached = list_total <= LIST_CAP;
-        const bool may_truncate = list_total > K;  // otherwise no pixel can see more than K faces
-        // depth ordering pays only where truncation can happen; it needs the whole list in LDS and 16-bit face ids
-        const bool sorted = list_cached && may_truncate && a.F < 65536 && list_total > FCHUNK;
-        float zlo = 0.f, zstep = 0.f;
-        __syncthreads();
-        if (sorted) depth_sort_list(a.fzmin + (size_t)n * a.F, lds.list, list_total, lane, zlo, zstep);
-        const uint32_t id_mask = sorted ? 0xFFFFu : 0xFFFFFFFFu;
-
+        uint32_t kmin, kmax;  // bounds of the depth keys of this tile
+        const int list_total = build_list(a, vn, a.tbox + (size_t)n * a.F, tx, ty, slist, lane, kmin, kmax);
+        const bool may_truncate = list_total > K;
+        const int n_chunks = (list_total + DCHUNK - 1) / DCHUNK;
+        // radix select: key bits below `nbits0` tell the tile's candidates apart, all keys share `pre0` above them
+        const uint32_t kdiff = kmin ^ kmax;
+        const int nbits0 = kdiff ? 32 - __clz(kdiff) : 0;  // depths > 0: <= 31
+        const uint32_t pre0 = kmax >> nbits0;
+        const int b1 = min(SEL_BITS, nbits0), shift1 = nbits0 - b1;
+        __syncthreads();  // the list stores are visible to the staging loads below
         TMARK(0)
-        // ---------------- pass 1: count, product of all, K smallest depths (sorted, in registers) ---------
-        int cnt = 0;
-        float prod_all = 1.0f;
-        int n_emit = 0, vbase = 0;            // headers / records written so far (wave-uniform)
-        bool stream_ok = STREAM && list_cached;
-        float r[KT];
-#pragma unroll
-        for (int i = 0; i < KT; ++i) r[i] = 3.0e38f;
-        // a pixel is settled once it holds K depths and its K-th smallest is not beyond the next face; the pass may
-        // stop when every pixel of the tile is settled (pixels with fewer than K candidates never are)
-        int n_chunks = 0;  // 64-face chunks pass 1 visited (it may stop early on a depth-sorted list)
-        CHUNK_LOOP_BEGIN(false, wave_max(!in_img ? -3.0e38f : (cnt < K ? 3.0e38f : kth_smallest<KT, EXACT>(r, K))))
-        {
-            if (STREAM && stream_ok) {
-                if (lane == 0) lds.cfirst[c0 >> 6] = (uint32_t)vbase;
-                n_chunks = (c0 >> 6) + 1;
-            }
-            for (int i = 0; i < m; ++i) {
-                const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                if (__ballot(!(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
-                PairEval e;
-                eval_pair(f, px, py, dxp, dyp, a.blur, e);
-                const unsigned long long cm = __ballot(e.cand);
-                if (cm == 0ull) continue;
-                const float fac = 1.0f - face_prob(e.sd, a.inv_sigma);
-                prod_all *= e.cand ? fac : 1.0f;
-                cnt += e.cand ? 1 : 0;
-                const float z = (may_truncate && e.cand) ? pair_depth(f, e) : 3.0e38f;
-                if (STREAM && stream_ok) {
-                    const int nc = __popcll(cm);
-                    if (vbase + nc > VAL_CAP) {
-                        stream_ok = false;  // wave-uniform: this tile re-evaluates in passes 2 and 3
-                    } else {
-                        // 3 code bits (inside, edge) replace the low mantissa bits of t in [0,1] (<= 4e-7 relative)
-                        const uint32_t tb = (__float_as_uint(e.t) & ~7u) | (e.inside ? 1u : 0u) | ((uint32_t)e.edge << 1);
-                        const int slot = vbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                        if (e.cand) {
-                            sval[slot] = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
-                            smeta[slot] = (uint32_t)lane | ((uint32_t)(c0 + i) << 6);
-                        }
-                        if (lane == 0) shdr[n_emit] = make_uint4((uint32_t)cm, (uint32_t)(cm >> 32), (uint32_t)(c0 + i), (uint32_t)vbase);
-                        ++n_emit;
-                        vbase += nc;
-                    }
-                }
-                if (!may_truncate) continue;
-                if (__ballot(z < r[KT - 1]) == 0ull) continue;  // nobody's K-nearest set changes
-                // sorted insert, dropping the largest: r'[i] = med3(r[i-1], r[i], z); r'[0] = min(r[0], z)
-#pragma unroll
-                for (int s_ = KT - 1; s_ >= 1; --s_) r[s_] = __builtin_amdgcn_fmed3f(r[s_ - 1], r[s_], z);
-                r[0] = fminf(r[0], z);
-            }
-        }
-        CHUNK_LOOP_END
-        if (STREAM && stream_ok && lane == 0) lds.cfirst[n_chunks] = (uint32_t)vbase;
-        TMARK(1)
-        // cnt may have stopped early at >= K: then "all candidates" and "the K nearest" only coincide when cnt == K,
-        // and pass 2 computes the right product in both cases
-        const bool trunc = sorted ? (cnt >= K) : (cnt > K);
-        float alpha = prod_all;
-        float zt = 3.0e38f;  // depth threshold (K-th smallest)
-        int r_ties = 0;
-        int tie_cut = -1;    // list position of the last face kept among those exactly at the threshold (stream form)
-        if (__ballot(trunc) != 0ull) {
-            zt = kth_smallest<KT, EXACT>(r, K);
-#pragma unroll
-            for (int i = 0; i < KT; ++i) r_ties += ((EXACT || i < K) && r[i] == zt) ? 1 : 0;
-            // ------------- pass 2: product over the K nearest for truncated pixels ---------------
-            float prod = 1.0f;
-            int ties = 0;
-            // faces whose nearest vertex is beyond every unfinished truncated pixel's threshold cannot be among its K
-            // nearest.  A pixel is finished once its product is below ALPHA_GRAD_EPS: 1 - alpha already rounds to 1.0f
-            // and the pixel is below the gradient threshold, so no output can change any more.
-            if (STREAM && stream_ok) {
-                __syncthreads();  // the records were written by other lanes of this workgroup
-                uint4 hn = make_uint4(0u, 0u, 0u, 0u);
-                if (lane < n_emit) hn = shdr[lane];
-                for (int e0 = 0; e0 < n_emit; e0 += WAVE) {
-                    const bool live = trunc && prod > ALPHA_GRAD_EPS;
-                    if (__ballot(live) == 0ull) break;
-                    const int mm = min(WAVE, n_emit - e0);
-                    const uint4 h = hn;  // headers of this batch; the next batch is requested right away
-                    hn = make_uint4(0u, 0u, 0u, 0u);
-                    if (e0 + WAVE + lane < n_emit) hn = shdr[e0 + WAVE + lane];
-                    if (sorted) {
-                        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.z);
-                        const float zlb = zlo + (float)(lds.list[p0] >> 16) * zstep;
-                        if (zlb >= nextafterf(wave_max(live ? zt : -3.0e38f), 3.0e38f)) break;
-                    }
-                    // SGROUP records are requested before the first is consumed (the stream lives in L2 / MALL: hundreds
-                    // of ns per access, and only two waves per SIMD to hide it).  Lanes >= mm hold all-zero headers.
-                    for (int j0 = 0; j0 < mm; j0 += SGROUP) {
-                        float4 v[SGROUP];
-                        bool mine[SGROUP];
-#pragma unroll
-                        for (int u = 0; u < SGROUP; ++u) {
-                            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)h.x, j0 + u), mhi = (uint32_t)__builtin_amdgcn_readlane((int)h.y, j0 + u);
-                            const int first = __builtin_amdgcn_readlane((int)h.w, j0 + u);
-                            mine[u] = ((mlo & lane_lo) | (mhi & lane_hi)) != 0u;
-                            v[u] = sval[first + (mine[u] ? (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) : 0)];
-                        }
-#pragma unroll
-                        for (int u = 0; u < SGROUP; ++u) {
-                            const bool c = mine[u] && trunc;
-                            const bool tie = c && (v[u].x == zt) && (ties < r_ties);
-                            const bool keep = c && ((v[u].x < zt) || tie);
-                            ties += tie ? 1 : 0;
-                            tie_cut = tie ? __builtin_amdgcn_readlane((int)h.z, j0 + u) : tie_cut;
-                            const float dist = sq2(v[u].y, v[u].z);
-                            const float sd = (__float_as_uint(v[u].w) & 1u) ? -dist : dist;
-                            const float fac = 1.0f - face_prob(sd, a.inv_sigma);
-                            prod *= keep ? fac : 1.0f;
-                        }
-                    }
-                }
-            } else
-            CHUNK_LOOP_BEGIN(false, nextafterf(wave_max((trunc && prod > ALPHA_GRAD_EPS) ? zt : -3.0e38f), 3.0e38f))
-            {
-                if (__ballot(trunc && prod > ALPHA_GRAD_EPS) != 0ull) {
-                    for (int i = 0; i < m; ++i) {
-                        const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                        if (__ballot(trunc && !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
-                        PairEval e;
-                        eval_pair(f, px, py, dxp, dyp, a.blur, e);
-                        if (__ballot(e.cand && trunc) == 0ull) continue;
-                        const float pz = pair_depth(f, e);
-                        const bool tie = e.cand && trunc && (pz == zt) && (ties < r_ties);
-                        const bool keep = e.cand && trunc && ((pz < zt) || tie);
-                        ties += tie ? 1 : 0;
-                        const float fac = 1.0f - face_prob(e.sd, a.inv_sigma);
-                        prod *= keep ? fac : 1.0f;
-                    }
-                }
-            }
-            CHUNK_LOOP_END
-            if (trunc) alpha = prod;
-        }
 
-        TMARK(2)
-        // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
-        const float silv = 1.0f - alpha;
-        float g = 0.f;
-        if (MODE == MODE_FWD) {
-            if (in_img) a.sil[pix] = silv;
-        } else if (MODE == MODE_BWD) {
-            if (in_img) g = a.grad_sil[pix];
-        } else {
-            float lsum = 0.f;
-            if (in_img) {
-                const float tg = a.target_u8 ? (float)a.target_u8[pix] : a.target[pix];
-                const float diff = silv - tg;
-                lsum = fabsf(diff) - fabsf(tg);  // loss_img starts at sum |0 - target|
-                g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
-                if (a.sil) a.sil[pix] = silv;
-            }
-            lsum = wave_sum(lsum);
-            if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
-        }
-        if (MODE == MODE_FWD) continue;
+        // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
+        // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
+#ifndef SPAN0
+#define SPAN0 WAVE
+#endif
+        int span = SPAN0;
+        while (span > 1 && (long long)span * list_total > 4ll * REC_CAP) span >>= 1;
+        for (int p_lo = 0; p_lo < WAVE;) {
+            const bool mine = lane >= p_lo && lane < p_lo + span;  // this lane's pixel belongs to the sub-tile
+            const int sy0 = p_lo >> 3, sy1 = (p_lo + span - 1) >> 3;                       // its rows ...
+            const int sx0 = span >= 8 ? 0 : (p_lo & 7), sx1 = span >= 8 ? 7 : ((p_lo & 7) + span - 1);  // ... and columns
+            // pixels outside the image or the sub-tile get a position no bbox can contain
+            const float px = (in_img && mine) ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
+            lds.pixt[lane] = make_float4(px, py, px - cx, py - cy);
+            if (may_truncate)
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist1[i_] = 0u;
+            __syncthreads();
 
-        TMARK(3)
-        // ---------------- pass 3: gradients ------------------------------------------------------
-        // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
-        const float coef = -g * alpha * a.inv_sigma;
-        const bool active = in_img && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
-        if (__ballot(active) == 0ull) continue;
-        float *dn = a.d_ndc + (size_t)n * a.V * 2;
-        const bool any_trunc = __ballot(trunc && active) != 0ull;
-        int ties = 0;
-        const float cut3 = wave_max(active ? (trunc ? zt : 3.0e38f) : -3.0e38f);
-        if (STREAM && stream_ok) {
-            // Dense walk: lane = record, not pixel.  Every lane fetches the state of the pixel its record belongs to from
-            // LDS; a record at the threshold depth is kept iff its face comes no later than the pixel's last kept tie.
-            lds.pcoef[lane] = active ? coef : 0.f;
-            lds.pzt[lane] = trunc ? zt : __builtin_inff();
-            lds.ptie[lane] = tie_cut;
-            __syncthreads();  // also orders pass 1's record stores before the loads below
-            for (int ch = 0; ch < n_chunks; ++ch) {
-                const int c0 = ch * FCHUNK;
-                if (sorted && zlo + (float)(lds.list[c0] >> 16) * zstep >= nextafterf(cut3, 3.0e38f)) break;
-                const int i_beg = (int)lds.cfirst[ch], i_end = (int)lds.cfirst[ch + 1];
-                if (i_beg == i_end) continue;
-                for (int i_ = lane; i_ < FCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.f;
+            // ---------------- pass 1: every pair inside a face's pixel box, once --------------------------------
+            int vbase = 0;  // records written so far (wave-uniform)
+            bool fits = true;
+            for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
+                const int m = min(DCHUNK, list_total - c0);
+                stage_faces(a, vn, slist, c0, m, lds.rec, lane, cx, cy);
+                if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
                 __syncthreads();
-                for (int g0 = i_beg; g0 < i_end; g0 += DGROUP * WAVE) {
-                    float4 v[DGROUP];
-                    uint32_t mt[DGROUP];
+                // lane = staged face: pixel box of its blurred bounding box inside this sub-tile (same rounding slack as the
+                // setup kernel: a superset; eval_pair applies the exact test)
+                int cf = 0, packed = 0;
+                if (lane < m) {
+                    const FaceRec &fr = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FREC);
+                    const int xi_lo = (int)ceilf(((fr.xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((fr.xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+                    const int yi_lo = (int)ceilf(((fr.ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((fr.ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+                    const int bx0 = max(a.S - 1 - xi_hi - tx * TILE, sx0), bx1 = min(a.S - 1 - xi_lo - tx * TILE, sx1);
+                    const int by0 = max(a.S - 1 - yi_hi - ty * TILE, sy0), by1 = min(a.S - 1 - yi_lo - ty * TILE, sy1);
+                    if (bx0 <= bx1 && by0 <= by1) {
+                        cf = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+                        packed = (bx0 << 13) | (by0 << 16) | ((bx1 - bx0) << 19);
+                    }
+                }
+                const int incl = wave_scan<false>(cf);
+                const int off = incl - cf;          // first pair of this face in the chunk's pair list
+                const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
+                packed |= off;                      // off <= DCHUNK * 64
+                if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
+                int carry = 0;                      // face (+1) of the last lane of the previous sweep step
+                for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
+                    // pair -> face: faces whose run starts inside this step mark their start, max-scan spreads it
+                    lds.start[lane] = 0;
+                    if (cf > 0 && off >= q0 && off < q0 + WAVE) lds.start[off - q0] = lane + 1;
+                    __syncthreads();  // other lanes' stores: without it the compiler forwards this lane's own 0
+                    const int fi = max(wave_scan<true>(lds.start[lane]), carry);
+                    carry = __builtin_amdgcn_readlane(fi, 63);
+                    const bool valid = q0 + lane < n_pairs;
+                    const int fs = max(fi - 1, 0);
+                    const int pk = __shfl(packed, fs, WAVE);
+                    const int rr = q0 + lane - (pk & 0x1FFF);
+                    const int bw = ((pk >> 19) & 7) + 1;
+                    const int dy = (int)((float)rr * __builtin_amdgcn_rcpf((float)bw) + 1e-3f);  // rr < 64, bw <= 8: exact
+                    const int p = (((((pk >> 16) & 7) + dy) << 3) + ((pk >> 13) & 7) + (rr - dy * bw)) & 63;
+                    const float4 pt = lds.pixt[p];
+                    const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FREC);
+                    PairEval e;
+                    eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
+                    const bool cand = valid && e.cand;
+                    const unsigned long long cm = __ballot(cand);
+                    if (cm == 0ull) continue;
+                    // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
+                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(pair_depth(fr, e)), kmin), kmax)) : 3.0e38f;
+                    const uint32_t zb = __float_as_uint(z);
+                    // 3 code bits (inside, edge) replace the low mantissa bits of t in [0,1] (<= 4e-7 relative)
+                    const uint32_t tb = (__float_as_uint(e.t) & ~7u) | (e.inside ? 1u : 0u) | ((uint32_t)e.edge << 1);
+                    const int slot = vbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    if (cand) {
+                        sval[slot] = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
+                        smeta[slot] = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
+                        skey[slot] = zb;
+                        if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
+                            const uint32_t bucket = (zb >> shift1) & ((1u << b1) - 1u);
+                            atomicAdd(&lds.hist1[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
+                        }
+                    }
+                    vbase += __popcll(cm);
+                }
+                __syncthreads();  // rec is rewritten by the next chunk
+            }
+            if (!fits) {  // wave-uniform: try again with half the pixels
+                span >>= 1;
+                __syncthreads();
+                continue;
+            }
+            if (lane == 0) scfirst[n_chunks] = (uint32_t)vbase;
+            __syncthreads();  // also: record stores of other lanes are visible from here on
+            TMARK(1)
+
+            // ---------------- select: K-th smallest depth of every pixel that has more than K candidates --------
+            // threshold: depth bits of the K-th smallest (0x7F800000 = +inf bits: keep everything); tie_cut: among the
+            // faces exactly at the threshold those up to this list position are kept
+            uint32_t zt_bits = 0x7F800000u;
+            int tie_cut = 0x7FFFFFFF;
+            if (may_truncate && vbase > 0) {
+                uint32_t pre = pre0;
+                int need = K, n_eq = 0;
+                const int tot = pick_digit(lds.hist1, lane, b1, pre, need, n_eq);
+                const bool trunc = tot > K;
+                if (!trunc) need = 0;
+                int nbits = nbits0 - b1;
+                if (__ballot(trunc) != 0ull) {
+                    // compaction: only the records of truncated pixels inside the chosen first digit go on
+                    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+                    __syncthreads();
+                    int n_cmp = 0;
+                    for (int g0 = 0; g0 < vbase; g0 += DGROUP * WAVE) {
+                        uint32_t kk[DGROUP], mt[DGROUP];
+#pragma unroll
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const int idx = min(g0 + u * WAVE + lane, vbase - 1);
+                            kk[u] = skey[idx];
+                            mt[u] = smeta[idx];
+                        }
+#pragma unroll
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const uint2 ps = lds.psel[mt[u] & 63u];
+                            const bool keep = (g0 + u * WAVE + lane < vbase) & (ps.y > 0u) & ((kk[u] >> nbits) == ps.x);
+                            const unsigned long long km = __ballot(keep);
+                            const int slot = n_cmp + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                            if (keep) {  // in place: slot <= index of the record being read
+                                skey[slot] = kk[u];
+                                scmeta[slot] = mt[u];
+                            }
+                            n_cmp += __popcll(km);
+                        }
+                    }
+                    __syncthreads();
+#ifdef DBG_TIMERS
+                    tph[5] += (unsigned long long)vbase; tph[6] += (unsigned long long)n_cmp;
+#endif
+                    auto depth_key = [&](int idx, uint32_t) { return skey[idx]; };
+                    while (nbits > 0 && __ballot(need > 0) != 0ull) {
+                        const int b = min(SEL_BITS, nbits);
+                        select_sweep(lds, scmeta, n_cmp, nbits, b, lane, pre, need, depth_key);
+#ifdef DBG_TIMERS
+                        tph[7] += 1ull;
+#endif
+                        pick_digit(lds.hist2, lane, b, pre, need, n_eq);
+                        nbits -= b;
+                        __syncthreads();
+                    }
+                    if (trunc) zt_bits = pre;
+                    // `need` of the n_eq faces at the threshold are kept: the first ones in list order
+                    const bool split = trunc && need < n_eq;
+                    if (__ballot(split) != 0ull) {
+                        // select on the list position among the records whose depth equals the pixel's threshold
+                        lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? zt_bits : 0xFFFFFFFFu), 0.f, 0.f);
+                        __syncthreads();
+                        int pbits = 32 - __clz(max(list_total - 1, 1));
+                        uint32_t ppre = 0u;
+                        int pneed = split ? need : 0, peq = 0;
+                        auto pos_key = [&](int idx, uint32_t mt) {
+                            // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
+                            return skey[idx] == __float_as_uint(lds.pgrad[mt & 63u].y) ? (mt >> 6) : 0xFFFFFFFFu;
+                        };
+                        while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
+                            const int b = min(SEL_BITS, pbits);
+                            select_sweep(lds, scmeta, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
+#ifdef DBG_TIMERS
+                            tph[7] += 1000000ull;
+#endif
+                            pick_digit(lds.hist2, lane, b, ppre, pneed, peq);
+                            pbits -= b;
+                            __syncthreads();
+                        }
+                        if (split) tie_cut = (int)ppre;
+                    }
+                }
+            }
+            TMARK(2)
+
+            // ---------------- pass 2: log2 of the kept factors, summed per pixel --------------------------------
+            lds.plog[lane] = 0.0;
+            lds.pgrad[lane] = make_float4(0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
+            __syncthreads();
+            if (vbase > 0) {
+                auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
-                        const int idx = min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
+                        const int idx = min(g0 + u * WAVE + lane, vbase - 1);
                         v[u] = sval[idx];
                         mt[u] = smeta[idx];
                     }
+                };
+                auto log_recs = [&](const float4 (&v)[DGROUP], const uint32_t (&mt)[DGROUP], int g0) {
+                    float4 pg[DGROUP];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) pg[u] = lds.pgrad[mt[u] & 63u];
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
-                        const bool valid = g0 + u * WAVE + lane < i_end;
-                        const int pxl = (int)(mt[u] & 63u), pos = (int)(mt[u] >> 6);
-                        const float pc = lds.pcoef[pxl], pz = lds.pzt[pxl];
-                        const int pt = lds.ptie[pxl];
-                        const uint32_t tb = __float_as_uint(v[u].w);
-                        const bool inside = (tb & 1u) != 0u;
+                        const uint32_t zb = __float_as_uint(v[u].x), zt_ = __float_as_uint(pg[u].y);
+                        const bool keep = (g0 + u * WAVE + lane < vbase) & ((zb < zt_) | ((zb == zt_) & ((int)(mt[u] >> 6) <= __float_as_int(pg[u].z))));
                         const float dist = sq2(v[u].y, v[u].z);
-                        float gd = pc * face_prob(inside ? -dist : dist, a.inv_sigma);
-                        gd = inside ? -gd : gd;
-                        const bool keep = valid && (gd != 0.f) && ((v[u].x < pz) || (v[u].x == pz && pos <= pt));
-                        const float t = __uint_as_float(tb & ~7u);
-                        const int edge = (int)((tb >> 1) & 3u);
-                        const int ia = edge == 2 ? 2 : 0, ib = edge == 0 ? 2 : 4;
-                        const float ex = 2.0f * v[u].y * gd, ey = 2.0f * v[u].z * gd;
-                        if (keep) {
-                            float *acc = lds.gacc + (pos & 63) * 6;
-                            atomicAdd(acc + ia, (1.0f - t) * ex);
-                            atomicAdd(acc + ia + 1, (1.0f - t) * ey);
-                            atomicAdd(acc + ib, t * ex);
-                            atomicAdd(acc + ib + 1, t * ey);
-                        }
+                        const float sd = (__float_as_uint(v[u].w) & 1u) ? -dist : dist;
+                        const float lf = __log2f(1.0f - face_prob(sd, a.inv_sigma));
+                        if (keep & (lf != 0.f)) atomicAdd(&lds.plog[mt[u] & 63u], (double)lf);
                     }
-                }
-                flush_gacc(a, lds, dn, ch, list_total, id_mask, lane);
-            }
-        } else
-        CHUNK_LOOP_BEGIN(true, nextafterf(cut3, 3.0e38f))
-        {
-            for (int i = 0; i < m; ++i) {
-                const FaceRec f = *reinterpret_cast<const FaceRec *>(lds.rec + i * FREC);
-                if (__ballot(active && !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin)) == 0ull) continue;
-                PairEval e;
-                eval_pair(f, px, py, dxp, dyp, a.blur, e);
-                bool keep = e.cand && active;
-                if (__ballot(keep) == 0ull) continue;
-                if (any_trunc) {
-                    const float pz = pair_depth(f, e);
-                    const bool tie = keep && trunc && (pz == zt) && (ties < r_ties);
-                    ties += tie ? 1 : 0;
-                    keep = keep && (!trunc || (pz < zt) || tie);
-                }
-                float gd = coef * face_prob(e.sd, a.inv_sigma);  // d L / d (signed dist)
-                gd = e.inside ? -gd : gd;                          // d L / d (unsigned squared distance)
-                keep = keep && (gd != 0.f);
-                if (__ballot(keep) == 0ull) continue;
-                const float t = e.t;
-                const int ia = e.edge == 2 ? 2 : 0, ib = e.edge == 0 ? 2 : 4;  // accumulator slots of the edge's end points
-                const float ex = 2.0f * e.rx * gd, ey = 2.0f * e.ry * gd;
-                if (keep) {
-                    float *acc = lds.gacc + i * 6;
-                    atomicAdd(acc + ia, (1.0f - t) * ex);
-                    atomicAdd(acc + ia + 1, (1.0f - t) * ey);
-                    atomicAdd(acc + ib, t * ex);
-                    atomicAdd(acc + ib + 1, t * ey);
+                };
+                float4 va[DGROUP], vb[DGROUP];
+                uint32_t ma[DGROUP], mb[DGROUP];
+                load_recs(va, ma, 0);
+                for (int g0 = 0; g0 < vbase; g0 += 2 * DGROUP * WAVE) {
+                    load_recs(vb, mb, g0 + DGROUP * WAVE);
+                    log_recs(va, ma, g0);
+                    load_recs(va, ma, g0 + 2 * DGROUP * WAVE);
+                    log_recs(vb, mb, g0 + DGROUP * WAVE);
                 }
             }
             __syncthreads();
-            // flush: lane = staged face, one global atomic per touched vertex component
-            if (lane < m) {
-                const FaceRec &f = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FREC);
-                const float *acc = lds.gacc + lane * 6;
-                if (acc[0] != 0.f) atomicAdd(&dn[2 * f.i0], acc[0]);
-                if (acc[1] != 0.f) atomicAdd(&dn[2 * f.i0 + 1], acc[1]);
-                if (acc[2] != 0.f) atomicAdd(&dn[2 * f.i1], acc[2]);
-                if (acc[3] != 0.f) atomicAdd(&dn[2 * f.i1 + 1], acc[3]);
-                if (acc[4] != 0.f) atomicAdd(&dn[2 * f.i2], acc[4]);
-                if (acc[5] != 0.f) atomicAdd(&dn[2 * f.i2 + 1], acc[5]);
+            const float alpha = exp2f((float)lds.plog[lane]);
+            TMARK(3)
+
+            // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
+            const float silv = 1.0f - alpha;
+            const bool own = in_img && mine;
+            float g = 0.f;
+            if (MODE == MODE_FWD) {
+                if (own) a.sil[pix] = silv;
+            } else if (MODE == MODE_BWD) {
+                if (own) g = a.grad_sil[pix];
+            } else {
+                float lsum = 0.f;
+                if (own) {
+                    const float tg = a.target_u8 ? (float)a.target_u8[pix] : a.target[pix];
+                    const float diff = silv - tg;
+                    lsum = fabsf(diff) - fabsf(tg);  // loss_img starts at sum |0 - target|
+                    g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+                    if (a.sil) a.sil[pix] = silv;
+                }
+                lsum = wave_sum(lsum);
+                if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
             }
+
+            // ---------------- pass 3: lane = record -------------------------------------------------
+            // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
+            const float coef = -g * alpha * a.inv_sigma;
+            const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
+            if (MODE != MODE_FWD && __ballot(active) != 0ull) {
+                float *dn = a.d_ndc + (size_t)n * a.V * 2;
+                lds.pgrad[lane] = make_float4(active ? coef : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
+                __syncthreads();
+                for (int ch = 0; ch < n_chunks; ++ch) {
+                    const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[ch + 1];
+                    if (i_beg == i_end) continue;
+                    // vertex ids of this chunk's faces: requested now, used by the flush
+                    const int fch = ch * DCHUNK + lane;
+                    int vi0 = 0, vi1 = 0, vi2 = 0;
+                    if (lane < DCHUNK && fch < list_total) {
+                        const int f = (int)slist[fch];
+                        vi0 = a.faces[3 * f]; vi1 = a.faces[3 * f + 1]; vi2 = a.faces[3 * f + 2];
+                    }
+                    for (int i_ = lane; i_ < DCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.0;
+                    __syncthreads();
+                    auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
+#pragma unroll
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const int idx = min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
+                            v[u] = sval[idx];
+                            mt[u] = smeta[idx];
+                        }
+                    };
+                    auto grad_recs = [&](const float4 (&v)[DGROUP], const uint32_t (&mt)[DGROUP], int g0) {
+                        float4 pg[DGROUP];  // all LDS gathers first
+#pragma unroll
+                        for (int u = 0; u < DGROUP; ++u) pg[u] = lds.pgrad[mt[u] & 63u];
+#pragma unroll
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const bool valid = g0 + u * WAVE + lane < i_end;
+                            const int pos = (int)(mt[u] >> 6);
+                            const uint32_t zb = __float_as_uint(v[u].x), zt_ = __float_as_uint(pg[u].y);
+                            const uint32_t tb = __float_as_uint(v[u].w);
+                            const bool inside = (tb & 1u) != 0u;
+                            const float dist = sq2(v[u].y, v[u].z);
+                            float gd = pg[u].x * face_prob(inside ? -dist : dist, a.inv_sigma);  // d L / d (signed dist)
+                            gd = inside ? -gd : gd;                                               // d L / d (unsigned squared distance)
+                            const bool keep = valid & (gd != 0.f) & ((zb < zt_) | ((zb == zt_) & (pos <= __float_as_int(pg[u].z))));
+                            const float t = __uint_as_float(tb & ~7u);
+                            const int edge = (int)((tb >> 1) & 3u);
+                            const int ia = edge == 2 ? 2 : 0, ib = edge == 0 ? 2 : 4;  // accumulator slots of the edge's end points
+                            const float ex = 2.0f * v[u].y * gd, ey = 2.0f * v[u].z * gd;
+                            if (keep) {
+                                double *acc = lds.gacc + (pos % DCHUNK) * 6;
+                                atomicAdd(acc + ia, (double)((1.0f - t) * ex));
+                                atomicAdd(acc + ia + 1, (double)((1.0f - t) * ey));
+                                atomicAdd(acc + ib, (double)(t * ex));
+                                atomicAdd(acc + ib + 1, (double)(t * ey));
+                            }
+                        }
+                    };
+                    {
+                        float4 va[DGROUP], vb[DGROUP];
+                        uint32_t ma[DGROUP], mb[DGROUP];
+                        load_recs(va, ma, i_beg);
+                        for (int g0 = i_beg; g0 < i_end; g0 += 2 * DGROUP * WAVE) {
+                            load_recs(vb, mb, g0 + DGROUP * WAVE);
+                            grad_recs(va, ma, g0);
+                            load_recs(va, ma, g0 + 2 * DGROUP * WAVE);
+                            grad_recs(vb, mb, g0 + DGROUP * WAVE);
+                        }
+                    }
+                    __syncthreads();
+                    if (lane < DCHUNK && fch < list_total) {  // flush: one global atomic per touched vertex component
+                        const double *acc = lds.gacc + lane * 6;
+                        if (acc[0] != 0.0) atomicAdd(&dn[2 * vi0], (float)acc[0]);
+                        if (acc[1] != 0.0) atomicAdd(&dn[2 * vi0 + 1], (float)acc[1]);
+                        if (acc[2] != 0.0) atomicAdd(&dn[2 * vi1], (float)acc[2]);
+                        if (acc[3] != 0.0) atomicAdd(&dn[2 * vi1 + 1], (float)acc[3]);
+                        if (acc[4] != 0.0) atomicAdd(&dn[2 * vi2], (float)acc[4]);
+                        if (acc[5] != 0.0) atomicAdd(&dn[2 * vi2 + 1], (float)acc[5]);
+                    }
+                    __syncthreads();
+                }
+            }
+            __syncthreads();
+            TMARK(4)
+            p_lo += span;
         }
-        CHUNK_LOOP_END
-        TMARK(4)
     }
-#ifdef DBG_TIMERS
-    if (a.dbg && lane == 0)
-        for (int k = 0; k < 5; ++k) atomicAdd(&a.dbg[k], tph[k]);
-#endif
+    TIMERS_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,20 +800,22 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
-    const long long resident = 256LL * 8;  // 256 CUs x 8 single-wave workgroups (2 waves per SIMD)
+    const long long resident = 256LL * RESIDENT_PER_CU;
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: LIST_CAP stream headers + VAL_CAP pair records
-static inline size_t stream_bytes(int grid) {
-    return (size_t)grid * ((size_t)LIST_CAP * sizeof(uint4) + (size_t)VAL_CAP * (sizeof(float4) + sizeof(uint32_t)));
+// per resident workgroup: F face ids, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) records of 28 bytes
+static inline size_t scratch_bytes(int grid, int F) {
+    return (size_t)grid * (align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+                           (size_t)(REC_CAP + REC_PAD) * (sizeof(float4) + 3 * sizeof(uint32_t)));
 }
 
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    return 2 * align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) +
-           256 + stream_bytes(tile_grid(N, ceil_div(S, TILE)));
+    // tile boxes (N,F), counters, work list (N, tiles), per-workgroup scratch
+    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) + 256 +
+           scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
@@ -757,31 +825,42 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
                  "raster: faces_per_pixel=%d outside 1..%d", rs->faces_per_pixel, SMIL_MAX_FACES_PER_PIXEL);
     SMIL_REQUIRE(rs->sigma > 0.f && rs->blur_radius >= 0.f, "raster: bad blend settings");
+    SMIL_REQUIRE(m->F <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP);
     const int tiles_x = ceil_div(S, TILE);
     SMIL_REQUIRE((double)N * tiles_x * tiles_x < 4294967295.0, "raster: N * tiles exceeds the 32-bit work-item code");
     char *ws = (char *)workspace;
     uint32_t *tbox = (uint32_t *)ws;
     ws += align256((size_t)N * m->F * sizeof(uint32_t));
     RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
-    float *fzmin = (float *)(ws + 256 + align256((size_t)N * tiles_x * tiles_x * sizeof(uint32_t)));
     ws += 256;
     uint32_t *items = (uint32_t *)ws;
+    ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint32_t));
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_words = (tiles_x * tiles_x + 31) / 32;
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), (size_t)(n_words + 256) * sizeof(uint32_t), stream, verts_ndc,
-                       m->faces, tbox, fzmin, items, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+                       m->faces, tbox, items, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
     SMIL_LAUNCH_CHECK();
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.fzmin = fzmin; a.items = items; a.ctr = ctr;
+    {
+        const size_t grid = (size_t)tile_grid(N, tiles_x);
+        a.list_stride = (int)(align256((size_t)m->F * sizeof(uint32_t)) / sizeof(uint32_t));
+        a.n_cf = (int)(align256((size_t)(m->F / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
+        ws += 256;
+        a.slist = (uint32_t *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
+        a.scfirst = (uint32_t *)ws;
+        ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
+        a.sval = (float4 *)ws;
+        ws += grid * (REC_CAP + REC_PAD) * sizeof(float4);
+        a.smeta = (uint32_t *)ws;
+        ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
+        a.skey = (uint32_t *)ws;
+        ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
+        a.scmeta = (uint32_t *)ws;
+    }
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.items = items; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
-    {
-        char *sp = (char *)fzmin + align256((size_t)N * m->F * sizeof(float));
-        const int grid = tile_grid(N, tiles_x);
-        a.shdr = (uint4 *)sp;
-        a.sval = (float4 *)(sp + (size_t)grid * LIST_CAP * sizeof(uint4));
-        a.smeta = (uint32_t *)((char *)a.sval + (size_t)grid * VAL_CAP * sizeof(float4));
-    }
     a.dbg = nullptr;
 #ifdef DBG_TIMERS
     {
@@ -789,8 +868,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 64); (void)hipMemset(dbg_dev, 0, 64); }
         unsigned long long h[8];
         (void)hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost);  // totals of the launches so far
-        fprintf(stderr, "[dbg timers] setup+list %.3e  p1 %.3e  p2 %.3e  epi %.3e  p3 %.3e cycles\n", (double)h[0], (double)h[1],
-                (double)h[2], (double)h[3], (double)h[4]);
+        fprintf(stderr, "[dbg timers] list %.3e  p1 %.3e  select %.3e  p2 %.3e  p3 %.3e cycles; records %.3e compacted %.3e sweeps %.0f\n",
+                (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)h[5], (double)h[6], (double)h[7]);
         (void)hipMemset(dbg_dev, 0, 64);
         a.dbg = dbg_dev;
     }
@@ -845,11 +924,7 @@ extern "C" int smil_profile_read(float *total_ms, int32_t *launches) {
 
 template <int MODE>
 static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
-    const dim3 grid(tile_grid(N, a.tiles_x)), block(64);
-    constexpr bool ST = MODE != MODE_FWD;  // backward passes read pass 1's pair stream instead of re-evaluating
-    if (a.K == 100) hipLaunchKernelGGL((k_raster_tiles<MODE, 100, true, ST>), grid, block, 0, stream, a);  // the reference's K
-    else if (a.K <= 16) hipLaunchKernelGGL((k_raster_tiles<MODE, 16, false, false>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_raster_tiles<MODE, SMIL_MAX_FACES_PER_PIXEL, false, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((k_raster_dense<MODE>), dim3(tile_grid(N, a.tiles_x)), dim3(64), 0, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

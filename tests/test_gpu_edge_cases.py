@@ -78,20 +78,26 @@ def test_faces_per_pixel_variants(K, tables):
         eng.silhouette_forward(dm, ndc.to(DEV), S, eng.raster_settings(K=129))
 
 
-def test_dense_tile_exceeding_list_capacity(tables):
-    """A whole 6019-face mesh squeezed into ~2x2 tiles: the per-tile face list overflows the LDS buffer and the
-    kernel must fall back to rebuilding it segment by segment."""
+@pytest.mark.parametrize("key,dist", [("stick", 14.0), ("mouse", 22.0)])
+def test_dense_tile_processed_in_sub_tiles(key, dist, tables):
+    """A whole mesh squeezed into ~2x2 tiles: thousands of faces per tile, far more (face, pixel) records than the
+    workgroup's stream holds, so the kernel works through the tile in sub-tiles (and, for the mouse, has to halve
+    them again after finding that its first estimate does not fit)."""
     eng = _eng()
-    t = tables("stick")
+    t = tables(key)
     dm = eng.DeviceModel(t, DEV)
     S = 32
-    ndc = _scene(t, 1, S, 14.0, 2)  # far away -> tiny on screen
+    ndc = _scene(t, 1, S, dist, 2)  # far away -> tiny on screen
     ref, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
     assert ncand.max() > 1024
     got = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
     d = np.abs(got - ref)
     assert d.mean() < 5e-4 and np.mean(d > 1e-2) < 0.01, (d.mean(), d.max())
-    # gradient path through the same overflow code
+    with render_ref.select_mode(1):
+        ref1, _ = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    d1 = np.abs(got - ref1)
+    assert d1.mean() < 2e-4 and np.mean(d1 > 1e-2) < 0.005, (d1.mean(), d1.max())
+    # gradient path through the same code
     gs = torch.ones(1, S, S)
     want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
     gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()

@@ -43,11 +43,28 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.reps
 ws = dm._ws
 off = ((N * dm.F * 4 + 255) // 256) * 256
-ctr = ws[off:off + 8].view(torch.int32).cpu().numpy()
+ctr = ws[off:off + 16].view(torch.int32).cpu().numpy()
 tb = ws[: N * dm.F * 4].view(torch.int32).reshape(N, dm.F).cpu().numpy().astype(np.uint32)
 tx0, ty0, tx1, ty1 = tb & 255, (tb >> 8) & 255, (tb >> 16) & 255, tb >> 24
 valid = tx0 <= tx1
 tiles_per_face = np.where(valid, (tx1.astype(int) - tx0 + 1) * (ty1.astype(int) - ty0 + 1), 0)
+print(f"handed over to the re-evaluating kernel: {ctr[2]} tiles")
 print(f"images {N}  time/launch {dt*1e3:.2f} ms  {dt/N*1e6:.1f} us/image  work items {ctr[0]} ({ctr[0]/N:.1f} tiles/image)  "
       f"valid faces/image {valid.sum(1).mean():.0f}  (tile,face) pairs/image {tiles_per_face.sum(1).mean():.0f}  "
       f"avg list length {tiles_per_face.sum()/max(ctr[0],1):.0f}")
+# distribution of per-tile list lengths (faces whose tile box contains the tile)
+T = (args.S + 7) // 8
+import collections
+lens = []
+for n in range(N):
+    cnt = np.zeros((T + 1, T + 1), np.int64)
+    v = valid[n]
+    np.add.at(cnt, (ty0[n][v], tx0[n][v]), 1)
+    np.add.at(cnt, (ty1[n][v].astype(int) + 1, tx0[n][v]), -1)
+    np.add.at(cnt, (ty0[n][v], tx1[n][v].astype(int) + 1), -1)
+    np.add.at(cnt, (ty1[n][v].astype(int) + 1, tx1[n][v].astype(int) + 1), 1)
+    c = cnt.cumsum(0).cumsum(1)[:T, :T]
+    lens.append(c[c > 0])
+lens = np.concatenate(lens)
+print("tiles", len(lens), "list length percentiles 50/90/99/99.9/max:", [int(np.percentile(lens, q)) for q in (50, 90, 99, 99.9)], int(lens.max()),
+      " >1024:", int((lens > 1024).sum()), " >2048:", int((lens > 2048).sum()), " >4096:", int((lens > 4096).sum()))

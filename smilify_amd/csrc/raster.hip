@@ -45,10 +45,10 @@
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
 #define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
 #define DGROUP 4            // 64-record rows per buffer in the dense walks (two buffers)
-#define KGROUP 8            // 64-key rows per buffer in the selection sweeps (two buffers)
+#define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
 #define REC_PAD 64          // slack so that a clamped read stays inside the allocation
-#define RESIDENT_PER_CU 12  // single-wave workgroups per CU (3 waves per SIMD: 168 VGPRs, 13 KB LDS)
+#define RESIDENT_PER_CU 14  // single-wave workgroups per CU (11 KB LDS each; 120 VGPRs allow 16)
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
@@ -73,6 +73,7 @@ struct RasterArgs {
     const int *faces;        // (F,3)
     const uint32_t *tbox;    // (N,F)
     const uint32_t *items;   // work list
+    const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
     float blur, sqrt_blur, inv_sigma;
@@ -89,7 +90,7 @@ struct RasterArgs {
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
     float4 *sval;            // REC_CAP + REC_PAD records {depth, rx, ry, t | code}
     uint32_t *smeta;         // pixel | list position << 6
-    uint32_t *skey;          // depth bits (the selection sweeps read 8 instead of 20 bytes per record)
+    uint32_t *skey;          // depth bits minus the tile's smallest (the selection sweeps read 8 instead of 20 bytes per record)
     uint32_t *scmeta;        // meta of the records that survive the first selection digit (keys are compacted in place)
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
@@ -106,8 +107,8 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ items,
-                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x,
-                                                      float sqrt_blur) {
+                                                      float2 *__restrict__ fzr, RasterCounters *ctr, int V, int F, int S,
+                                                      int tiles_x, float sqrt_blur) {
     extern __shared__ uint32_t bitmap[];  // tiles_x*tiles_x bits, then 256 scan slots
     const int n = blockIdx.x;
     const int n_tiles = tiles_x * tiles_x;
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
             }
         }
         tbox[(size_t)n * F + f] = box;
+        fzr[(size_t)n * F + f] = make_float2(zmin, fmaxf(fmaxf(z0, z1), z2));
     }
     __syncthreads();
     // ordered compaction of touched tiles -> global work list
@@ -258,19 +260,28 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
 // ---------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------
+#define GCHUNK 64            // faces whose gradient accumulators are live in pass 3 (a multiple of DCHUNK)
 struct alignas(16) DenseLds {
     union {
-        float rec[DCHUNK * FREC];                   // pass 1: staged face records
-        uint32_t hist2[(1 << SEL_BITS) / 2 * WAVE];  // select, later digits: [bucket / 2][pixel], two 16-bit counts per word
+        float rec[DCHUNK * FREC];    // pass 1: staged face records
+        struct {                     // passes 2 / 3 (fp64: ds_add_f64 runs at full rate on gfx950, ds_add_f32 at ~3
+            double gacc[GCHUNK * 6]; //              cycles per active lane)
+            double plog[WAVE];       // pass 2: sum of log2(1 - p_k)
+        };
     };
-    uint32_t hist1[(1 << SEL_BITS) / 2 * WAVE];      // select, first digit: filled by pass 1
-    double gacc[DCHUNK * 6];         // fp64: ds_add_f64 runs at full rate on gfx950, ds_add_f32 at ~3 cycles per lane
-    double plog[WAVE];               // pass 2: sum of log2(1 - p_k)
+    // select: [bucket / 2][pixel], two 16-bit counts per word; the first digit is counted by pass 1
+    uint32_t hist[(1 << SEL_BITS) / 2 * WAVE];
     float4 pixt[WAVE];               // px, py, px - cx, py - cy
     float4 pgrad[WAVE];              // passes 2/3: {gradient coefficient, threshold depth bits, last kept list position, -}
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     int start[WAVE];                 // pair -> face mapping scratch
 };
+static_assert(sizeof(double) * (GCHUNK * 6 + WAVE) <= sizeof(float) * DCHUNK * FREC, "pass 2/3 accumulators must fit the record buffer");
+
+// Single-wave workgroups: lanes exchange data through LDS without s_barrier, but the compiler must not forward a lane's
+// own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
+// outstanding global stores (vmcnt), which in pass 1 would stall every sweep step on the previous step's record stores.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // inclusive wave64 scans in DPP (row_shr within 16-lane rows, then row_bcast across rows)
 template <bool IS_MAX>
@@ -282,19 +293,11 @@ __device__ __forceinline__ int wave_scan(int x) {
     return x;  // IS_MAX assumes non-negative inputs (identity 0)
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, WAVE));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, WAVE));
-    return v;
-}
-
-// Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the
-// nearest / farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's
-// vertex depths), which fixes the radix-select digits before pass 1 starts.
-__device__ __forceinline__ int build_list(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *__restrict__ tbox_n,
+// Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the nearest /
+// farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's vertex
+// depths), which fixes the radix-select digits before pass 1 starts.  Depths are positive: the bit patterns order like
+// the values.
+__device__ __forceinline__ int build_list(const RasterArgs &a, const uint32_t *__restrict__ tbox_n, const float2 *__restrict__ fzr_n,
                                           int tx, int ty, uint32_t *list, int lane, uint32_t &kmin, uint32_t &kmax) {
     int cnt = 0;
     float zlo = 3.0e38f, zhi = 0.f;
@@ -313,15 +316,20 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, const float *__re
             if (hit) {
                 const int f = base + u * WAVE + lane;
                 list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)f;
-                const float z0 = vn[3 * a.faces[3 * f] + 2], z1 = vn[3 * a.faces[3 * f + 1] + 2], z2 = vn[3 * a.faces[3 * f + 2] + 2];
-                zlo = fminf(zlo, fminf(fminf(z0, z1), z2));
-                zhi = fmaxf(zhi, fmaxf(fmaxf(z0, z1), z2));
+                const float2 zz = fzr_n[f];
+                zlo = fminf(zlo, zz.x);
+                zhi = fmaxf(zhi, zz.y);
             }
             cnt += __popcll(mask);
         }
     }
-    kmin = wave_min_u32(__float_as_uint(zlo));  // depths are positive: the bit patterns order like the values
-    kmax = wave_max_u32(__float_as_uint(zhi));
+    uint32_t lo = __float_as_uint(zlo), hi = __float_as_uint(zhi);
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, WAVE));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, WAVE));
+    }
+    kmin = lo;
+    kmax = hi;
     return cnt;
 }
 
@@ -388,7 +396,7 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
                                              int lane, uint32_t pre, int need, KeyFn key_of) {
     const int shift = nbits - b;
     lds.psel[lane] = make_uint2(pre, (uint32_t)need);
-    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist2[i_] = 0u;
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
     __syncthreads();
     auto load_keys = [&](uint32_t (&kk)[KGROUP], uint32_t (&mt)[KGROUP], int g0) {
 #pragma unroll
@@ -407,7 +415,7 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
             const uint32_t pxl = mt[u] & 63u;
             const bool hit = (g0 + u * WAVE + lane < n_rec) & (ps[u].y > 0u) & ((kk[u] >> nbits) == ps[u].x) & (kk[u] != 0xFFFFFFFFu);
             const uint32_t bucket = (kk[u] >> shift) & ((1u << b) - 1u);
-            if (hit) atomicAdd(&lds.hist2[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+            if (hit) atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
         }
     };
     if (n_rec > 0) {  // double-buffered: the next KGROUP rows are in flight while this one is counted
@@ -424,7 +432,7 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
+__global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
     const int lane = threadIdx.x;
     uint32_t *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
@@ -454,13 +462,13 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
         uint32_t kmin, kmax;  // bounds of the depth keys of this tile
-        const int list_total = build_list(a, vn, a.tbox + (size_t)n * a.F, tx, ty, slist, lane, kmin, kmax);
+        const int list_total = build_list(a, a.tbox + (size_t)n * a.F, a.fzr + (size_t)n * a.F, tx, ty, slist, lane, kmin, kmax);
         const bool may_truncate = list_total > K;
         const int n_chunks = (list_total + DCHUNK - 1) / DCHUNK;
-        // radix select: key bits below `nbits0` tell the tile's candidates apart, all keys share `pre0` above them
-        const uint32_t kdiff = kmin ^ kmax;
-        const int nbits0 = kdiff ? 32 - __clz(kdiff) : 0;  // depths > 0: <= 31
-        const uint32_t pre0 = kmax >> nbits0;
+        // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
+        // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
+        const uint32_t krange = kmax - kmin;
+        const int nbits0 = krange ? 32 - __clz(krange) : 0;
         const int b1 = min(SEL_BITS, nbits0), shift1 = nbits0 - b1;
         __syncthreads();  // the list stores are visible to the staging loads below
         TMARK(0)
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
             const float px = (in_img && mine) ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
             lds.pixt[lane] = make_float4(px, py, px - cx, py - cy);
             if (may_truncate)
-                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist1[i_] = 0u;
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
 
             // ---------------- pass 1: every pair inside a face's pixel box, once --------------------------------
@@ -490,7 +498,7 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                 const int m = min(DCHUNK, list_total - c0);
                 stage_faces(a, vn, slist, c0, m, lds.rec, lane, cx, cy);
                 if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
-                __syncthreads();
+                lds_fence();
                 // lane = staged face: pixel box of its blurred bounding box inside this sub-tile (same rounding slack as the
                 // setup kernel: a superset; eval_pair applies the exact test)
                 int cf = 0, packed = 0;
@@ -510,12 +518,15 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
                 packed |= off;                      // off <= DCHUNK * 64
                 if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
+#ifdef DBG_TIMERS
+                { const unsigned long long now_ = __builtin_readcyclecounter(); tph[5] += now_ - tlast; tlast = now_; tph[6] += (unsigned long long)((n_pairs + 63) / 64); tph[7] += 1ull; }
+#endif
                 int carry = 0;                      // face (+1) of the last lane of the previous sweep step
                 for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
                     // pair -> face: faces whose run starts inside this step mark their start, max-scan spreads it
                     lds.start[lane] = 0;
                     if (cf > 0 && off >= q0 && off < q0 + WAVE) lds.start[off - q0] = lane + 1;
-                    __syncthreads();  // other lanes' stores: without it the compiler forwards this lane's own 0
+                    lds_fence();  // other lanes' stores: without it the compiler forwards this lane's own 0
                     const int fi = max(wave_scan<true>(lds.start[lane]), carry);
                     carry = __builtin_amdgcn_readlane(fi, 63);
                     const bool valid = q0 + lane < n_pairs;
@@ -541,15 +552,15 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                     if (cand) {
                         sval[slot] = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
                         smeta[slot] = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
-                        skey[slot] = zb;
+                        skey[slot] = zb - kmin;
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
-                            const uint32_t bucket = (zb >> shift1) & ((1u << b1) - 1u);
-                            atomicAdd(&lds.hist1[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
+                            const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
+                            atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
                         }
                     }
                     vbase += __popcll(cm);
                 }
-                __syncthreads();  // rec is rewritten by the next chunk
+                lds_fence();  // rec is rewritten by the next chunk
             }
             if (!fits) {  // wave-uniform: try again with half the pixels
                 span >>= 1;
@@ -566,15 +577,18 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
             uint32_t zt_bits = 0x7F800000u;
             int tie_cut = 0x7FFFFFFF;
             if (may_truncate && vbase > 0) {
-                uint32_t pre = pre0;
+                uint32_t pre = 0u;
                 int need = K, n_eq = 0;
-                const int tot = pick_digit(lds.hist1, lane, b1, pre, need, n_eq);
+                const int tot = pick_digit(lds.hist, lane, b1, pre, need, n_eq);
                 const bool trunc = tot > K;
                 if (!trunc) need = 0;
                 int nbits = nbits0 - b1;
                 if (__ballot(trunc) != 0ull) {
-                    // compaction: only the records of truncated pixels inside the chosen first digit go on
+                    // compaction: only the records of truncated pixels inside the chosen first digit go on; their second
+                    // digit is histogrammed in the same sweep
                     lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+                    const int b2 = min(SEL_BITS, nbits), shift2 = nbits - b2;
+                    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
                     __syncthreads();
                     int n_cmp = 0;
                     for (int g0 = 0; g0 < vbase; g0 += DGROUP * WAVE) {
@@ -594,31 +608,32 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                             if (keep) {  // in place: slot <= index of the record being read
                                 skey[slot] = kk[u];
                                 scmeta[slot] = mt[u];
+                                const uint32_t bucket = (kk[u] >> shift2) & ((1u << b2) - 1u);
+                                atomicAdd(&lds.hist[(bucket >> 1) * WAVE + (mt[u] & 63u)], (bucket & 1u) ? 0x10000u : 1u);
                             }
                             n_cmp += __popcll(km);
                         }
                     }
                     __syncthreads();
-#ifdef DBG_TIMERS
-                    tph[5] += (unsigned long long)vbase; tph[6] += (unsigned long long)n_cmp;
-#endif
+                    if (nbits > 0) {  // second digit: counted above
+                        pick_digit(lds.hist, lane, b2, pre, need, n_eq);
+                        nbits -= b2;
+                        __syncthreads();
+                    }
                     auto depth_key = [&](int idx, uint32_t) { return skey[idx]; };
                     while (nbits > 0 && __ballot(need > 0) != 0ull) {
                         const int b = min(SEL_BITS, nbits);
                         select_sweep(lds, scmeta, n_cmp, nbits, b, lane, pre, need, depth_key);
-#ifdef DBG_TIMERS
-                        tph[7] += 1ull;
-#endif
-                        pick_digit(lds.hist2, lane, b, pre, need, n_eq);
+                        pick_digit(lds.hist, lane, b, pre, need, n_eq);
                         nbits -= b;
                         __syncthreads();
                     }
-                    if (trunc) zt_bits = pre;
+                    if (trunc) zt_bits = pre + kmin;
                     // `need` of the n_eq faces at the threshold are kept: the first ones in list order
                     const bool split = trunc && need < n_eq;
                     if (__ballot(split) != 0ull) {
                         // select on the list position among the records whose depth equals the pixel's threshold
-                        lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? zt_bits : 0xFFFFFFFFu), 0.f, 0.f);
+                        lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
                         __syncthreads();
                         int pbits = 32 - __clz(max(list_total - 1, 1));
                         uint32_t ppre = 0u;
@@ -630,10 +645,7 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                         while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
                             const int b = min(SEL_BITS, pbits);
                             select_sweep(lds, scmeta, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
-#ifdef DBG_TIMERS
-                            tph[7] += 1000000ull;
-#endif
-                            pick_digit(lds.hist2, lane, b, ppre, pneed, peq);
+                            pick_digit(lds.hist, lane, b, ppre, pneed, peq);
                             pbits -= b;
                             __syncthreads();
                         }
@@ -713,17 +725,18 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                 float *dn = a.d_ndc + (size_t)n * a.V * 2;
                 lds.pgrad[lane] = make_float4(active ? coef : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
                 __syncthreads();
-                for (int ch = 0; ch < n_chunks; ++ch) {
-                    const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[ch + 1];
+                constexpr int GR = GCHUNK / DCHUNK;
+                for (int ch = 0; ch < n_chunks; ch += GR) {
+                    const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[min(ch + GR, n_chunks)];
                     if (i_beg == i_end) continue;
                     // vertex ids of this chunk's faces: requested now, used by the flush
                     const int fch = ch * DCHUNK + lane;
                     int vi0 = 0, vi1 = 0, vi2 = 0;
-                    if (lane < DCHUNK && fch < list_total) {
+                    if (fch < list_total) {
                         const int f = (int)slist[fch];
                         vi0 = a.faces[3 * f]; vi1 = a.faces[3 * f + 1]; vi2 = a.faces[3 * f + 2];
                     }
-                    for (int i_ = lane; i_ < DCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.0;
+                    for (int i_ = lane; i_ < GCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.0;
                     __syncthreads();
                     auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
 #pragma unroll
@@ -753,7 +766,7 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                             const int ia = edge == 2 ? 2 : 0, ib = edge == 0 ? 2 : 4;  // accumulator slots of the edge's end points
                             const float ex = 2.0f * v[u].y * gd, ey = 2.0f * v[u].z * gd;
                             if (keep) {
-                                double *acc = lds.gacc + (pos % DCHUNK) * 6;
+                                double *acc = lds.gacc + (pos % GCHUNK) * 6;
                                 atomicAdd(acc + ia, (double)((1.0f - t) * ex));
                                 atomicAdd(acc + ia + 1, (double)((1.0f - t) * ey));
                                 atomicAdd(acc + ib, (double)(t * ex));
@@ -773,7 +786,7 @@ __global__ void __launch_bounds__(64, 3) k_raster_dense(RasterArgs a) {
                         }
                     }
                     __syncthreads();
-                    if (lane < DCHUNK && fch < list_total) {  // flush: one global atomic per touched vertex component
+                    if (fch < list_total) {  // flush: one global atomic per touched vertex component
                         const double *acc = lds.gacc + lane * 6;
                         if (acc[0] != 0.0) atomicAdd(&dn[2 * vi0], (float)acc[0]);
                         if (acc[1] != 0.0) atomicAdd(&dn[2 * vi0 + 1], (float)acc[1]);
@@ -813,9 +826,9 @@ static inline size_t scratch_bytes(int grid, int F) {
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    // tile boxes (N,F), counters, work list (N, tiles), per-workgroup scratch
-    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) + 256 +
-           scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
+    // tile boxes (N,F), counters, work list (N, tiles), per-face depth ranges (N,F), per-workgroup scratch
+    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) +
+           align256((size_t)N * m->F * sizeof(float2)) + 256 + scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
@@ -835,11 +848,13 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += 256;
     uint32_t *items = (uint32_t *)ws;
     ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint32_t));
+    float2 *fzr = (float2 *)ws;
+    ws += align256((size_t)N * m->F * sizeof(float2));
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_words = (tiles_x * tiles_x + 31) / 32;
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), (size_t)(n_words + 256) * sizeof(uint32_t), stream, verts_ndc,
-                       m->faces, tbox, items, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+                       m->faces, tbox, items, fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
@@ -858,7 +873,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
         a.scmeta = (uint32_t *)ws;
     }
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.items = items; a.ctr = ctr;
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.items = items; a.fzr = fzr; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;
@@ -868,7 +883,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 64); (void)hipMemset(dbg_dev, 0, 64); }
         unsigned long long h[8];
         (void)hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost);  // totals of the launches so far
-        fprintf(stderr, "[dbg timers] list %.3e  p1 %.3e  select %.3e  p2 %.3e  p3 %.3e cycles; records %.3e compacted %.3e sweeps %.0f\n",
+        fprintf(stderr, "[dbg timers] list %.3e  p1 %.3e  select %.3e  p2 %.3e  p3 %.3e cycles; p1 staging %.3e (not in p1) steps %.3e chunks %.3e\n",
                 (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)h[5], (double)h[6], (double)h[7]);
         (void)hipMemset(dbg_dev, 0, 64);
         a.dbg = dbg_dev;

@@ -41,6 +41,8 @@
 #define TILE 8
 #define DCHUNK 32           // faces staged per chunk
 #define FREC 32             // floats per staged face record
+#define FSTR 36             // its stride in LDS: 128-byte records would put the same field of every face in the same bank, and
+                            // pass 1 gathers 3-5 different faces per instruction; 144 bytes keeps 8 consecutive faces apart
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
 #define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
@@ -71,7 +73,8 @@ struct RasterCounters {
 struct RasterArgs {
     const float *verts_ndc;  // (N,V,3)
     const int *faces;        // (F,3)
-    const uint32_t *tbox;    // (N,F)
+    const uint32_t *tbox;    // (N,F) tile box of every face
+    const uint32_t *gbox;    // (N, ceil(F/64)) union of the tile boxes of 64 consecutive faces
     const uint32_t *items;   // work list
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
@@ -106,8 +109,8 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
-                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ items,
-                                                      float2 *__restrict__ fzr, RasterCounters *ctr, int V, int F, int S,
+                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
+                                                      uint32_t *__restrict__ items, float2 *__restrict__ fzr, RasterCounters *ctr, int V, int F, int S,
                                                       int tiles_x, float sqrt_blur) {
     extern __shared__ uint32_t bitmap[];  // tiles_x*tiles_x bits, then 256 scan slots
     const int n = blockIdx.x;
@@ -118,12 +121,15 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
     __syncthreads();
     const float *vn = verts_ndc + (size_t)n * V * 3;
     const float fS = (float)S;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const int n_groups = (F + WAVE - 1) / WAVE;
+    for (int f0 = 0; f0 < F; f0 += blockDim.x) {  // every wave handles 64 consecutive faces per round
+        const int f = f0 + threadIdx.x;
+        uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
+        if (f < F) {
         const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
         const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
         const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
         const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
-        uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
         const float zmin = fminf(fminf(z0, z1), z2);
         const float area = edge_fn(x0, y0, x1, y1, x2, y2);
         const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
@@ -150,6 +156,16 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
         }
         tbox[(size_t)n * F + f] = box;
         fzr[(size_t)n * F + f] = make_float2(zmin, fmaxf(fmaxf(z0, z1), z2));
+        }
+        // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test
+        int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
+        for (int o = 32; o > 0; o >>= 1) {
+            gx0 = min(gx0, __shfl_xor(gx0, o, WAVE)); gy0 = min(gy0, __shfl_xor(gy0, o, WAVE));
+            gx1 = max(gx1, __shfl_xor(gx1, o, WAVE)); gy1 = max(gy1, __shfl_xor(gy1, o, WAVE));
+        }
+        const int grp = (f0 + (int)threadIdx.x) / WAVE;
+        if ((threadIdx.x & (WAVE - 1)) == 0 && grp < n_groups)
+            gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
     __syncthreads();
     // ordered compaction of touched tiles -> global work list
@@ -263,7 +279,7 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
 #define GCHUNK 64            // faces whose gradient accumulators are live in pass 3 (a multiple of DCHUNK)
 struct alignas(16) DenseLds {
     union {
-        float rec[DCHUNK * FREC];    // pass 1: staged face records
+        float rec[DCHUNK * FSTR];    // pass 1: staged face records
         struct {                     // passes 2 / 3 (fp64: ds_add_f64 runs at full rate on gfx950, ds_add_f32 at ~3
             double gacc[GCHUNK * 6]; //              cycles per active lane)
             double plog[WAVE];       // pass 2: sum of log2(1 - p_k)
@@ -276,7 +292,7 @@ struct alignas(16) DenseLds {
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     int start[WAVE];                 // pair -> face mapping scratch
 };
-static_assert(sizeof(double) * (GCHUNK * 6 + WAVE) <= sizeof(float) * DCHUNK * FREC, "pass 2/3 accumulators must fit the record buffer");
+static_assert(sizeof(double) * (GCHUNK * 6 + WAVE) <= sizeof(float) * DCHUNK * FSTR, "pass 2/3 accumulators must fit the record buffer");
 
 // Single-wave workgroups: lanes exchange data through LDS without s_barrier, but the compiler must not forward a lane's
 // own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
@@ -297,30 +313,47 @@ __device__ __forceinline__ int wave_scan(int x) {
 // farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's vertex
 // depths), which fixes the radix-select digits before pass 1 starts.  Depths are positive: the bit patterns order like
 // the values.
-__device__ __forceinline__ int build_list(const RasterArgs &a, const uint32_t *__restrict__ tbox_n, const float2 *__restrict__ fzr_n,
-                                          int tx, int ty, uint32_t *list, int lane, uint32_t &kmin, uint32_t &kmax) {
+__device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
+    const int tx0 = b & 0xFF, ty0 = (b >> 8) & 0xFF, tx1 = (b >> 16) & 0xFF, ty1 = b >> 24;
+    return (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
+}
+
+__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, uint32_t *list, int lane, uint32_t &kmin,
+                                          uint32_t &kmax) {
+    const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.F;
+    const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.F;
+    const int n_groups = (a.F + WAVE - 1) / WAVE;
+    const uint32_t *__restrict__ gbox_n = a.gbox + (size_t)n * n_groups;
     int cnt = 0;
     float zlo = 3.0e38f, zhi = 0.f;
-    for (int base = 0; base < a.F; base += 4 * WAVE) {
-        uint32_t b[4];  // four independent loads in flight per lane
+    for (int g0 = 0; g0 < n_groups; g0 += WAVE) {
+        // lane = group of 64 consecutive faces: does its box union reach this tile?
+        const int g = g0 + lane;
+        unsigned long long gm = __ballot(g < n_groups && box_has(gbox_n[min(g, n_groups - 1)], tx, ty));
+        while (gm) {  // wave-uniform: the groups that do, in ascending order, four at a time (independent loads in flight)
+            int fidx[4];
+            uint32_t tb[4];
+            float2 zz[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = base + u * WAVE + lane;
-            b[u] = f < a.F ? tbox_n[f] : 0x0000FFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int tx0 = b[u] & 0xFF, ty0 = (b[u] >> 8) & 0xFF, tx1 = (b[u] >> 16) & 0xFF, ty1 = b[u] >> 24;
-            const bool hit = (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
-            const unsigned long long mask = __ballot(hit);
-            if (hit) {
-                const int f = base + u * WAVE + lane;
-                list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)f;
-                const float2 zz = fzr_n[f];
-                zlo = fminf(zlo, zz.x);
-                zhi = fmaxf(zhi, zz.y);
+            for (int u = 0; u < 4; ++u) {
+                const int gi = gm ? g0 + (int)__builtin_ctzll(gm) : -1;
+                gm &= gm - 1ull;  // 0 stays 0
+                fidx[u] = gi >= 0 ? gi * WAVE + lane : a.F;
+                const int fc = min(fidx[u], a.F - 1);
+                tb[u] = tbox_n[fc];
+                zz[u] = fzr_n[fc];
             }
-            cnt += __popcll(mask);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool hit = fidx[u] < a.F && box_has(tb[u], tx, ty);
+                const unsigned long long mask = __ballot(hit);
+                if (hit) {
+                    list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)fidx[u];
+                    zlo = fminf(zlo, zz[u].x);
+                    zhi = fmaxf(zhi, zz[u].y);
+                }
+                cnt += __popcll(mask);
+            }
         }
     }
     uint32_t lo = __float_as_uint(zlo), hi = __float_as_uint(zhi);
@@ -359,7 +392,7 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
         r.rl02 = l02 <= K_EPS ? 0.f : 1.0f / l02;
         r.rl12 = l12 <= K_EPS ? 0.f : 1.0f / l12;
         r.i0 = i0; r.i1 = i1; r.i2 = i2;
-        *reinterpret_cast<FaceRec *>(rec + lane * FREC) = r;
+        *reinterpret_cast<FaceRec *>(rec + lane * FSTR) = r;
     }
 }
 
@@ -462,7 +495,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
         uint32_t kmin, kmax;  // bounds of the depth keys of this tile
-        const int list_total = build_list(a, a.tbox + (size_t)n * a.F, a.fzr + (size_t)n * a.F, tx, ty, slist, lane, kmin, kmax);
+        const int list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
         const bool may_truncate = list_total > K;
         const int n_chunks = (list_total + DCHUNK - 1) / DCHUNK;
         // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
@@ -503,7 +536,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 // setup kernel: a superset; eval_pair applies the exact test)
                 int cf = 0, packed = 0;
                 if (lane < m) {
-                    const FaceRec &fr = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FREC);
+                    const FaceRec &fr = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FSTR);
                     const int xi_lo = (int)ceilf(((fr.xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((fr.xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
                     const int yi_lo = (int)ceilf(((fr.ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((fr.ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
                     const int bx0 = max(a.S - 1 - xi_hi - tx * TILE, sx0), bx1 = min(a.S - 1 - xi_lo - tx * TILE, sx1);
@@ -537,7 +570,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const int dy = (int)((float)rr * __builtin_amdgcn_rcpf((float)bw) + 1e-3f);  // rr < 64, bw <= 8: exact
                     const int p = (((((pk >> 16) & 7) + dy) << 3) + ((pk >> 13) & 7) + (rr - dy * bw)) & 63;
                     const float4 pt = lds.pixt[p];
-                    const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FREC);
+                    const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FSTR);
                     PairEval e;
                     eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
                     const bool cand = valid && e.cand;
@@ -828,7 +861,8 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
     // tile boxes (N,F), counters, work list (N, tiles), per-face depth ranges (N,F), per-workgroup scratch
     return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) +
-           align256((size_t)N * m->F * sizeof(float2)) + 256 + scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
+           align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) + 256 +
+           scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
@@ -850,11 +884,13 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint32_t));
     float2 *fzr = (float2 *)ws;
     ws += align256((size_t)N * m->F * sizeof(float2));
+    uint32_t *gbox = (uint32_t *)ws;
+    ws += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_words = (tiles_x * tiles_x + 31) / 32;
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), (size_t)(n_words + 256) * sizeof(uint32_t), stream, verts_ndc,
-                       m->faces, tbox, items, fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+                       m->faces, tbox, gbox, items, fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
@@ -873,7 +909,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
         a.scmeta = (uint32_t *)ws;
     }
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.items = items; a.fzr = fzr; a.ctr = ctr;
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.fzr = fzr; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;

@@ -180,7 +180,7 @@ def main():
         achieved = (n_img * per_view) / (kern_avg_ms * 1e-3) / 1e9 if kern_n else 0.0
         iter_bytes = frames * (per_frame + views * per_view)
         traffic = None
-        tpath = os.path.join(REPO, "profiles", "r1e_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r1f_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath)).get(args.workload)
             if tj and tj["images_per_launch"] == n_img:
@@ -204,13 +204,13 @@ def main():
                        "weights": synthetic.STAGE1_WEIGHTS, "w_temporal": synthetic.STAGE1_TEMPORAL, "faces_per_pixel": 100,
                        "parallelism": f"frames sharded x{world}, all-reduce of shared-parameter gradients"},
             "final_loss": loss,
-            "roofline": {"bound": "hbm", "kernel": "k_raster_tiles<FUSED> (soft silhouette fwd + L1 + bwd)",
+            "roofline": {"bound": "hbm", "kernel": "k_raster_dense<FUSED> (soft silhouette fwd + L1 + bwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1e_traffic.json" if traffic else None,
+                         "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1f_traffic.json" if traffic else None,
                          "algorithmic_bytes_per_launch": n_img * per_view, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_image": per_view,
                          "iteration_frac": (iter_bytes / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
-                         "note": "VALU-bound (K=100 nearest-depth selection per pixel), not HBM-bound: see DESIGN.md"},
+                         "note": "the kernel trades HBM traffic for arithmetic: each (face, pixel) pair is evaluated once and its 28-byte record re-read by the selection / blend / gradient sweeps, so measured traffic is ~10x the algorithmic bytes and the VALU pipes are ~50% busy; see DESIGN.md section 6"},
         }
         if world == 1 and args.cpu_frames != 0:
             n_cpu = args.cpu_frames if args.cpu_frames > 0 else max(1, 32 // views)

@@ -9,8 +9,9 @@
 // Design (see DESIGN.md "raster"):
 //  * The reference visits all F faces for all S^2 pixels and stores (S,S,K) fragments in HBM (157 MB / image at 256^2).
 //  * k_raster_setup (one workgroup per image): per-face validity + blurred bbox in 8x8-pixel tile units (4 x u8 packed),
-//    a tile-occupancy bitmap in LDS, and the compacted list of touched tiles appended to a global work list.  Untouched
-//    tiles are never visited (their silhouette is 0).
+//    the union of those boxes per 64 consecutive faces, per-face vertex-depth range, a tile-occupancy bitmap in LDS, and
+//    the compacted list of touched tiles appended to a global work list.  Untouched tiles are never visited (their
+//    silhouette is 0).
 //  * k_raster_dense (persistent single-wave workgroups, work item = one 8x8 tile).  Every (face, pixel) pair is
 //    evaluated ONCE, by a lane that exists only for pairs inside the face's pixel box; every later step is a dense sweep
 //    (lane = record) over the records that pass produced.  An earlier design (lane = pixel, each face broadcast to the 64
@@ -126,36 +127,36 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
         const int f = f0 + threadIdx.x;
         uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
         if (f < F) {
-        const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-        const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
-        const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
-        const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
-        const float zmin = fminf(fminf(z0, z1), z2);
-        const float area = edge_fn(x0, y0, x1, y1, x2, y2);
-        const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
-        if (finite && !(zmin < K_EPS) && !(area <= K_EPS && area >= -K_EPS)) {
-            const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
-            const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
-            // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
-            // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides
-            int xi_lo = (int)ceilf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-            int yi_lo = (int)ceilf(((ylo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((yhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-            xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
-            xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
-            if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
-                // output column xo = S-1-xi
-                const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
-                const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
-                box = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-                for (int ty = ty0; ty <= ty1; ++ty)
-                    for (int tx = tx0; tx <= tx1; ++tx) {
-                        const int t = ty * tiles_x + tx;
-                        atomicOr(&bitmap[t >> 5], 1u << (t & 31));
-                    }
+            const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+            const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
+            const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
+            const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
+            const float zmin = fminf(fminf(z0, z1), z2);
+            const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+            const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
+            if (finite && !(zmin < K_EPS) && !(area <= K_EPS && area >= -K_EPS)) {
+                const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
+                const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
+                // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
+                // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides
+                int xi_lo = (int)ceilf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+                int yi_lo = (int)ceilf(((ylo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((yhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+                xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
+                xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
+                if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
+                    // output column xo = S-1-xi
+                    const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
+                    const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
+                    box = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) {
+                            const int t = ty * tiles_x + tx;
+                            atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+                        }
+                }
             }
-        }
-        tbox[(size_t)n * F + f] = box;
-        fzr[(size_t)n * F + f] = make_float2(zmin, fmaxf(fmaxf(z0, z1), z2));
+            tbox[(size_t)n * F + f] = box;
+            fzr[(size_t)n * F + f] = make_float2(zmin, fmaxf(fmaxf(z0, z1), z2));
         }
         // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test
         int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
@@ -508,10 +509,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 
         // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
         // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
-#ifndef SPAN0
-#define SPAN0 WAVE
-#endif
-        int span = SPAN0;
+        int span = WAVE;
         while (span > 1 && (long long)span * list_total > 4ll * REC_CAP) span >>= 1;
         for (int p_lo = 0; p_lo < WAVE;) {
             const bool mine = lane >= p_lo && lane < p_lo + span;  // this lane's pixel belongs to the sub-tile
@@ -551,9 +549,6 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
                 packed |= off;                      // off <= DCHUNK * 64
                 if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
-#ifdef DBG_TIMERS
-                { const unsigned long long now_ = __builtin_readcyclecounter(); tph[5] += now_ - tlast; tlast = now_; tph[6] += (unsigned long long)((n_pairs + 63) / 64); tph[7] += 1ull; }
-#endif
                 int carry = 0;                      // face (+1) of the last lane of the previous sweep step
                 for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
                     // pair -> face: faces whose run starts inside this step mark their start, max-scan spreads it
@@ -919,8 +914,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 64); (void)hipMemset(dbg_dev, 0, 64); }
         unsigned long long h[8];
         (void)hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost);  // totals of the launches so far
-        fprintf(stderr, "[dbg timers] list %.3e  p1 %.3e  select %.3e  p2 %.3e  p3 %.3e cycles; p1 staging %.3e (not in p1) steps %.3e chunks %.3e\n",
-                (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)h[5], (double)h[6], (double)h[7]);
+        fprintf(stderr, "[dbg timers] list %.3e  pass1 %.3e  select %.3e  pass2 %.3e  pass3 %.3e cycles (summed over waves)\n",
+                (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4]);
         (void)hipMemset(dbg_dev, 0, 64);
         a.dbg = dbg_dev;
     }

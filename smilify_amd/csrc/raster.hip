@@ -66,8 +66,16 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #define TIMERS_FLUSH
 #endif
 
+// Work items (touched tiles) are queued in four cost classes by the number of faces that reach the tile, and handed out
+// heaviest class first: a persistent kernel whose longest item takes a third of the whole launch must not start it last.
+// Two arrays of N * tiles entries hold two classes each (one filled from the front, one from the back).
+#define N_CLASSES 4
+#define CLASS_T0 2048
+#define CLASS_T1 1024
+#define CLASS_T2 384
+#define COUNT_TILES_MAX 8192  // per-tile face counts live in LDS (4 bytes each); larger images queue everything in the last class
 struct RasterCounters {
-    unsigned int n_items;
+    unsigned int n_class[N_CLASSES];
     unsigned int next;
 };
 
@@ -76,7 +84,8 @@ struct RasterArgs {
     const int *faces;        // (F,3)
     const uint32_t *tbox;    // (N,F) tile box of every face
     const uint32_t *gbox;    // (N, ceil(F/64)) union of the tile boxes of 64 consecutive faces
-    const uint32_t *items;   // work list
+    const uint32_t *items;   // work lists: [0, cap) classes 0 (front) / 1 (back), [cap, 2 cap) classes 2 / 3
+    uint32_t item_cap;       // N * tiles
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
@@ -111,14 +120,14 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
-                                                      uint32_t *__restrict__ items, float2 *__restrict__ fzr, RasterCounters *ctr, int V, int F, int S,
-                                                      int tiles_x, float sqrt_blur) {
-    extern __shared__ uint32_t bitmap[];  // tiles_x*tiles_x bits, then 256 scan slots
+                                                      uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
+                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur) {
+    extern __shared__ uint32_t tcnt[];  // faces per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
     const int n_tiles = tiles_x * tiles_x;
-    const int n_words = (n_tiles + 31) >> 5;
-    uint32_t *scan = bitmap + n_words;
-    for (int i = threadIdx.x; i < n_words; i += blockDim.x) bitmap[i] = 0u;
+    const bool counted = n_tiles <= COUNT_TILES_MAX;
+    const int n_words = counted ? n_tiles : (n_tiles + 31) >> 5;
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) tcnt[i] = 0u;
     __syncthreads();
     const float *vn = verts_ndc + (size_t)n * V * 3;
     const float fS = (float)S;
@@ -151,7 +160,8 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
                     for (int ty = ty0; ty <= ty1; ++ty)
                         for (int tx = tx0; tx <= tx1; ++tx) {
                             const int t = ty * tiles_x + tx;
-                            atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+                            if (counted) atomicAdd(&tcnt[t], 1u);
+                            else atomicOr(&tcnt[t >> 5], 1u << (t & 31));
                         }
                 }
             }
@@ -169,26 +179,39 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
             gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
     __syncthreads();
-    // ordered compaction of touched tiles -> global work list
-    uint32_t mine = 0;
-    for (int w = threadIdx.x; w < n_words; w += blockDim.x) mine += __popc(bitmap[w]);
-    scan[threadIdx.x] = mine;
+    // touched tiles -> the work list of their cost class
+    __shared__ uint32_t s_cnt[N_CLASSES], s_base[N_CLASSES];
+    if (threadIdx.x < N_CLASSES) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    __shared__ uint32_t base_slot;
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < (int)blockDim.x; ++i) { const uint32_t c = scan[i]; scan[i] = run; run += c; }
-        base_slot = run ? atomicAdd(&ctr->n_items, run) : 0u;
+    auto tile_class = [&](int t) -> int {  // -1: untouched
+        if (!counted) return ((tcnt[t >> 5] >> (t & 31)) & 1u) ? N_CLASSES - 1 : -1;
+        const uint32_t c = tcnt[t];
+        return c == 0u ? -1 : (c >= CLASS_T0 ? 0 : (c >= CLASS_T1 ? 1 : (c >= CLASS_T2 ? 2 : 3)));
+    };
+    uint32_t mine[N_CLASSES] = {0u, 0u, 0u, 0u};
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int c = tile_class(t);
+#pragma unroll
+        for (int k = 0; k < N_CLASSES; ++k) mine[k] += (c == k) ? 1u : 0u;
     }
+    uint32_t off[N_CLASSES];
+#pragma unroll
+    for (int k = 0; k < N_CLASSES; ++k) off[k] = mine[k] ? atomicAdd(&s_cnt[k], mine[k]) : 0u;
     __syncthreads();
-    uint32_t pos = base_slot + scan[threadIdx.x];
-    for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
-        uint32_t bits = bitmap[w];
-        while (bits) {
-            const int bit = __ffs(bits) - 1;
-            bits &= bits - 1;
-            items[pos++] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)(w * 32 + bit);
-        }
+    if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr->n_class[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N_CLASSES; ++k) off[k] += s_base[k];
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int c = tile_class(t);
+        if (c < 0) continue;
+        uint32_t slot = 0u;
+#pragma unroll
+        for (int k = 0; k < N_CLASSES; ++k)
+            if (c == k) slot = off[k]++;
+        // classes 0 and 2 grow from the front of their array, 1 and 3 from the back
+        const uint32_t idx = (uint32_t)(c >> 1) * item_cap + ((c & 1) ? item_cap - 1u - slot : slot);
+        items[idx] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
     }
 }
 
@@ -477,7 +500,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     uint32_t *const scmeta = a.scmeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
-    const unsigned int n_items = a.ctr->n_items;
+    const unsigned int nc0 = a.ctr->n_class[0], nc1 = a.ctr->n_class[1], nc2 = a.ctr->n_class[2], nc3 = a.ctr->n_class[3];
+    const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
     const float fS = (float)a.S;
 
     TIMERS_INIT
@@ -486,7 +510,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         if (lane == 0) item = atomicAdd(&a.ctr->next, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
-        const uint32_t code = a.items[item];
+        // heaviest class first
+        const uint32_t code = item < nc0 ? a.items[item]
+                            : item < nc0 + nc1 ? a.items[a.item_cap - 1u - (item - nc0)]
+                            : item < nc0 + nc1 + nc2 ? a.items[a.item_cap + (item - nc0 - nc1)]
+                            : a.items[2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2)];
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
@@ -854,8 +882,8 @@ static inline size_t scratch_bytes(int grid, int F) {
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    // tile boxes (N,F), counters, work list (N, tiles), per-face depth ranges (N,F), per-workgroup scratch
-    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)N * tiles * sizeof(uint32_t)) +
+    // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), per-workgroup scratch
+    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)2 * N * tiles * sizeof(uint32_t)) +
            align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) + 256 +
            scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
@@ -876,16 +904,18 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
     ws += 256;
     uint32_t *items = (uint32_t *)ws;
-    ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint32_t));
+    const uint32_t item_cap = (uint32_t)N * (uint32_t)(tiles_x * tiles_x);
+    ws += align256((size_t)2 * item_cap * sizeof(uint32_t));
     float2 *fzr = (float2 *)ws;
     ws += align256((size_t)N * m->F * sizeof(float2));
     uint32_t *gbox = (uint32_t *)ws;
     ws += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
-    const int n_words = (tiles_x * tiles_x + 31) / 32;
-    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), (size_t)(n_words + 256) * sizeof(uint32_t), stream, verts_ndc,
-                       m->faces, tbox, gbox, items, fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+    const int n_tiles = tiles_x * tiles_x;
+    const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
+                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
@@ -904,7 +934,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
         a.scmeta = (uint32_t *)ws;
     }
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.fzr = fzr; a.ctr = ctr;
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;

@@ -44,14 +44,15 @@ dt = (time.perf_counter() - t0) / args.reps
 ws = dm._ws
 off = ((N * dm.F * 4 + 255) // 256) * 256
 ctr = ws[off:off + 16].view(torch.int32).cpu().numpy()
+n_work = int(ctr[:4].sum())
 tb = ws[: N * dm.F * 4].view(torch.int32).reshape(N, dm.F).cpu().numpy().astype(np.uint32)
 tx0, ty0, tx1, ty1 = tb & 255, (tb >> 8) & 255, (tb >> 16) & 255, tb >> 24
 valid = tx0 <= tx1
 tiles_per_face = np.where(valid, (tx1.astype(int) - tx0 + 1) * (ty1.astype(int) - ty0 + 1), 0)
-print(f"handed over to the re-evaluating kernel: {ctr[2]} tiles")
-print(f"images {N}  time/launch {dt*1e3:.2f} ms  {dt/N*1e6:.1f} us/image  work items {ctr[0]} ({ctr[0]/N:.1f} tiles/image)  "
+print(f"work items per cost class (faces >= 2048 / 1024 / 384 / rest): {ctr[:4].tolist()}")
+print(f"images {N}  time/launch {dt*1e3:.2f} ms  {dt/N*1e6:.1f} us/image  work items {n_work} ({n_work/N:.1f} tiles/image)  "
       f"valid faces/image {valid.sum(1).mean():.0f}  (tile,face) pairs/image {tiles_per_face.sum(1).mean():.0f}  "
-      f"avg list length {tiles_per_face.sum()/max(ctr[0],1):.0f}")
+      f"avg list length {tiles_per_face.sum()/max(n_work,1):.0f}")
 # distribution of per-tile list lengths (faces whose tile box contains the tile)
 T = (args.S + 7) // 8
 import collections

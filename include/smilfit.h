@@ -236,6 +236,11 @@ int smil_sil_objective(const float *loss_img, const float *pix_scale, int32_t N,
 /* torch.optim.Adam semantics (no amsgrad, no weight decay). step = 1-based step count. */
 int smil_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, int32_t step, void *stream);
+/* Same update with the step count read from device memory: step = *step_dev - step_offset.  Lets a whole fit iteration be
+ * captured once in a hipGraph and replayed (the host only bumps the counter - or the graph does, with an increment node). */
+int smil_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, const int32_t *step_dev, int32_t step_offset,
+                       void *stream);
 
 #ifdef __cplusplus
 }

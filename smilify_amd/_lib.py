@@ -17,7 +17,8 @@ EXPORTS = [
     "smil_lbs_forward", "smil_lbs_backward", "smil_project", "smil_project_backward", "smil_fov_reduce",
     "smil_raster_workspace_bytes", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
-    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_profile_enable", "smil_profile_read",
+    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_adam_step_dev", "smil_profile_enable",
+    "smil_profile_read",
 ]
 
 N_OBJS = 10
@@ -110,6 +111,8 @@ def load():
     lib.smil_sil_objective.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
     lib.smil_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                    c_int32, c_void_p]
+    lib.smil_adam_step_dev.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                       c_void_p, c_int32, c_void_p]
     lib.smil_profile_enable.argtypes = [c_int32]
     lib.smil_profile_read.argtypes = [POINTER(c_float), POINTER(c_int32)]
     for name in EXPORTS:

@@ -270,6 +270,32 @@ __global__ void __launch_bounds__(256) k_adam(float *__restrict__ p, const float
     }
 }
 
+__global__ void __launch_bounds__(256) k_adam_dev(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                  float *__restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                  const int *__restrict__ step_dev, int step_offset) {
+    const float t = (float)(*step_dev - step_offset);
+    const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int smil_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, const int32_t *step_dev, int32_t step_offset,
+                                  void *stream_) {
+    SMIL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev, "smil_adam_step_dev: bad argument");
+    const int grid = (int)std::min<long long>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(k_adam_dev, dim3(grid), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq, (long long)n,
+                       lr, beta1, beta2, eps, step_dev, step_offset);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
 extern "C" int smil_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, int32_t step, void *stream_) {
     SMIL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "smil_adam_step: bad argument");

@@ -502,14 +502,20 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     const int n_tiles = a.tiles_x * a.tiles_x;
     const unsigned int nc0 = a.ctr->n_class[0], nc1 = a.ctr->n_class[1], nc2 = a.ctr->n_class[2], nc3 = a.ctr->n_class[3];
     const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
+    // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
+    // the launch finishes in a fraction of one tile's serial time.
+    const unsigned int split_log = n_items * 8u <= gridDim.x ? 3u : (n_items * 4u <= gridDim.x ? 2u : (n_items * 2u <= gridDim.x ? 1u : 0u));
+    const unsigned int n_units = n_items << split_log;
     const float fS = (float)a.S;
 
     TIMERS_INIT
     while (true) {
-        unsigned int item = 0;
-        if (lane == 0) item = atomicAdd(&a.ctr->next, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
+        unsigned int unit = 0;
+        if (lane == 0) unit = atomicAdd(&a.ctr->next, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= n_units) break;
+        const unsigned int item = unit >> split_log;
+        const int p_begin = (int)(unit & ((1u << split_log) - 1u)) * (WAVE >> split_log), p_end = p_begin + (WAVE >> split_log);
         // heaviest class first
         const uint32_t code = item < nc0 ? a.items[item]
                             : item < nc0 + nc1 ? a.items[a.item_cap - 1u - (item - nc0)]
@@ -537,9 +543,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 
         // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
         // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
-        int span = WAVE;
+        int span = p_end - p_begin;
         while (span > 1 && (long long)span * list_total > 4ll * REC_CAP) span >>= 1;
-        for (int p_lo = 0; p_lo < WAVE;) {
+        for (int p_lo = p_begin; p_lo < p_end;) {
             const bool mine = lane >= p_lo && lane < p_lo + span;  // this lane's pixel belongs to the sub-tile
             const int sy0 = p_lo >> 3, sy1 = (p_lo + span - 1) >> 3;                       // its rows ...
             const int sx0 = span >= 8 ? 0 : (p_lo & 7), sx1 = span >= 8 ? 7 : ((p_lo & 7) + span - 1);  // ... and columns

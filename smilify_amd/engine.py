@@ -350,6 +350,12 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.5, beta2=0.999
                                           beta2, eps, step, _stream()), "smil_adam_step")
 
 
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr, step_dev, step_offset=0, beta1=0.5, beta2=0.999, eps=1e-8):
+    """Adam update whose step count is ``step_dev[0] - step_offset`` (int32 device tensor): capturable in a hipGraph."""
+    _lib.check(_lib.load().smil_adam_step_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1,
+                                              beta2, eps, _ptr(step_dev), int(step_offset), _stream()), "smil_adam_step_dev")
+
+
 def profile_enable(on: bool) -> None:
     _lib.check(_lib.load().smil_profile_enable(int(on)), "smil_profile_enable")
 

@@ -415,6 +415,7 @@ class SMALFitter(nn.Module):
         self._adam = {}
         self._adam_step = 0
         self._adam_hyper = dict(lr=float(lr), fov_lr=float(fov_lr), betas=betas, eps=eps)
+        self._graph = None  # a captured iteration belongs to one stage
 
     def _param_tensor(self, name: str) -> torch.Tensor:
         return self._pose if name == "pose" else getattr(self, name).data
@@ -446,6 +447,61 @@ class SMALFitter(nn.Module):
             shared_grad_hook(shared, objs)
         self.apply_adam(grads)
         return objs
+
+    # ---- the same epoch as one hipGraph: ~40 kernel launches replayed with a single call --------------------
+    def _graph_key(self, weights, w_temp, window):
+        flags = tuple(bool(getattr(self, n).requires_grad) for n in
+                      ("betas", "log_beta_scales", "betas_trans", "global_rotation", "joint_rotations", "trans", "fov"))
+        return (tuple(float(w) for w in weights), float(w_temp), window, flags, self._target_signature)
+
+    def fit_step_graph(self, weights, w_temp: float, window: Optional[int] = None):
+        """``fit_step`` for a single rank, captured once per (stage, weights) in a hipGraph (``torch.cuda.CUDAGraph``)
+        and replayed afterwards.  Worth it when the iteration is launch-bound (few frames); results are identical.
+        Returns objs (10,) in a buffer that the next replay overwrites."""
+        window = self.config.WINDOW_SIZE if window is None else window
+        if self._targets_dirty or self._signature() != self._target_signature:
+            self._refresh_targets()
+        key = self._graph_key(weights, w_temp, window)
+        g = getattr(self, "_graph", None)
+        if g is None or g["key"] != key:
+            g = self._capture_step(weights, w_temp, window, key)
+        if g["t_mirror"] != self._adam_step:  # eager steps in between: bring the device counter back in line
+            self._adam_t.fill_(self._adam_step)
+        self._adam_step += 1
+        g["t_mirror"] = self._adam_step
+        g["graph"].replay()
+        return g["objs"]
+
+    def _capture_step(self, weights, w_temp, window, key):
+        dev = self.device
+        if not hasattr(self, "_adam_t"):
+            self._adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        h = self._adam_hyper
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            # eager dry run (no parameter update): sizes the rasteriser workspace and tells which parameters get a gradient
+            _, grads = self._loss_and_grads(None, weights, w_temp, window=window)
+            for name, gr in grads.items():
+                if gr is not None and name not in self._adam:
+                    p = self._param_tensor(name)
+                    self._adam[name] = dict(m=torch.zeros_like(p), v=torch.zeros_like(p), t0=self._adam_step)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._adam_t.fill_(self._adam_step)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._adam_t.add_(1)
+            objs, grads = self._loss_and_grads(None, weights, w_temp, window=window)
+            for name, gr in grads.items():
+                if gr is None:
+                    continue
+                st = self._adam[name]
+                lr = h["fov_lr"] if name == "fov" else h["lr"]
+                engine.adam_step_dev(self._param_tensor(name), gr.contiguous(), st["m"], st["v"], lr, self._adam_t, st["t0"],
+                                     h["betas"][0], h["betas"][1], h["eps"])
+        self._graph = dict(key=key, graph=graph, objs=objs, t_mirror=self._adam_step)
+        return self._graph
 
     def _is_shared(self, name: str) -> bool:
         if name in ("betas",):

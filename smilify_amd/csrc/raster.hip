@@ -314,23 +314,33 @@ struct alignas(16) DenseLds {
     float4 pixt[WAVE];               // px, py, px - cx, py - cy
     float4 pgrad[WAVE];              // passes 2/3: {gradient coefficient, threshold depth bits, last kept list position, -}
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
-    int start[WAVE];                 // pair -> face mapping scratch
+    int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run
 };
 static_assert(sizeof(double) * (GCHUNK * 6 + WAVE) <= sizeof(float) * DCHUNK * FSTR, "pass 2/3 accumulators must fit the record buffer");
+
+// Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
+// VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
+template <typename T>
+__device__ __forceinline__ T &at(T *base, uint32_t i) {
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
+}
+template <typename T>
+__device__ __forceinline__ const T &at(const T *base, uint32_t i) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
+}
 
 // Single-wave workgroups: lanes exchange data through LDS without s_barrier, but the compiler must not forward a lane's
 // own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
 // outstanding global stores (vmcnt), which in pass 1 would stall every sweep step on the previous step's record stores.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// inclusive wave64 scans in DPP (row_shr within 16-lane rows, then row_bcast across rows)
-template <bool IS_MAX>
-__device__ __forceinline__ int wave_scan(int x) {
-#define SCAN_STEP(ctrl, rows) { const int t_ = __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); x = IS_MAX ? max(x, t_) : x + t_; }
+// inclusive wave64 prefix sum in DPP (row_shr within 16-lane rows, then row_bcast across rows)
+__device__ __forceinline__ int wave_scan_add(int x) {
+#define SCAN_STEP(ctrl, rows) { x += __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); }
     SCAN_STEP(0x111, 0xF) SCAN_STEP(0x112, 0xF) SCAN_STEP(0x114, 0xF) SCAN_STEP(0x118, 0xF)
     SCAN_STEP(0x142, 0xA) SCAN_STEP(0x143, 0xC)
 #undef SCAN_STEP
-    return x;  // IS_MAX assumes non-negative inputs (identity 0)
+    return x;
 }
 
 // Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the nearest /
@@ -458,8 +468,8 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
     auto load_keys = [&](uint32_t (&kk)[KGROUP], uint32_t (&mt)[KGROUP], int g0) {
 #pragma unroll
         for (int u = 0; u < KGROUP; ++u) {
-            const int idx = min(g0 + u * WAVE + lane, n_rec - 1);
-            mt[u] = meta[idx];
+            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_rec - 1);  // unsigned 32-bit: SGPR base + VGPR offset addressing
+            mt[u] = at(meta, idx);
             kk[u] = key_of(idx, mt[u]);
         }
     };
@@ -498,6 +508,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     uint32_t *const smeta = a.smeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     uint32_t *const skey = a.skey + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     uint32_t *const scmeta = a.scmeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
     const unsigned int nc0 = a.ctr->n_class[0], nc1 = a.ctr->n_class[1], nc2 = a.ctr->n_class[2], nc3 = a.ctr->n_class[3];
@@ -578,22 +589,38 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         packed = (bx0 << 13) | (by0 << 16) | ((bx1 - bx0) << 19);
                     }
                 }
-                const int incl = wave_scan<false>(cf);
+                const int incl = wave_scan_add(cf);
                 const int off = incl - cf;          // first pair of this face in the chunk's pair list
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
                 packed |= off;                      // off <= DCHUNK * 64
                 if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
-                int carry = 0;                      // face (+1) of the last lane of the previous sweep step
+                // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
+                // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
+                // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
+                // (start bits at or below its lane) - 1, two v_mbcnt and one ds_bpermute away.
+                const unsigned long long nonempty = __ballot(cf > 0);
+                lds.start[lane] = 0;
+                lds_fence();
+                if (cf > 0) {
+                    atomicOr(reinterpret_cast<uint32_t *>(lds.start) + (off >> 5), 1u << (off & 31));
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nonempty >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nonempty, 0u));
+                    reinterpret_cast<uint32_t *>(lds.psel)[rank] = (uint32_t)packed | ((uint32_t)lane << 22);
+                }
+                lds_fence();
+                const uint32_t fl_lo = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane) & 63];
+                const uint32_t fl_hi = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane + 1) & 63];
+                const int pk_rank = (int)reinterpret_cast<const uint32_t *>(lds.psel)[lane & (DCHUNK - 1)];
+                lds_fence();
+                uint32_t carry = 0;                 // faces started before this step
                 for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
-                    // pair -> face: faces whose run starts inside this step mark their start, max-scan spreads it
-                    lds.start[lane] = 0;
-                    if (cf > 0 && off >= q0 && off < q0 + WAVE) lds.start[off - q0] = lane + 1;
-                    lds_fence();  // other lanes' stores: without it the compiler forwards this lane's own 0
-                    const int fi = max(wave_scan<true>(lds.start[lane]), carry);
-                    carry = __builtin_amdgcn_readlane(fi, 63);
+                    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)fl_lo, q0 >> 6), whi = (uint32_t)__builtin_amdgcn_readlane((int)fl_hi, q0 >> 6);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+                    const uint32_t own = ((wlo & lane_lo) | (whi & lane_hi)) ? 1u : 0u;
+                    const int r = min((int)(carry + below + own) - 1, DCHUNK - 1);
+                    carry += (uint32_t)(__popc(wlo) + __popc(whi));
                     const bool valid = q0 + lane < n_pairs;
-                    const int fs = max(fi - 1, 0);
-                    const int pk = __shfl(packed, fs, WAVE);
+                    const int pk = __shfl(pk_rank, max(r, 0), WAVE);
+                    const int fs = (pk >> 22) & (DCHUNK - 1);
                     const int rr = q0 + lane - (pk & 0x1FFF);
                     const int bw = ((pk >> 19) & 7) + 1;
                     const int dy = (int)((float)rr * __builtin_amdgcn_rcpf((float)bw) + 1e-3f);  // rr < 64, bw <= 8: exact
@@ -610,11 +637,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const uint32_t zb = __float_as_uint(z);
                     // 3 code bits (inside, edge) replace the low mantissa bits of t in [0,1] (<= 4e-7 relative)
                     const uint32_t tb = (__float_as_uint(e.t) & ~7u) | (e.inside ? 1u : 0u) | ((uint32_t)e.edge << 1);
-                    const int slot = vbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (cand) {
-                        sval[slot] = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
-                        smeta[slot] = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
-                        skey[slot] = zb - kmin;
+                        at(sval, slot) = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
+                        at(smeta, slot) = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
+                        at(skey, slot) = zb - kmin;
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
@@ -657,19 +684,19 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         uint32_t kk[DGROUP], mt[DGROUP];
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
-                            const int idx = min(g0 + u * WAVE + lane, vbase - 1);
-                            kk[u] = skey[idx];
-                            mt[u] = smeta[idx];
+                            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
+                            kk[u] = at(skey, idx);
+                            mt[u] = at(smeta, idx);
                         }
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const uint2 ps = lds.psel[mt[u] & 63u];
                             const bool keep = (g0 + u * WAVE + lane < vbase) & (ps.y > 0u) & ((kk[u] >> nbits) == ps.x);
                             const unsigned long long km = __ballot(keep);
-                            const int slot = n_cmp + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                            const uint32_t slot = (uint32_t)n_cmp + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
                             if (keep) {  // in place: slot <= index of the record being read
-                                skey[slot] = kk[u];
-                                scmeta[slot] = mt[u];
+                                at(skey, slot) = kk[u];
+                                at(scmeta, slot) = mt[u];
                                 const uint32_t bucket = (kk[u] >> shift2) & ((1u << b2) - 1u);
                                 atomicAdd(&lds.hist[(bucket >> 1) * WAVE + (mt[u] & 63u)], (bucket & 1u) ? 0x10000u : 1u);
                             }
@@ -682,7 +709,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         nbits -= b2;
                         __syncthreads();
                     }
-                    auto depth_key = [&](int idx, uint32_t) { return skey[idx]; };
+                    auto depth_key = [&](uint32_t idx, uint32_t) { return at(skey, idx); };
                     while (nbits > 0 && __ballot(need > 0) != 0ull) {
                         const int b = min(SEL_BITS, nbits);
                         select_sweep(lds, scmeta, n_cmp, nbits, b, lane, pre, need, depth_key);
@@ -700,9 +727,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         int pbits = 32 - __clz(max(list_total - 1, 1));
                         uint32_t ppre = 0u;
                         int pneed = split ? need : 0, peq = 0;
-                        auto pos_key = [&](int idx, uint32_t mt) {
+                        auto pos_key = [&](uint32_t idx, uint32_t mt) {
                             // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
-                            return skey[idx] == __float_as_uint(lds.pgrad[mt & 63u].y) ? (mt >> 6) : 0xFFFFFFFFu;
+                            return at(skey, idx) == __float_as_uint(lds.pgrad[mt & 63u].y) ? (mt >> 6) : 0xFFFFFFFFu;
                         };
                         while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
                             const int b = min(SEL_BITS, pbits);
@@ -725,9 +752,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
-                        const int idx = min(g0 + u * WAVE + lane, vbase - 1);
-                        v[u] = sval[idx];
-                        mt[u] = smeta[idx];
+                        const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
+                        v[u] = at(sval, idx);
+                        mt[u] = at(smeta, idx);
                     }
                 };
                 auto log_recs = [&](const float4 (&v)[DGROUP], const uint32_t (&mt)[DGROUP], int g0) {
@@ -803,9 +830,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
-                            const int idx = min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
-                            v[u] = sval[idx];
-                            mt[u] = smeta[idx];
+                            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
+                            v[u] = at(sval, idx);
+                            mt[u] = at(smeta, idx);
                         }
                     };
                     auto grad_recs = [&](const float4 (&v)[DGROUP], const uint32_t (&mt)[DGROUP], int g0) {

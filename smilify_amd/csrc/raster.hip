@@ -18,18 +18,21 @@
 //    pixels of the tile, three re-evaluating passes, K smallest depths in a sorted register array) spent ~75 % of its
 //    lanes on pairs that do not exist and 100 v_med3 per face on the selection; it is gone.
 //      pass 1  lane = pair.  Per DCHUNK-face chunk: lane = face computes its pixel box inside the tile, a prefix sum lays
-//              the boxes end to end, and the wave sweeps that pair list 64 at a time (face found with a scatter + max-scan,
-//              face record and pixel coordinates gathered from LDS).  Accepted pairs are ballot-compacted into the
-//              workgroup's record stream {depth, rx, ry, t|code}, {pixel | list position << 6}, {depth bits} in global
-//              memory (reused for every tile, so it lives in L2 / MALL).  The first radix digit of every depth is
-//              histogrammed on the way (the tile's depth range is known from the face list).
-//      select  (only if the tile lists more than K faces) K-th smallest depth of every pixel by radix select on the depth
-//              bits, SEL_BITS per sweep, per-pixel histograms in LDS.  After the first digit the records that can still
-//              matter are compacted, so the remaining sweeps touch a few rows.  Exact, including the number of faces tied
-//              at the threshold; when a tie group straddles K, further sweeps select on the list position (= face id).
-//      pass 2  log2 of every kept factor added to its pixel's LDS accumulator; alpha = exp2(sum) (the fp32 product and the
-//              fp64-accumulated log-sum are both ~1e-6 relative from the exact product).
-//      pass 3  gradient of every kept record into per-face LDS accumulators, flushed per chunk.
+//              the boxes end to end, and the wave sweeps that pair list 64 at a time (a start-bit map gives each pair its
+//              face with two v_mbcnt and one ds_bpermute; face record and pixel coordinates are gathered from LDS).
+//              Accepted pairs are ballot-compacted into the workgroup's record streams - depth, {pixel | list position |
+//              inside | edge}, rx, ry, t: five words, structure of arrays - in global memory (reused for every tile).  The
+//              first radix digit of every depth is histogrammed on the way (the tile's depth range is known from the list).
+//      blend   one sweep over the records (16 of the 20 bytes).  A record of a pixel with <= K candidates, or whose first
+//              digit lies below the digit that holds the pixel's K-th depth, is kept for certain: log2 of its factor is
+//              added to the pixel's sum (fp64 LDS atomics).  A record inside that digit goes on to a compact stream {key,
+//              meta, log} and has its second digit counted; one above it is dropped.
+//      select  (only where a pixel has more than K candidates) the remaining digits by radix select over the compact
+//              stream, SEL_BITS per sweep, per-pixel histograms in LDS.  Exact, including the number of faces tied at the
+//              threshold; when a tie group straddles K, further sweeps select on the list position (= face id).  A last
+//              sweep over the compact stream adds the logs of the records that made it; alpha = exp2(sum) (the fp32
+//              product and the fp64-accumulated log-sum are both ~1e-6 relative from the exact product).
+//      pass 3  gradient of every kept record into per-face LDS accumulators, flushed per 64 faces.
 //    LDS accumulators are fp64: ds_add_f64 runs at full rate on gfx950 while ds_add_f32 costs ~3 cycles per active lane.
 //  * A tile whose records would not fit the stream (REC_CAP) is processed in sub-tiles: power-of-two runs of its 64 pixels,
 //    halved until pass 1 fits.  A single pixel always fits because F <= REC_CAP is required on the host.
@@ -101,10 +104,13 @@ struct RasterArgs {
     // scratch per resident workgroup
     uint32_t *slist;         // F face ids of the current tile
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
-    float4 *sval;            // REC_CAP + REC_PAD records {depth, rx, ry, t | code}
-    uint32_t *smeta;         // pixel | list position << 6
-    uint32_t *skey;          // depth bits minus the tile's smallest (the selection sweeps read 8 instead of 20 bytes per record)
-    uint32_t *scmeta;        // meta of the records that survive the first selection digit (keys are compacted in place)
+    // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
+    uint32_t *sz;            // depth bits
+    uint32_t *smeta;         // pixel | list position << 6 | inside << 22 | closest edge << 23
+    float *srx, *sry, *st;   // closest point minus pixel, clamped edge parameter
+    // records that survive the first selection digit: key (depth bits - tile minimum), meta, log2 of the blend factor
+    uint32_t *ckey, *cmeta;
+    float *clf;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
 };
@@ -504,10 +510,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     const int lane = threadIdx.x;
     uint32_t *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
-    float4 *const sval = a.sval + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
-    uint32_t *const smeta = a.smeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
-    uint32_t *const skey = a.skey + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
-    uint32_t *const scmeta = a.scmeta + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    uint32_t *const sz = a.sz + rec0, *const smeta = a.smeta + rec0;
+    float *const srx = a.srx + rec0, *const sry = a.sry + rec0, *const st = a.st + rec0;
+    uint32_t *const ckey = a.ckey + rec0, *const cmeta = a.cmeta + rec0;
+    float *const clf = a.clf + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
@@ -635,13 +642,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
                     const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(pair_depth(fr, e)), kmin), kmax)) : 3.0e38f;
                     const uint32_t zb = __float_as_uint(z);
-                    // 3 code bits (inside, edge) replace the low mantissa bits of t in [0,1] (<= 4e-7 relative)
-                    const uint32_t tb = (__float_as_uint(e.t) & ~7u) | (e.inside ? 1u : 0u) | ((uint32_t)e.edge << 1);
                     const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (cand) {
-                        at(sval, slot) = make_float4(z, e.rx, e.ry, __uint_as_float(tb));
-                        at(smeta, slot) = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
-                        at(skey, slot) = zb - kmin;
+                        at(sz, slot) = zb;
+                        at(smeta, slot) = (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23);
+                        at(srx, slot) = e.rx;
+                        at(sry, slot) = e.ry;
+                        at(st, slot) = e.t;
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
@@ -660,128 +667,138 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             __syncthreads();  // also: record stores of other lanes are visible from here on
             TMARK(1)
 
-            // ---------------- select: K-th smallest depth of every pixel that has more than K candidates --------
-            // threshold: depth bits of the K-th smallest (0x7F800000 = +inf bits: keep everything); tie_cut: among the
-            // faces exactly at the threshold those up to this list position are kept
+            // ---------------- select + pass 2 ---------------------------------------------------------------------
+            // K-th smallest depth of every pixel that has more than K candidates, and log2 of every kept blend factor summed
+            // per pixel.  threshold: depth bits of the K-th smallest (0x7F800000 = +inf bits: keep everything); tie_cut: among
+            // the faces exactly at the threshold those up to this list position are kept.
             uint32_t zt_bits = 0x7F800000u;
             int tie_cut = 0x7FFFFFFF;
+            uint32_t pre = 0u;
+            int need = 0, n_eq = 0, nbits = nbits0 - b1;
+            bool trunc = false;
             if (may_truncate && vbase > 0) {
-                uint32_t pre = 0u;
-                int need = K, n_eq = 0;
+                need = K;
                 const int tot = pick_digit(lds.hist, lane, b1, pre, need, n_eq);
-                const bool trunc = tot > K;
+                trunc = tot > K;
                 if (!trunc) need = 0;
-                int nbits = nbits0 - b1;
-                if (__ballot(trunc) != 0ull) {
-                    // compaction: only the records of truncated pixels inside the chosen first digit go on; their second
-                    // digit is histogrammed in the same sweep
-                    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
-                    const int b2 = min(SEL_BITS, nbits), shift2 = nbits - b2;
-                    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
-                    __syncthreads();
-                    int n_cmp = 0;
-                    for (int g0 = 0; g0 < vbase; g0 += DGROUP * WAVE) {
-                        uint32_t kk[DGROUP], mt[DGROUP];
+            }
+            const bool any_trunc = __ballot(trunc) != 0ull;
+            // One sweep over all records.  A record of a pixel that is not truncated, or whose first digit is below the
+            // pixel's chosen one, is kept for certain: its log goes to the pixel's sum.  One inside the chosen digit goes on
+            // to the compact stream (with its log) and has its second digit counted; one above it is dropped.
+            lds.plog[lane] = 0.0;
+            lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+            const int b2 = min(SEL_BITS, nbits), shift2 = nbits - b2;
+            if (any_trunc)
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+            __syncthreads();
+            int n_cmp = 0;
+            if (vbase > 0) {
+                struct Rec { uint32_t z, mt; float rx, ry; };
+                auto load_recs = [&](Rec (&r)[DGROUP], int g0) {
 #pragma unroll
-                        for (int u = 0; u < DGROUP; ++u) {
-                            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
-                            kk[u] = at(skey, idx);
-                            mt[u] = at(smeta, idx);
-                        }
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
+                        r[u].z = at(sz, idx); r[u].mt = at(smeta, idx); r[u].rx = at(srx, idx); r[u].ry = at(sry, idx);
+                    }
+                };
+                auto blend_recs = [&](const Rec (&r)[DGROUP], int g0) {
+                    uint2 ps[DGROUP];
 #pragma unroll
-                        for (int u = 0; u < DGROUP; ++u) {
-                            const uint2 ps = lds.psel[mt[u] & 63u];
-                            const bool keep = (g0 + u * WAVE + lane < vbase) & (ps.y > 0u) & ((kk[u] >> nbits) == ps.x);
-                            const unsigned long long km = __ballot(keep);
+                    for (int u = 0; u < DGROUP; ++u) ps[u] = lds.psel[r[u].mt & 63u];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const bool valid = g0 + u * WAVE + lane < vbase;
+                        const uint32_t key = r[u].z - kmin, d1 = key >> nbits;
+                        const bool sure = valid & ((ps[u].y == 0u) | (d1 < ps[u].x));
+                        const bool maybe = valid & (ps[u].y > 0u) & (d1 == ps[u].x);
+                        const float dist = sq2(r[u].rx, r[u].ry);
+                        const float lf = __log2f(1.0f - face_prob(((r[u].mt >> 22) & 1u) ? -dist : dist, a.inv_sigma));
+                        if (sure & (lf != 0.f)) atomicAdd(&lds.plog[r[u].mt & 63u], (double)lf);
+                        if (any_trunc) {  // wave-uniform
+                            const unsigned long long km = __ballot(maybe);
                             const uint32_t slot = (uint32_t)n_cmp + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                            if (keep) {  // in place: slot <= index of the record being read
-                                at(skey, slot) = kk[u];
-                                at(scmeta, slot) = mt[u];
-                                const uint32_t bucket = (kk[u] >> shift2) & ((1u << b2) - 1u);
-                                atomicAdd(&lds.hist[(bucket >> 1) * WAVE + (mt[u] & 63u)], (bucket & 1u) ? 0x10000u : 1u);
+                            if (maybe) {
+                                at(ckey, slot) = key;
+                                at(cmeta, slot) = r[u].mt;
+                                at(clf, slot) = lf;
+                                const uint32_t bucket = (key >> shift2) & ((1u << b2) - 1u);
+                                atomicAdd(&lds.hist[(bucket >> 1) * WAVE + (r[u].mt & 63u)], (bucket & 1u) ? 0x10000u : 1u);
                             }
                             n_cmp += __popcll(km);
                         }
                     }
+                };
+                Rec ra[DGROUP], rb[DGROUP];
+                load_recs(ra, 0);
+                for (int g0 = 0; g0 < vbase; g0 += 2 * DGROUP * WAVE) {
+                    load_recs(rb, g0 + DGROUP * WAVE);
+                    blend_recs(ra, g0);
+                    load_recs(ra, g0 + 2 * DGROUP * WAVE);
+                    blend_recs(rb, g0 + DGROUP * WAVE);
+                }
+            }
+            __syncthreads();
+            if (any_trunc) {
+                if (nbits > 0) {  // second digit: counted above
+                    pick_digit(lds.hist, lane, b2, pre, need, n_eq);
+                    nbits -= b2;
                     __syncthreads();
-                    if (nbits > 0) {  // second digit: counted above
-                        pick_digit(lds.hist, lane, b2, pre, need, n_eq);
-                        nbits -= b2;
+                }
+                auto depth_key = [&](uint32_t idx, uint32_t) { return at(ckey, idx); };
+                while (nbits > 0 && __ballot(need > 0) != 0ull) {
+                    const int b = min(SEL_BITS, nbits);
+                    select_sweep(lds, cmeta, n_cmp, nbits, b, lane, pre, need, depth_key);
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
+                    nbits -= b;
+                    __syncthreads();
+                }
+                if (trunc) zt_bits = pre + kmin;
+                // `need` of the n_eq faces at the threshold are kept: the first ones in list order
+                const bool split = trunc && need < n_eq;
+                if (__ballot(split) != 0ull) {
+                    // select on the list position among the records whose depth equals the pixel's threshold
+                    lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
+                    __syncthreads();
+                    int pbits = 32 - __clz(max(list_total - 1, 1));
+                    uint32_t ppre = 0u;
+                    int pneed = split ? need : 0, peq = 0;
+                    auto pos_key = [&](uint32_t idx, uint32_t mt) {
+                        // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
+                        return at(ckey, idx) == __float_as_uint(lds.pgrad[mt & 63u].y) ? ((mt >> 6) & 0xFFFFu) : 0xFFFFFFFFu;
+                    };
+                    while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
+                        const int b = min(SEL_BITS, pbits);
+                        select_sweep(lds, cmeta, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
+                        pick_digit(lds.hist, lane, b, ppre, pneed, peq);
+                        pbits -= b;
                         __syncthreads();
                     }
-                    auto depth_key = [&](uint32_t idx, uint32_t) { return at(skey, idx); };
-                    while (nbits > 0 && __ballot(need > 0) != 0ull) {
-                        const int b = min(SEL_BITS, nbits);
-                        select_sweep(lds, scmeta, n_cmp, nbits, b, lane, pre, need, depth_key);
-                        pick_digit(lds.hist, lane, b, pre, need, n_eq);
-                        nbits -= b;
-                        __syncthreads();
+                    if (split) tie_cut = (int)ppre;
+                }
+                // the compact records that made it: depth below the threshold, or at it up to the tie cut
+                lds.pgrad[lane] = make_float4(0.f, __uint_as_float(trunc ? pre : 0u), __int_as_float(tie_cut), 0.f);
+                __syncthreads();
+                for (int g0 = 0; g0 < n_cmp; g0 += DGROUP * WAVE) {
+                    uint32_t kk[DGROUP], mt[DGROUP];
+                    float lf[DGROUP];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_cmp - 1);
+                        kk[u] = at(ckey, idx); mt[u] = at(cmeta, idx); lf[u] = at(clf, idx);
                     }
-                    if (trunc) zt_bits = pre + kmin;
-                    // `need` of the n_eq faces at the threshold are kept: the first ones in list order
-                    const bool split = trunc && need < n_eq;
-                    if (__ballot(split) != 0ull) {
-                        // select on the list position among the records whose depth equals the pixel's threshold
-                        lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
-                        __syncthreads();
-                        int pbits = 32 - __clz(max(list_total - 1, 1));
-                        uint32_t ppre = 0u;
-                        int pneed = split ? need : 0, peq = 0;
-                        auto pos_key = [&](uint32_t idx, uint32_t mt) {
-                            // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
-                            return at(skey, idx) == __float_as_uint(lds.pgrad[mt & 63u].y) ? (mt >> 6) : 0xFFFFFFFFu;
-                        };
-                        while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
-                            const int b = min(SEL_BITS, pbits);
-                            select_sweep(lds, scmeta, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
-                            pick_digit(lds.hist, lane, b, ppre, pneed, peq);
-                            pbits -= b;
-                            __syncthreads();
-                        }
-                        if (split) tie_cut = (int)ppre;
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const float4 pg = lds.pgrad[mt[u] & 63u];
+                        const uint32_t zt_ = __float_as_uint(pg.y);
+                        const bool keep = (g0 + u * WAVE + lane < n_cmp) &
+                                          ((kk[u] < zt_) | ((kk[u] == zt_) & ((int)((mt[u] >> 6) & 0xFFFFu) <= __float_as_int(pg.z))));
+                        if (keep & (lf[u] != 0.f)) atomicAdd(&lds.plog[mt[u] & 63u], (double)lf[u]);
                     }
                 }
+                __syncthreads();
             }
             TMARK(2)
-
-            // ---------------- pass 2: log2 of the kept factors, summed per pixel --------------------------------
-            lds.plog[lane] = 0.0;
-            lds.pgrad[lane] = make_float4(0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
-            __syncthreads();
-            if (vbase > 0) {
-                auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
-#pragma unroll
-                    for (int u = 0; u < DGROUP; ++u) {
-                        const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
-                        v[u] = at(sval, idx);
-                        mt[u] = at(smeta, idx);
-                    }
-                };
-                auto log_recs = [&](const float4 (&v)[DGROUP], const uint32_t (&mt)[DGROUP], int g0) {
-                    float4 pg[DGROUP];
-#pragma unroll
-                    for (int u = 0; u < DGROUP; ++u) pg[u] = lds.pgrad[mt[u] & 63u];
-#pragma unroll
-                    for (int u = 0; u < DGROUP; ++u) {
-                        const uint32_t zb = __float_as_uint(v[u].x), zt_ = __float_as_uint(pg[u].y);
-                        const bool keep = (g0 + u * WAVE + lane < vbase) & ((zb < zt_) | ((zb == zt_) & ((int)(mt[u] >> 6) <= __float_as_int(pg[u].z))));
-                        const float dist = sq2(v[u].y, v[u].z);
-                        const float sd = (__float_as_uint(v[u].w) & 1u) ? -dist : dist;
-                        const float lf = __log2f(1.0f - face_prob(sd, a.inv_sigma));
-                        if (keep & (lf != 0.f)) atomicAdd(&lds.plog[mt[u] & 63u], (double)lf);
-                    }
-                };
-                float4 va[DGROUP], vb[DGROUP];
-                uint32_t ma[DGROUP], mb[DGROUP];
-                load_recs(va, ma, 0);
-                for (int g0 = 0; g0 < vbase; g0 += 2 * DGROUP * WAVE) {
-                    load_recs(vb, mb, g0 + DGROUP * WAVE);
-                    log_recs(va, ma, g0);
-                    load_recs(va, ma, g0 + 2 * DGROUP * WAVE);
-                    log_recs(vb, mb, g0 + DGROUP * WAVE);
-                }
-            }
-            __syncthreads();
             const float alpha = exp2f((float)lds.plog[lane]);
             TMARK(3)
 
@@ -827,33 +844,34 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     }
                     for (int i_ = lane; i_ < GCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.0;
                     __syncthreads();
-                    auto load_recs = [&](float4 (&v)[DGROUP], uint32_t (&mt)[DGROUP], int g0) {
+                    struct GRec { uint32_t z, mt; float rx, ry, t; };
+                    auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
-                            v[u] = at(sval, idx);
-                            mt[u] = at(smeta, idx);
+                            r[u].z = at(sz, idx); r[u].mt = at(smeta, idx);
+                            r[u].rx = at(srx, idx); r[u].ry = at(sry, idx); r[u].t = at(st, idx);
                         }
                     };
-                    auto grad_recs = [&](const float4 (&v)[DGROUP], const uint32_t (&mt)[DGROUP], int g0) {
+                    auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {
                         float4 pg[DGROUP];  // all LDS gathers first
 #pragma unroll
-                        for (int u = 0; u < DGROUP; ++u) pg[u] = lds.pgrad[mt[u] & 63u];
+                        for (int u = 0; u < DGROUP; ++u) pg[u] = lds.pgrad[r[u].mt & 63u];
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const bool valid = g0 + u * WAVE + lane < i_end;
-                            const int pos = (int)(mt[u] >> 6);
-                            const uint32_t zb = __float_as_uint(v[u].x), zt_ = __float_as_uint(pg[u].y);
-                            const uint32_t tb = __float_as_uint(v[u].w);
-                            const bool inside = (tb & 1u) != 0u;
-                            const float dist = sq2(v[u].y, v[u].z);
+                            const uint32_t mt = r[u].mt;
+                            const int pos = (int)((mt >> 6) & 0xFFFFu);
+                            const uint32_t zt_ = __float_as_uint(pg[u].y);
+                            const bool inside = ((mt >> 22) & 1u) != 0u;
+                            const float dist = sq2(r[u].rx, r[u].ry);
                             float gd = pg[u].x * face_prob(inside ? -dist : dist, a.inv_sigma);  // d L / d (signed dist)
                             gd = inside ? -gd : gd;                                               // d L / d (unsigned squared distance)
-                            const bool keep = valid & (gd != 0.f) & ((zb < zt_) | ((zb == zt_) & (pos <= __float_as_int(pg[u].z))));
-                            const float t = __uint_as_float(tb & ~7u);
-                            const int edge = (int)((tb >> 1) & 3u);
+                            const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & (pos <= __float_as_int(pg[u].z))));
+                            const float t = r[u].t;
+                            const int edge = (int)(mt >> 23);
                             const int ia = edge == 2 ? 2 : 0, ib = edge == 0 ? 2 : 4;  // accumulator slots of the edge's end points
-                            const float ex = 2.0f * v[u].y * gd, ey = 2.0f * v[u].z * gd;
+                            const float ex = 2.0f * r[u].rx * gd, ey = 2.0f * r[u].ry * gd;
                             if (keep) {
                                 double *acc = lds.gacc + (pos % GCHUNK) * 6;
                                 atomicAdd(acc + ia, (double)((1.0f - t) * ex));
@@ -864,14 +882,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         }
                     };
                     {
-                        float4 va[DGROUP], vb[DGROUP];
-                        uint32_t ma[DGROUP], mb[DGROUP];
-                        load_recs(va, ma, i_beg);
+                        GRec ra[DGROUP], rb[DGROUP];
+                        load_recs(ra, i_beg);
                         for (int g0 = i_beg; g0 < i_end; g0 += 2 * DGROUP * WAVE) {
-                            load_recs(vb, mb, g0 + DGROUP * WAVE);
-                            grad_recs(va, ma, g0);
-                            load_recs(va, ma, g0 + 2 * DGROUP * WAVE);
-                            grad_recs(vb, mb, g0 + DGROUP * WAVE);
+                            load_recs(rb, g0 + DGROUP * WAVE);
+                            grad_recs(ra, g0);
+                            load_recs(ra, g0 + 2 * DGROUP * WAVE);
+                            grad_recs(rb, g0 + DGROUP * WAVE);
                         }
                     }
                     __syncthreads();
@@ -906,10 +923,11 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: F face ids, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) records of 28 bytes
+// per resident workgroup: F face ids, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (five record + three compact) words
+#define N_STREAMS 8
 static inline size_t scratch_bytes(int grid, int F) {
     return (size_t)grid * (align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
-                           (size_t)(REC_CAP + REC_PAD) * (sizeof(float4) + 3 * sizeof(uint32_t)));
+                           (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
 
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
@@ -959,13 +977,15 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
         ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
-        a.sval = (float4 *)ws;
-        ws += grid * (REC_CAP + REC_PAD) * sizeof(float4);
-        a.smeta = (uint32_t *)ws;
-        ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
-        a.skey = (uint32_t *)ws;
-        ws += grid * (REC_CAP + REC_PAD) * sizeof(uint32_t);
-        a.scmeta = (uint32_t *)ws;
+        const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(uint32_t);
+        a.sz = (uint32_t *)ws; ws += stream;
+        a.smeta = (uint32_t *)ws; ws += stream;
+        a.srx = (float *)ws; ws += stream;
+        a.sry = (float *)ws; ws += stream;
+        a.st = (float *)ws; ws += stream;
+        a.ckey = (uint32_t *)ws; ws += stream;
+        a.cmeta = (uint32_t *)ws; ws += stream;
+        a.clf = (float *)ws;
     }
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;

@@ -81,6 +81,7 @@ def load():
         raise SmilError(
             f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C smilify_amd/csrc). There is no CPU fallback.")
+    import torch  # noqa: F401  the library must bind to the HIP runtime torch has loaded, not bring up a second one
     lib = ctypes.CDLL(LIB_PATH)
     lib.smil_last_error.restype = c_char_p
     lib.smil_version.restype = c_char_p

@@ -417,7 +417,8 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
         FaceRec r;
         r.xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur; r.xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
         r.ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur; r.ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
-        const float rcp_area = 1.0f / (edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
+        // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
+        const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
         // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
         const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
         r.A0 = (y2 - y1) * s0; r.B0 = -(x2 - x1) * s0; r.C0 = edge_fn(cx, cy, x1, y1, x2, y2) * s0;
@@ -428,9 +429,9 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
         r.e01x = x1 - x0; r.e01y = y1 - y0; r.e02x = x2 - x0; r.e02y = y2 - y0; r.e12x = x2 - x1; r.e12y = y2 - y1;
         const float l01 = r.e01x * r.e01x + r.e01y * r.e01y, l02 = r.e02x * r.e02x + r.e02y * r.e02y,
                     l12 = r.e12x * r.e12x + r.e12y * r.e12y;
-        r.rl01 = l01 <= K_EPS ? 0.f : 1.0f / l01;
-        r.rl02 = l02 <= K_EPS ? 0.f : 1.0f / l02;
-        r.rl12 = l12 <= K_EPS ? 0.f : 1.0f / l12;
+        r.rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
+        r.rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
+        r.rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
         r.i0 = i0; r.i1 = i1; r.i2 = i2;
         *reinterpret_cast<FaceRec *>(rec + lane * FSTR) = r;
     }

@@ -249,13 +249,25 @@ def fov_reduce(cams: CameraSet, d_fov_img: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # silhouette
 # ----------------------------------------------------------------------------------------------
+# The per-image tables of one rasteriser launch (tile boxes, depth ranges, work lists: ~12 F + 8 tiles bytes per image) are
+# part of the workspace; launches are cut into slices of this many images so that the workspace stays bounded at cfg5
+# scale (147 k images per GPU).  Each slice still holds millions of tiles.
+MAX_IMAGES_PER_LAUNCH = 16384
+
+
+def _slices(N: int):
+    for n0 in range(0, N, MAX_IMAGES_PER_LAUNCH):
+        yield n0, min(N, n0 + MAX_IMAGES_PER_LAUNCH)
+
+
 def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=None) -> torch.Tensor:
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     sil = torch.empty(N, S, S, dtype=torch.float32, device=verts_ndc.device)
-    ws = model.workspace(N, S)
-    _lib.check(_lib.load().smil_silhouette_forward(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(sil), _ptr(ws),
-                                                   _stream()), "smil_silhouette_forward")
+    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
+    for n0, n1 in _slices(N):
+        _lib.check(_lib.load().smil_silhouette_forward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
+                                                       _ptr(sil[n0:n1]), _ptr(ws), _stream()), "smil_silhouette_forward")
     return sil
 
 
@@ -263,9 +275,11 @@ def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, gra
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=verts_ndc.device)
-    ws = model.workspace(N, S)
-    _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(grad_sil),
-                                                    _ptr(d_ndc), _ptr(ws), _stream()), "smil_silhouette_backward")
+    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
+    for n0, n1 in _slices(N):
+        _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
+                                                        _ptr(grad_sil[n0:n1]), _ptr(d_ndc[n0:n1]), _ptr(ws), _stream()),
+                   "smil_silhouette_backward")
     return d_ndc
 
 
@@ -279,13 +293,14 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
     if d_ndc is None:
         d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=dev)
     sil = torch.empty(N, S, S, dtype=torch.float32, device=dev) if want_sil else None
-    ws = model.workspace(N, S)
+    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
     if target.dtype not in (torch.float32, torch.uint8):
         raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
-    _lib.check(_lib.load().smil_silhouette_l1_fused(model.handle, _ptr(verts_ndc), N, S, ctypes.byref(rs), _ptr(target),
-                                                    int(target.dtype == torch.uint8), _ptr(target_sum), _ptr(pix_scale),
-                                                    _ptr(loss_img), _ptr(d_ndc), _ptr(sil), _ptr(ws), _stream()),
-               "smil_silhouette_l1_fused")
+    for n0, n1 in _slices(N):
+        _lib.check(_lib.load().smil_silhouette_l1_fused(
+            model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs), _ptr(target[n0:n1]), int(target.dtype == torch.uint8),
+            _ptr(target_sum[n0:n1]), _ptr(pix_scale[n0:n1]), _ptr(loss_img[n0:n1]), _ptr(d_ndc[n0:n1]),
+            _ptr(None if sil is None else sil[n0:n1]), _ptr(ws), _stream()), "smil_silhouette_l1_fused")
     return loss_img, d_ndc, sil
 
 

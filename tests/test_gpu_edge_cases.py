@@ -234,3 +234,24 @@ def test_full_resolution_against_oracle(key, dist, tables):
     cos = (g * want).sum() / (np.linalg.norm(g) * np.linalg.norm(want))
     rel = np.linalg.norm(g - want) / np.linalg.norm(want)
     assert cos > 0.9999 and rel < 2e-2, (cos, rel)
+
+
+def test_sliced_launches_equal_one_launch(tables, monkeypatch):
+    """The engine cuts very large image batches into several rasteriser launches (bounded workspace); the results must
+    not depend on where the cuts fall."""
+    eng = _eng()
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S, N = 40, 7
+    ndc = _scene(t, N, S, 2.2, 5).to(DEV)
+    tgt = (eng.silhouette_forward(dm, _scene(t, N, S, 2.2, 6).to(DEV), S) > 0.5).to(torch.uint8)
+    scale = torch.linspace(0.5, 1.5, N, device=DEV) / (S * S)
+    ref = eng.silhouette_l1_fused(dm, ndc, S, tgt, eng.image_abs_sum(tgt), scale, want_sil=True)
+    ref_fwd = eng.silhouette_forward(dm, ndc, S)
+    monkeypatch.setattr(eng, "MAX_IMAGES_PER_LAUNCH", 3)
+    got = eng.silhouette_l1_fused(dm, ndc, S, tgt, eng.image_abs_sum(tgt), scale, want_sil=True)
+    got_fwd = eng.silhouette_forward(dm, ndc, S)
+    torch.testing.assert_close(got_fwd, ref_fwd, rtol=0, atol=1e-6)
+    torch.testing.assert_close(got[2], ref[2], rtol=0, atol=1e-6)
+    torch.testing.assert_close(got[0], ref[0], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-7)

@@ -60,22 +60,25 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
 // -DDBG_TIMERS: per-phase cycle sums of the tile kernel (printed by the next launch); off in normal builds
 #ifdef DBG_TIMERS
-#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter();
+#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast;
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
-#define TIMERS_FLUSH if (a.dbg && lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.dbg[k_], tph[k_]);
+#define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
+        atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); }
 #else
 #define TIMERS_INIT
 #define TMARK(k)
 #define TIMERS_FLUSH
 #endif
 
-// Work items (touched tiles) are queued in four cost classes by the number of faces that reach the tile, and handed out
-// heaviest class first: a persistent kernel whose longest item takes a third of the whole launch must not start it last.
+// Work items (touched tiles) are queued in four cost classes by the number of (face, pixel) pairs the tile will evaluate
+// (the sum of its faces' pixel boxes), and handed out heaviest class first: a persistent kernel whose longest items take
+// a fifth of the whole launch must not start them last.
 // Two arrays of N * tiles entries hold two classes each (one filled from the front, one from the back).
 #define N_CLASSES 4
-#define CLASS_T0 2048
-#define CLASS_T1 1024
-#define CLASS_T2 384
+#define CLASS_T0 65536        // class 0 is always dealt out in quarters (SPLIT0_LOG)
+#define CLASS_T1 16384
+#define CLASS_T2 4096
+#define SPLIT0_LOG 2
 #define COUNT_TILES_MAX 8192  // per-tile face counts live in LDS (4 bytes each); larger images queue everything in the last class
 struct RasterCounters {
     unsigned int n_class[N_CLASSES];
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur) {
-    extern __shared__ uint32_t tcnt[];  // faces per tile (counted), or a touched-tile bitmap when the image has too many tiles
+    extern __shared__ uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
@@ -163,11 +166,17 @@ __global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ 
                     const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
                     const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
                     box = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                    const int xo0 = S - 1 - xi_hi, xo1 = S - 1 - xi_lo, yo0 = S - 1 - yi_hi, yo1 = S - 1 - yi_lo;
                     for (int ty = ty0; ty <= ty1; ++ty)
                         for (int tx = tx0; tx <= tx1; ++tx) {
                             const int t = ty * tiles_x + tx;
-                            if (counted) atomicAdd(&tcnt[t], 1u);
-                            else atomicOr(&tcnt[t >> 5], 1u << (t & 31));
+                            if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it
+                                const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
+                                const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
+                                atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
+                            } else {
+                                atomicOr(&tcnt[t >> 5], 1u << (t & 31));
+                            }
                         }
                 }
             }
@@ -524,7 +533,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
     // the launch finishes in a fraction of one tile's serial time.
     const unsigned int split_log = n_items * 8u <= gridDim.x ? 3u : (n_items * 4u <= gridDim.x ? 2u : (n_items * 2u <= gridDim.x ? 1u : 0u));
-    const unsigned int n_units = n_items << split_log;
+    // The heaviest class is always dealt out in quarters: one such tile alone takes a good part of what a whole 512-image
+    // launch takes per workgroup.
+    const unsigned int split0_log = SPLIT0_LOG;
+    const unsigned int units0 = nc0 << split0_log;
+    const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
     const float fS = (float)a.S;
 
     TIMERS_INIT
@@ -533,8 +546,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         if (lane == 0) unit = atomicAdd(&a.ctr->next, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= n_units) break;
-        const unsigned int item = unit >> split_log;
-        const int p_begin = (int)(unit & ((1u << split_log) - 1u)) * (WAVE >> split_log), p_end = p_begin + (WAVE >> split_log);
+#ifdef DBG_TIMERS
+        const unsigned long long tunit_ = tlast;
+#endif
+        const bool heavy = unit < units0;
+        const unsigned int sl = heavy ? split0_log : split_log, u_ = heavy ? unit : unit - units0;
+        const unsigned int item = (u_ >> sl) + (heavy ? 0u : nc0);
+        const int p_begin = (int)(u_ & ((1u << sl) - 1u)) * (WAVE >> sl), p_end = p_begin + (WAVE >> sl);
         // heaviest class first
         const uint32_t code = item < nc0 ? a.items[item]
                             : item < nc0 + nc1 ? a.items[a.item_cap - 1u - (item - nc0)]
@@ -909,6 +927,15 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             TMARK(4)
             p_lo += span;
         }
+#ifdef DBG_TIMERS
+        if (a.dbg && lane == 0) {
+            const int cls = item < nc0 ? 0 : (item < nc0 + nc1 ? 1 : (item < nc0 + nc1 + nc2 ? 2 : 3));
+            const unsigned long long dt_ = tlast - tunit_;
+            atomicAdd(&a.dbg[8 + cls], dt_);
+            atomicMax(&a.dbg[12 + cls], dt_);
+            atomicMax(&a.dbg[16 + cls], tunit_ - tstart_);  // latest start of a unit of this class
+        }
+#endif
     }
     TIMERS_FLUSH
 }
@@ -995,12 +1022,17 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
 #ifdef DBG_TIMERS
     {
         static unsigned long long *dbg_dev = nullptr;
-        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 64); (void)hipMemset(dbg_dev, 0, 64); }
-        unsigned long long h[8];
-        (void)hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost);  // totals of the launches so far
-        fprintf(stderr, "[dbg timers] list %.3e  pass1 %.3e  select %.3e  pass2 %.3e  pass3 %.3e cycles (summed over waves)\n",
-                (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4]);
-        (void)hipMemset(dbg_dev, 0, 64);
+        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 160); (void)hipMemset(dbg_dev, 0, 160); }
+        unsigned long long h[20];
+        (void)hipMemcpy(h, dbg_dev, 160, hipMemcpyDeviceToHost);  // totals of the launches so far
+        fprintf(stderr, "[dbg timers] list %.3e  pass1 %.3e  blend+select %.3e  - %.3e  pass3 %.3e cycles (summed over waves); "
+                "first wave exit %.3e, last wave exit %.3e cycles after the first start\n",
+                (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)(h[6] - h[5]), (double)(h[7] - h[5]));
+        fprintf(stderr, "[dbg timers] per class: unit time sums %.3e %.3e %.3e %.3e  longest unit %.3e %.3e %.3e %.3e  latest unit start %.3e %.3e %.3e %.3e\n",
+                (double)h[8], (double)h[9], (double)h[10], (double)h[11], (double)h[12], (double)h[13], (double)h[14], (double)h[15],
+                (double)h[16], (double)h[17], (double)h[18], (double)h[19]);
+        (void)hipMemset(dbg_dev, 0, 160);
+        { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;
     }
 #endif

@@ -49,7 +49,7 @@ tb = ws[: N * dm.F * 4].view(torch.int32).reshape(N, dm.F).cpu().numpy().astype(
 tx0, ty0, tx1, ty1 = tb & 255, (tb >> 8) & 255, (tb >> 16) & 255, tb >> 24
 valid = tx0 <= tx1
 tiles_per_face = np.where(valid, (tx1.astype(int) - tx0 + 1) * (ty1.astype(int) - ty0 + 1), 0)
-print(f"work items per cost class (faces >= 2048 / 1024 / 384 / rest): {ctr[:4].tolist()}")
+print(f"work items per cost class (pairs >= 65536 / 16384 / 4096 / rest): {ctr[:4].tolist()}")
 print(f"images {N}  time/launch {dt*1e3:.2f} ms  {dt/N*1e6:.1f} us/image  work items {n_work} ({n_work/N:.1f} tiles/image)  "
       f"valid faces/image {valid.sum(1).mean():.0f}  (tile,face) pairs/image {tiles_per_face.sum(1).mean():.0f}  "
       f"avg list length {tiles_per_face.sum()/max(n_work,1):.0f}")

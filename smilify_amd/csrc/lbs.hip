@@ -81,22 +81,30 @@ __global__ void k_shape_blend(const float *__restrict__ vt, const float *__restr
 }
 
 // rest joints: J = J_static or J_regressor^T v_shaped (CSR gather)               (smal_torch.py:257-264)
-__global__ void k_rest_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
-                              const float *__restrict__ val, const float *__restrict__ v_shaped,
-                              const float *__restrict__ J_static, float *__restrict__ J_rest, int V, int J,
-                              int is_static) {
+// One wave per joint (strided over the block's waves), lanes over the non-zeros of its regressor row.
+__global__ void __launch_bounds__(256) k_rest_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                     const float *__restrict__ val, const float *__restrict__ v_shaped,
+                                                     const float *__restrict__ J_static, float *__restrict__ J_rest, int V, int J,
+                                                     int is_static) {
     const int s = blockIdx.x;
-    for (int idx = threadIdx.x; idx < 3 * J; idx += blockDim.x) {
-        float acc;
-        if (is_static) {
-            acc = J_static[idx];
-        } else {
-            const int j = idx / 3, c = idx - 3 * j;
-            acc = 0.f;
-            const float *vs = v_shaped + (size_t)s * V * 3;
-            for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) acc += vs[3 * col[e] + c] * val[e];
+    if (is_static) {
+        for (int idx = threadIdx.x; idx < 3 * J; idx += blockDim.x) J_rest[(size_t)s * J * 3 + idx] = J_static[idx];
+        return;
+    }
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    const float *vs = v_shaped + (size_t)s * V * 3;
+    for (int j = wid; j < J; j += nw) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int e = rowptr[j] + lane; e < rowptr[j + 1]; e += WAVE) {
+            const float w = val[e];
+            const float *p = vs + 3 * col[e];
+            a0 += p[0] * w; a1 += p[1] * w; a2 += p[2] * w;
         }
-        J_rest[(size_t)s * J * 3 + idx] = acc;
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) {
+            float *o = J_rest + ((size_t)s * J + j) * 3;
+            o[0] = a0; o[1] = a1; o[2] = a2;
+        }
     }
 }
 
@@ -319,17 +327,27 @@ __global__ void __launch_bounds__(256) k_skin_fwd(const float *__restrict__ A, c
 // posed joints by regression from the posed vertices                           (smal_torch.py:348-351)
 // trans_after != NULL: the vertices already carry the frame translation but the reference regresses the
 // joints from the untranslated vertices and adds the translation afterwards (fitter.py:280-281).
-__global__ void k_regress_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                 const float *__restrict__ val, const float *__restrict__ verts,
-                                 const float *__restrict__ trans_after, float *__restrict__ joints, int V, int J) {
+__global__ void __launch_bounds__(256) k_regress_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                        const float *__restrict__ val, const float *__restrict__ verts,
+                                                        const float *__restrict__ trans_after, float *__restrict__ joints, int V,
+                                                        int J) {
     const int b = blockIdx.x;
     const float *vb = verts + (size_t)b * V * 3;
-    for (int idx = threadIdx.x; idx < 3 * J; idx += blockDim.x) {
-        const int j = idx / 3, c = idx - 3 * j;
-        const float t = trans_after ? trans_after[3 * b + c] : 0.f;
-        float acc = 0.f;
-        for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) acc += (vb[3 * col[e] + c] - t) * val[e];
-        joints[(size_t)b * J * 3 + idx] = acc + t;
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    const float t0 = trans_after ? trans_after[3 * b] : 0.f, t1 = trans_after ? trans_after[3 * b + 1] : 0.f,
+                t2 = trans_after ? trans_after[3 * b + 2] : 0.f;
+    for (int j = wid; j < J; j += nw) {  // one wave per joint, lanes over the non-zeros of its regressor row
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int e = rowptr[j] + lane; e < rowptr[j + 1]; e += WAVE) {
+            const float w = val[e];
+            const float *p = vb + 3 * col[e];
+            a0 += (p[0] - t0) * w; a1 += (p[1] - t1) * w; a2 += (p[2] - t2) * w;
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) {
+            float *o = joints + ((size_t)b * J + j) * 3;
+            o[0] = a0 + t0; o[1] = a1 + t1; o[2] = a2 + t2;
+        }
     }
 }
 

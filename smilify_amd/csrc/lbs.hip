@@ -435,7 +435,7 @@ __device__ __forceinline__ void vertex_upstream(const float *__restrict__ d_vert
 
 // d_A[b][j] = sum_{v in bone j} w (dv (x) [v_posed;1]).  One block per frame, one wave per bone
 // (strided); deterministic (no atomics).
-__global__ void __launch_bounds__(256) k_skin_bwd_transforms(
+__global__ void __launch_bounds__(1024) k_skin_bwd_transforms(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ v_posed,
     const int *__restrict__ bone_ptr, const int *__restrict__ bone_vid, const float *__restrict__ bone_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
 
 // Per frame: d v_posed = T_R^T dv (+ regressor^T d J_rest), reduced against shapedirs -> d_beta[b],
 // and d_trans[b] = sum_v dv.  One block per frame, deterministic.
-__global__ void __launch_bounds__(256) k_shape_bwd(
+__global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
@@ -737,7 +737,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     const float *v_skin = m->posedirs ? sv->v_posed : sv->v_shaped;
     const int nS_skin = m->posedirs ? B : nS;
     SMIL_REQUIRE(!m->posedirs || (sv->v_posed && g->d_vposed), "smil_lbs_backward: pose blend shapes need v_posed and d_vposed");
-    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(256), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
+    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(1024), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
                        g->d_joints, v_skin, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
                        m->jreg_cval, g->d_A, V, J, nS_skin, regress);
     SMIL_LAUNCH_CHECK();
@@ -791,7 +791,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         float *dbeta_frame = nullptr;
         if (g->d_beta && nBu > 0) dbeta_frame = in->shared_beta ? g->d_A : g->d_beta;  // d_A is free again
         const size_t lds = ((size_t)J * 18 + 16) * sizeof(float);
-        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(256), lds, stream, g->d_verts, g->d_joints,
+        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(1024), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
                            m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, V, J, nBu, regress,
                            in->trans_after_joints ? 1 : 0);

@@ -127,7 +127,7 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // ---------------------------------------------------------------------------------------------
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
+__global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur) {
@@ -993,7 +993,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
     const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(256), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
+    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(1024), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
                        fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
     SMIL_LAUNCH_CHECK();
     {

@@ -207,6 +207,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_raster_dense<FUSED> (soft silhouette fwd + L1 + bwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1f_traffic.json" if traffic else None,
+                         "traffic_achieved": (traffic / (kern_avg_ms * 1e-3) / 1e9) if (traffic and kern_n) else None,
+                         "traffic_frac": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_n) else None,
                          "algorithmic_bytes_per_launch": n_img * per_view, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_image": per_view,
                          "iteration_frac": (iter_bytes / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,

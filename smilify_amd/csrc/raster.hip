@@ -54,7 +54,7 @@
 #define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
 #define REC_PAD 64          // slack so that a clamped read stays inside the allocation
-#define RESIDENT_PER_CU 14  // single-wave workgroups per CU (11 KB LDS each; 120 VGPRs allow 16)
+#define RESIDENT_PER_CU 14  // single-wave workgroups per CU (10.5 KB LDS each: 15 would fit, no faster; 122 VGPRs allow 16)
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
@@ -326,8 +326,10 @@ struct alignas(16) DenseLds {
     };
     // select: [bucket / 2][pixel], two 16-bit counts per word; the first digit is counted by pass 1
     uint32_t hist[(1 << SEL_BITS) / 2 * WAVE];
-    float4 pixt[WAVE];               // px, py, px - cx, py - cy
-    float4 pgrad[WAVE];              // passes 2/3: {gradient coefficient, threshold depth bits, last kept list position, -}
+    union {
+        float4 pixt[WAVE];           // pass 1: px, py, px - cx, py - cy
+        float4 pgrad[WAVE];          // later: {gradient coefficient, threshold depth bits, last kept list position, -}
+    };
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run
 };

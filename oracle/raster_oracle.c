@@ -157,7 +157,7 @@ static int gather_pixel(const float *vn, const int32_t *faces, int F, float px, 
     return qsize;
 }
 
-static int g_select_mode; /* 0 = faithful sequential queue; 1 = K smallest by (z, face) [analysis only] */
+static int g_select_mode; /* 0 = faithful sequential queue (the reference); 1 = K smallest by (z, face): the documented rule of the HIP rasteriser, used by tests to check that rule exactly */
 void oracle_set_select_mode(int m) { g_select_mode = m; }
 
 static int frag_less(const void *a, const void *b) {

@@ -236,6 +236,19 @@ int smil_sil_objective(const float *loss_img, const float *pix_scale, int32_t N,
 /* torch.optim.Adam semantics (no amsgrad, no weight decay). step = 1-based step count. */
 int smil_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, int32_t step, void *stream);
+/* The same update for up to SMIL_ADAM_MAX_TENSORS parameter tensors in ONE launch (a fit iteration updates five small
+ * tensors; five launches cost more than the arithmetic).  Each tensor has its own learning rate and step count. */
+#define SMIL_ADAM_MAX_TENSORS 8
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    int64_t n;
+    float lr;
+    int32_t step;             /* 1-based */
+} SmilAdamTensor;
+int smil_adam_step_multi(const SmilAdamTensor *tensors, int32_t count, float beta1, float beta2, float eps, void *stream);
+
 /* Same update with the step count read from device memory: step = *step_dev - step_offset.  Lets a whole fit iteration be
  * captured once in a hipGraph and replayed (the host only bumps the counter - or the graph does, with an increment node). */
 int smil_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,

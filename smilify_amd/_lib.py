@@ -17,11 +17,19 @@ EXPORTS = [
     "smil_lbs_forward", "smil_lbs_backward", "smil_project", "smil_project_backward", "smil_fov_reduce",
     "smil_raster_workspace_bytes", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
-    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_adam_step_dev", "smil_profile_enable",
+    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_adam_step_multi", "smil_adam_step_dev", "smil_profile_enable",
     "smil_profile_read",
 ]
 
 N_OBJS = 10
+
+
+class AdamTensor(Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64),
+                ("lr", c_float), ("step", c_int32)]
+
+
+ADAM_MAX_TENSORS = 8
 
 
 class SmilError(RuntimeError):
@@ -112,6 +120,7 @@ def load():
     lib.smil_sil_objective.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
     lib.smil_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                    c_int32, c_void_p]
+    lib.smil_adam_step_multi.argtypes = [POINTER(AdamTensor), c_int32, c_float, c_float, c_float, c_void_p]
     lib.smil_adam_step_dev.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                        c_void_p, c_int32, c_void_p]
     lib.smil_profile_enable.argtypes = [c_int32]

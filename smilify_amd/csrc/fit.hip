@@ -270,6 +270,44 @@ __global__ void __launch_bounds__(256) k_adam(float *__restrict__ p, const float
     }
 }
 
+struct AdamMulti {
+    SmilAdamTensor t[SMIL_ADAM_MAX_TENSORS];
+    float bc1[SMIL_ADAM_MAX_TENSORS], bc2_sqrt[SMIL_ADAM_MAX_TENSORS];
+};
+
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti a, float b1, float b2, float eps) {
+    const SmilAdamTensor &t = a.t[blockIdx.y];
+    const float bc1 = a.bc1[blockIdx.y], bc2_sqrt = a.bc2_sqrt[blockIdx.y], lr = t.lr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = t.grad[i];
+        const float mi = t.exp_avg[i] + (gi - t.exp_avg[i]) * (1.0f - b1);
+        const float vi = t.exp_avg_sq[i] * b2 + (1.0f - b2) * gi * gi;
+        t.exp_avg[i] = mi; t.exp_avg_sq[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        t.param[i] = t.param[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int smil_adam_step_multi(const SmilAdamTensor *tensors, int32_t count, float beta1, float beta2, float eps,
+                                    void *stream_) {
+    SMIL_REQUIRE(tensors && count > 0 && count <= SMIL_ADAM_MAX_TENSORS, "smil_adam_step_multi: count=%d outside 1..%d", count,
+                 SMIL_ADAM_MAX_TENSORS);
+    AdamMulti a;
+    long long n_max = 0;
+    for (int k = 0; k < count; ++k) {
+        const SmilAdamTensor &t = tensors[k];
+        SMIL_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq && t.n > 0 && t.step > 0, "smil_adam_step_multi: bad tensor %d", k);
+        a.t[k] = t;
+        a.bc1[k] = 1.0f - powf(beta1, (float)t.step);
+        a.bc2_sqrt[k] = sqrtf(1.0f - powf(beta2, (float)t.step));
+        n_max = std::max<long long>(n_max, t.n);
+    }
+    const int gx = (int)std::min<long long>(512, (n_max + 255) / 256);
+    hipLaunchKernelGGL(k_adam_multi, dim3(gx, count), dim3(256), 0, (hipStream_t)stream_, a, beta1, beta2, eps);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
 __global__ void __launch_bounds__(256) k_adam_dev(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                   float *__restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                   const int *__restrict__ step_dev, int step_offset) {

@@ -365,6 +365,17 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.5, beta2=0.999
                                           beta2, eps, step, _stream()), "smil_adam_step")
 
 
+def adam_step_multi(items, beta1=0.5, beta2=0.999, eps=1e-8):
+    """One launch for several tensors: ``items`` = [(param, grad, exp_avg, exp_avg_sq, lr, step), ...]."""
+    for k0 in range(0, len(items), _lib.ADAM_MAX_TENSORS):
+        chunk = items[k0:k0 + _lib.ADAM_MAX_TENSORS]
+        arr = (_lib.AdamTensor * len(chunk))()
+        for a, (p, g, m, v, lr, step) in zip(arr, chunk):
+            a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            a.n, a.lr, a.step = p.numel(), float(lr), int(step)
+        _lib.check(_lib.load().smil_adam_step_multi(arr, len(chunk), beta1, beta2, eps, _stream()), "smil_adam_step_multi")
+
+
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr, step_dev, step_offset=0, beta1=0.5, beta2=0.999, eps=1e-8):
     """Adam update whose step count is ``step_dev[0] - step_offset`` (int32 device tensor): capturable in a hipGraph."""
     _lib.check(_lib.load().smil_adam_step_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1,

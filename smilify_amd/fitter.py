@@ -424,6 +424,7 @@ class SMALFitter(nn.Module):
         """torch.optim.Adam(betas=(0.5,0.999)) semantics on every parameter that received a gradient."""
         h = self._adam_hyper
         self._adam_step += 1
+        items = []
         for name, g in grads.items():
             if g is None:
                 continue
@@ -432,7 +433,9 @@ class SMALFitter(nn.Module):
             if st is None:
                 st = self._adam[name] = dict(m=torch.zeros_like(p), v=torch.zeros_like(p), t0=self._adam_step - 1)
             lr = h["fov_lr"] if name == "fov" else h["lr"]
-            engine.adam_step(p, g.contiguous(), st["m"], st["v"], lr, self._adam_step - st["t0"], h["betas"][0], h["betas"][1], h["eps"])
+            items.append((p, g.contiguous(), st["m"], st["v"], lr, self._adam_step - st["t0"]))
+        if items:  # one launch for all of them
+            engine.adam_step_multi(items, h["betas"][0], h["betas"][1], h["eps"])
 
     def fit_step(self, weights, w_temp: float, window: Optional[int] = None, halo_prev=None, halo_next=None,
                  shared_grad_hook=None):

@@ -60,10 +60,11 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
 // -DDBG_TIMERS: per-phase cycle sums of the tile kernel (printed by the next launch); off in normal builds
 #ifdef DBG_TIMERS
-#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast;
+#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0;
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
 #define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
-        atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); }
+        atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); \
+        atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); }
 #else
 #define TIMERS_INIT
 #define TMARK(k)
@@ -639,6 +640,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 const uint32_t fl_hi = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane + 1) & 63];
                 const int pk_rank = (int)reinterpret_cast<const uint32_t *>(lds.psel)[lane & (DCHUNK - 1)];
                 lds_fence();
+#ifdef DBG_TIMERS
+                { const unsigned long long now_ = __builtin_readcyclecounter(); tstage_ += now_ - tlast; tlast = now_; }
+#endif
                 uint32_t carry = 0;                 // faces started before this step
                 for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
                     const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)fl_lo, q0 >> 6), whi = (uint32_t)__builtin_amdgcn_readlane((int)fl_hi, q0 >> 6);
@@ -677,6 +681,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     }
                     vbase += __popcll(cm);
                 }
+#ifdef DBG_TIMERS
+                { const unsigned long long now_ = __builtin_readcyclecounter(); tsweep_ += now_ - tlast; tlast = now_; }
+#endif
                 lds_fence();  // rec is rewritten by the next chunk
             }
             if (!fits) {  // wave-uniform: try again with half the pixels
@@ -1027,7 +1034,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 160); (void)hipMemset(dbg_dev, 0, 160); }
         unsigned long long h[20];
         (void)hipMemcpy(h, dbg_dev, 160, hipMemcpyDeviceToHost);  // totals of the launches so far
-        fprintf(stderr, "[dbg timers] list %.3e  pass1 %.3e  blend+select %.3e  - %.3e  pass3 %.3e cycles (summed over waves); "
+        fprintf(stderr, "[dbg timers] list %.3e  pass1 sweep %.3e  blend+select %.3e  pass1 staging %.3e  pass3 %.3e cycles (summed over waves); "
                 "first wave exit %.3e, last wave exit %.3e cycles after the first start\n",
                 (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)(h[6] - h[5]), (double)(h[7] - h[5]));
         fprintf(stderr, "[dbg timers] per class: unit time sums %.3e %.3e %.3e %.3e  longest unit %.3e %.3e %.3e %.3e  latest unit start %.3e %.3e %.3e %.3e\n",

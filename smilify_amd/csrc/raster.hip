@@ -985,7 +985,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(rs->sigma > 0.f && rs->blur_radius >= 0.f, "raster: bad blend settings");
     SMIL_REQUIRE(m->F <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP);
     const int tiles_x = ceil_div(S, TILE);
-    SMIL_REQUIRE((double)N * tiles_x * tiles_x < 4294967295.0, "raster: N * tiles exceeds the 32-bit work-item code");
+    SMIL_REQUIRE((double)N * tiles_x * tiles_x < 2147483647.0, "raster: N * tiles exceeds the work-item index range (2^31); launch in slices");
     char *ws = (char *)workspace;
     uint32_t *tbox = (uint32_t *)ws;
     ws += align256((size_t)N * m->F * sizeof(uint32_t));

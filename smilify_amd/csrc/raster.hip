@@ -301,11 +301,12 @@ __device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e)
     const float m0 = fmaxf(e.w0, 0.f), m1 = fmaxf(e.w1, 0.f), m2 = fmaxf(e.w2, 0.f);
     const float cs = fmaxf(m0 + m1 + m2, 1e-5f * den);
     const float rc = __builtin_amdgcn_rcpf(cs);
-    float pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
-    pz = (m1 == 0.f && m2 == 0.f && m0 >= cs) ? f.z0 : pz;
-    pz = (m0 == 0.f && m2 == 0.f && m1 >= cs) ? f.z1 : pz;
-    pz = (m0 == 0.f && m1 == 0.f && m2 >= cs) ? f.z2 : pz;
-    return pz;
+    const float pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
+    // one survivor <=> the sum of the clipped weights equals their maximum (and was not lifted by the 1e-5 floor)
+    const float mx = fmaxf(fmaxf(m0, m1), m2);
+    const bool single = (m0 + m1 + m2 == mx) && (mx >= cs);
+    const float zv = m0 > 0.f ? f.z0 : (m1 > 0.f ? f.z1 : f.z2);
+    return single ? zv : pz;
 }
 
 __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {

@@ -1,0 +1,44 @@
+import os, sys
+import numpy as np, torch
+REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from smilify_amd import engine, model_io
+from oracle import render_ref, lbs_ref, fitter_ref
+from conftest import oracle_model
+DEV = "cuda:0"
+models = {"synthetic": model_io.synthetic_model(),
+          "stick": model_io.load_model(os.path.join(REPO, "data/models/SMILy_STICK.npz")),
+          "mouse": model_io.load_model(os.path.join(REPO, "data/models/SMILy_Mouse_static_joints.npz"))}
+dms = {k: engine.DeviceModel(t, DEV) for k, t in models.items()}
+def scene(t, N, S, dist, seed, scale=1.0):
+    m = oracle_model(t)
+    g = torch.Generator().manual_seed(seed)
+    theta = 0.3 * torch.randn(N, t.J, 3, generator=g)
+    theta[:, 0] = torch.from_numpy(fitter_ref.default_global_rotation()) + 0.5 * torch.randn(N, 3, generator=g)
+    verts = lbs_ref.smal_forward(m, torch.zeros(N, t.nB), theta)["verts"] * scale
+    R, T = render_ref.look_at_view_transform(dist, float(g.initial_seed() % 60), torch.linspace(0, 300, N))
+    return render_ref.project_to_ndc(verts, R, T, torch.full((N,), 60.0)).contiguous()
+bad = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(seed)
+    key = ["synthetic", "stick", "mouse"][int(rng.integers(0, 3))]
+    t, dm = models[key], dms[key]
+    S = int(rng.integers(9, 140)); K = int(rng.choice([1, 2, 5, 17, 64, 100, 128]))
+    dist = float(np.exp(rng.uniform(np.log(1.2), np.log(40.0)))) * (1.5 if key == "mouse" else 1.0)
+    N = int(rng.integers(1, 4))
+    ndc = scene(t, N, S, dist, seed)
+    with render_ref.select_mode(1):
+        ref1, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)
+    got = engine.silhouette_forward(dm, ndc.to(DEV), S, engine.raster_settings(K=K)).cpu().numpy()
+    d1 = np.abs(got - ref1)
+    ok = d1.mean() < 5e-6 and np.mean(d1 > 1e-4) < 5e-3 and d1[ncand <= K].max(initial=0.0) < 3e-4
+    gs = torch.from_numpy(rng.standard_normal((N, S, S)).astype(np.float32))
+    with render_ref.select_mode(1):
+        want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy(), K=K)[..., :2]
+    gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), engine.raster_settings(K=K)).cpu().numpy()
+    nrm = np.linalg.norm(want)
+    cos = (gotg * want).sum() / (np.linalg.norm(gotg) * nrm + 1e-30) if nrm > 0 else 1.0
+    ok = ok and (cos > 0.99 or nrm < 1e-6) and np.isfinite(gotg).all()
+    print(f"seed {seed:3d} {key:9s} N={N} S={S:3d} K={K:3d} dist={dist:6.2f} maxcand={ncand.max():5d} mean|d|={d1.mean():.2e} frac>1e-4={np.mean(d1>1e-4):.1e} cos={cos:.5f} {'ok' if ok else 'FAIL'}", flush=True)
+    bad += (not ok)
+print("failures", bad)

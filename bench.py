@@ -6,6 +6,10 @@ silhouette -> six loss terms -> backward -> Adam, over the whole synthetic batch
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: starts the line above as a child process and relays it)
+
+Default workload: cfg2b (STICK, 4096 frames x 1 view @256^2), the configuration BASELINE.json's north-star
+roofline target is stated on; ``--workload`` selects the other BASELINE configs.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` (dominant kernel = the fused
 tile rasteriser, timed live with HIP events on its launch stream) and ``cpu_baseline`` (the CPU oracle timed on
@@ -38,6 +42,7 @@ WORKLOADS = {
     "tiny": dict(model="SMILy_STICK", frames=16, views=1, S=128, radius=2.7, name="tiny: STICK B=16 @128^2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+TRAFFIC_FILE = "r2_traffic.json"  # PMC byte counts per launch recorded this round (tools/pmc_traffic.py)
 
 
 def algorithmic_bytes(V, J, S, views):
@@ -47,50 +52,87 @@ def algorithmic_bytes(V, J, S, views):
     return per_view, per_frame
 
 
-def cpu_baseline(tables, wl, n_frames):
-    """Time the CPU oracle (a port of the reference algorithm) on ``n_frames`` frames of the same workload:
-    forward + backward of the full loss + Adam step, host cores only."""
+def cpu_sample(fitter, n_frames):
+    """Host copies of the first ``n_frames`` frames of the workload (parameters as initialised, targets, cameras):
+    taken before the first GPU step so that the CPU oracle is timed on the workload's own inputs."""
+    views = fitter.views
+    c = lambda t: t.detach().float().cpu().clone()  # noqa: E731
+    n_img = n_frames * views
+    return dict(
+        params=dict(betas=c(fitter.betas), log_beta_scales=c(fitter.log_beta_scales[:n_frames]), betas_trans=c(fitter.betas_trans[:n_frames]),
+                    global_rotation=c(fitter.global_rotation[:n_frames]), trans=c(fitter.trans[:n_frames]),
+                    joint_rotations=c(fitter.joint_rotations[:n_frames]), fov=c(fitter.fov)),
+        sil=c(fitter.sil_imgs[:n_img]), joints=c(fitter.target_joints[:n_img]), visibility=fitter.target_visibility[:n_img].cpu().clone(),
+        R=c(fitter.renderer.cameras.R), T=c(fitter.renderer.cameras.T), mean_betas=c(fitter.mean_betas), betas_prec=c(fitter.betas_prec),
+        n_frames=n_frames, views=views)
+
+
+def cpu_baseline(tables, wl, sample, window, iters=3):
+    """Time the CPU oracle (a port of the reference algorithm) on a bounded sample of the same workload: one warm-up
+    iteration, then ``iters`` timed fit iterations (forward + backward of the full loss + Adam step), host cores only."""
     import numpy as np
 
     from oracle import fitter_ref, render_ref
     from smilify_amd import synthetic
-    from smilify_amd.fitter import shape_prior_precision
 
-    J, nB, S, views = tables.J, tables.nB, wl["S"], wl["views"]
+    n_frames, views, S = sample["n_frames"], sample["views"], wl["S"]
     model = dict(v_template=torch.from_numpy(tables.v_template), shapedirs=torch.from_numpy(tables.shapedirs),
                  J_regressor=torch.from_numpy(tables.dense_J_regressor()), weights=torch.from_numpy(tables.dense_weights()),
                  parents=tables.parents, faces=torch.from_numpy(tables.faces.astype(np.int64)),
                  J_static=torch.from_numpy(tables.J_static) if tables.static_joints else None, posedirs=None)
-    gen = torch.Generator().manual_seed(1234)
-    pose, trans = synthetic.random_pose(n_frames, J, gen)
-    R, T = synthetic.camera_ring(views, wl["radius"])
-    params = dict(betas=(0.5 * torch.randn(nB, generator=gen)).requires_grad_(), log_beta_scales=torch.zeros(n_frames, J, 3).requires_grad_(),
-                  betas_trans=torch.zeros(n_frames, J, 3), global_rotation=pose[:, 0].clone().requires_grad_(),
-                  trans=trans.clone().requires_grad_(), joint_rotations=pose[:, 1:].clone().requires_grad_(),
-                  fov=torch.full((1,), 60.0).requires_grad_())
-    mean_b = torch.zeros(nB) if tables.shape_mean_betas is None else torch.from_numpy(np.asarray(tables.shape_mean_betas, np.float32))[:nB]
-    prec = torch.from_numpy(shape_prior_precision(tables.shape_cov if tables.shape_mean_betas is not None else None, nB))
+    params = {k: v.clone() for k, v in sample["params"].items()}
+    for k in ("betas", "log_beta_scales", "global_rotation", "trans", "joint_rotations", "fov"):
+        params[k].requires_grad_()
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=synthetic.STAGE1_LR, betas=(0.5, 0.999))
-    targets = dict(sil=(torch.rand(n_frames, 1, S, S, generator=gen) > 0.97).float(), joints=torch.rand(n_frames, J, 2, generator=gen) * S,
-                   visibility=torch.ones(n_frames, J, dtype=torch.long))
+    windows = [list(range(s0, min(n_frames, s0 + window))) for s0 in range(0, n_frames, window)]
+
+    def iteration():
+        opt.zero_grad()
+        total = 0.0
+        for v in range(views):  # the oracle renderer takes one camera per image: one pass per view
+            tg = dict(sil=sample["sil"][v::views], joints=sample["joints"][v::views], visibility=sample["visibility"][v::views])
+            cams = dict(R=sample["R"][v:v + 1], T=sample["T"][v:v + 1])
+            for br in windows:
+                loss, _, _ = fitter_ref.fit_losses(model, params, br, synthetic.STAGE1_WEIGHTS, tg, cams, S, sample["mean_betas"],
+                                                   sample["betas_prec"])
+                total = total + loss
+        jl, gl, tl = fitter_ref.temporal(params, synthetic.STAGE1_TEMPORAL)
+        (total + jl + gl + tl).backward()
+        opt.step()
+        return float(total)
+
+    iteration()  # warm-up (thread pools, page faults, the oracle's shared object)
     t0 = time.perf_counter()
-    total = 0.0
-    for v in range(views):  # one camera per pass: the oracle renderer takes one camera per image
-        cams = dict(R=R[v:v + 1], T=T[v:v + 1])
-        loss, _, _ = fitter_ref.fit_losses(model, params, range(n_frames), synthetic.STAGE1_WEIGHTS, targets, cams, S, mean_b, prec)
-        total = total + loss
-    jl, gl, tl = fitter_ref.temporal(params, synthetic.STAGE1_TEMPORAL)
-    (total + jl + gl + tl).backward()
-    opt.step()
-    dt = time.perf_counter() - t0
+    for _ in range(iters):
+        iteration()
+    dt = (time.perf_counter() - t0) / iters
     try:
         cores = min(render_ref.num_threads(), len(os.sched_getaffinity(0)))
     except AttributeError:
         cores = render_ref.num_threads()
     return dict(value=n_frames / dt, unit="frame-iters/s", cores=cores, omp_threads=render_ref.num_threads(),
-                torch_threads=torch.get_num_threads(), kind="port",
-                sample=f"{n_frames} frames x {views} view(s) @ {S}^2 of the same workload, 1 fit iteration "
-                       f"(oracle: torch-CPU LBS/losses + OpenMP C naive rasteriser), {dt:.1f} s")
+                torch_threads=torch.get_num_threads(), kind="port", iterations_timed=iters, warmup_iterations=1, s_per_iteration=dt,
+                sample=f"first {n_frames} frames x {views} view(s) @ {S}^2 of the same workload (same parameters, targets and cameras), "
+                       f"{iters} timed fit iterations after 1 warm-up (oracle: torch-CPU LBS/losses + OpenMP C naive rasteriser), "
+                       f"{dt:.2f} s per iteration")
+
+
+def relaunch_multi_gpu(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD
+    process (never exec: nothing here has touched the GPU yet, and it stays that way in this process), relay its output
+    and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def main():
@@ -98,8 +140,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="cfg2b", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip; default: about 8 images)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-gpu rehearses the multi-rank path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only; never for reported numbers)")
@@ -108,8 +150,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_multi_gpu(args))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.share_gpu:
         local_rank = 0
@@ -125,13 +169,14 @@ def main():
 
     from smilify_amd import _lib
 
-    if not os.path.exists(_lib.LIB_PATH):  # fresh checkout: build once (rank 0), everybody else waits
-        if rank == 0:
-            import __graft_entry__
+    # fresh checkout: rank 0 alone decides and builds (the Makefile links to a temporary name and renames it), every
+    # rank then meets at the same barrier, and the library is loaded only behind it
+    if rank == 0 and not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
 
-            __graft_entry__.build()
-        if world > 1:
-            dist.barrier()
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
     from smilify_amd import engine, model_io, optimize, synthetic
 
     wl = WORKLOADS[args.workload]
@@ -141,6 +186,10 @@ def main():
     # weak scaling: every rank holds `frames` frames of one long sequence (shards aligned to windows)
     fitter = synthetic.make_problem(tables, frames, views, S, dev, radius=wl["radius"], seed=1234 + rank, window=window,
                                     frame0=rank * frames, n_frames_total=world * frames)
+    n_cpu = 0
+    if rank == 0 and world == 1 and args.cpu_frames != 0:
+        n_cpu = min(frames, args.cpu_frames if args.cpu_frames > 0 else max(1, 8 // views))
+        sample = cpu_sample(fitter, n_cpu)
     fitter.begin_stage(synthetic.STAGE1_LR, fov_lr=1.0)
     staged = args.backend == "gloo"  # gloo: stage the (tiny) collective payloads through host memory
     hook = (lambda shared, objs: optimize.allreduce_shared(shared, objs, host_staged=staged)) if world > 1 else None
@@ -179,14 +228,19 @@ def main():
         kern_avg_ms = kern_ms / max(kern_n, 1)
         achieved = (n_img * per_view) / (kern_avg_ms * 1e-3) / 1e9 if kern_n else 0.0
         iter_bytes = frames * (per_frame + views * per_view)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r1f_traffic.json")
+        # HBM bytes of one tile-kernel launch from the PMC passes committed under profiles/ (offline data of this round:
+        # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 passes, so they cannot be read inside this run); used only
+        # when the recorded launch has the same number of images as this one.
+        traffic = traffic_src = None
+        tpath = os.path.join(REPO, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath):
             tj = json.load(open(tpath)).get(args.workload)
             if tj and tj["images_per_launch"] == n_img:
                 traffic = (tj["FETCH_SIZE_KB"] * tj["fetch_correction"] + tj["WRITE_SIZE_KB"]) * 1024.0
+                traffic_src = f"offline PMC passes (FETCH_SIZE x{tj['fetch_correction']:g} + WRITE_SIZE per launch), profiles/{TRAFFIC_FILE}"
+        alg_launch = n_img * per_view
         out = {
-            "metric": "SMIL fit-iters/sec (LBS+render+loss)",
+            "metric": "SMIL fit frame-iters/sec (LBS+render+loss), whole job",
             "value": world * frames / (dt / args.steps),
             "unit": "frame-iters/s",
             "n_gpus": world,
@@ -206,17 +260,19 @@ def main():
             "final_loss": loss,
             "roofline": {"bound": "hbm", "kernel": "k_raster_dense<FUSED> (soft silhouette fwd + L1 + bwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r1f_traffic.json" if traffic else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / alg_launch) if traffic else None,
                          "traffic_achieved": (traffic / (kern_avg_ms * 1e-3) / 1e9) if (traffic and kern_n) else None,
                          "traffic_frac": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_n) else None,
-                         "algorithmic_bytes_per_launch": n_img * per_view, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
+                         "algorithmic_bytes_per_launch": alg_launch, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_image": per_view,
                          "iteration_frac": (iter_bytes / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
-                         "note": "the kernel trades HBM traffic for arithmetic: each (face, pixel) pair is evaluated once and its 28-byte record re-read by the selection / blend / gradient sweeps, so measured traffic is ~10x the algorithmic bytes and the VALU pipes are ~50% busy; see DESIGN.md section 6"},
+                         "note": "achieved = algorithmic bytes (SURVEY.md 8(d): 36V + 20S^2 + 28J + 56 per image) / tile-kernel time from HIP "
+                                 "events on its launch stream; traffic = HBM bytes the kernel really moved (its per-pair record streams), "
+                                 "see DESIGN.md section 6"},
         }
-        if world == 1 and args.cpu_frames != 0:
-            n_cpu = args.cpu_frames if args.cpu_frames > 0 else max(1, 32 // views)
-            out["cpu_baseline"] = cpu_baseline(tables, wl, n_cpu)
+        if n_cpu:
+            out["cpu_baseline"] = cpu_baseline(tables, wl, sample, window)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

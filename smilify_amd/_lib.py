@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmilfit.so")
+# SMILFIT_LIB: load another build of the same library (instrumented builds under tools/dbg); never a CPU path
+LIB_PATH = os.environ.get("SMILFIT_LIB") or os.path.join(_HERE, "lib", "libsmilfit.so")
 
 EXPORTS = [
     "smil_model_create", "smil_model_destroy", "smil_model_dims", "smil_last_error", "smil_version",

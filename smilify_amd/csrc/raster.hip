@@ -62,12 +62,14 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #ifdef DBG_TIMERS
 #define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0;
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
+#define STAT(k, v) { if (a.dbg && lane == 0) atomicAdd(&a.dbg[k], (unsigned long long)(v)); }
 #define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
         atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); \
         atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); }
 #else
 #define TIMERS_INIT
 #define TMARK(k)
+#define STAT(k, v)
 #define TIMERS_FLUSH
 #endif
 
@@ -339,12 +341,20 @@ static_assert(sizeof(double) * (GCHUNK * 6 + WAVE) <= sizeof(float) * DCHUNK * F
 
 // Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
 // VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
+#ifdef RASTER_EXPERIMENT  // tools/dbg experiments only: wrap every stream index (results are garbage, timing is not)
+__constant__ uint32_t g_wrap_mask = 0xFFFFFFFFu;
+#define WRAP_IDX(i) ((i) & g_wrap_mask)
+#else
+#define WRAP_IDX(i) (i)
+#endif
 template <typename T>
 __device__ __forceinline__ T &at(T *base, uint32_t i) {
+    i = WRAP_IDX(i);
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
 }
 template <typename T>
 __device__ __forceinline__ const T &at(const T *base, uint32_t i) {
+    i = WRAP_IDX(i);
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
 }
 
@@ -624,6 +634,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
                 packed |= off;                      // off <= DCHUNK * 64
                 if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
+                STAT(20, n_pairs)
                 // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
                 // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
                 // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
@@ -693,6 +704,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 continue;
             }
             if (lane == 0) scfirst[n_chunks] = (uint32_t)vbase;
+            STAT(21, vbase) STAT(26, 1) STAT(27, list_total)
             __syncthreads();  // also: record stores of other lanes are visible from here on
             TMARK(1)
 
@@ -828,6 +840,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 __syncthreads();
             }
             TMARK(2)
+            STAT(22, n_cmp) STAT(23, __popcll(__ballot(trunc))) STAT(24, __popcll(__ballot(lds.plog[lane] != 0.0)))
             const float alpha = exp2f((float)lds.plog[lane]);
             TMARK(3)
 
@@ -856,6 +869,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
             const float coef = -g * alpha * a.inv_sigma;
             const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
+            STAT(25, __popcll(__ballot(active)))
             if (MODE != MODE_FWD && __ballot(active) != 0ull) {
                 float *dn = a.d_ndc + (size_t)n * a.V * 2;
                 lds.pgrad[lane] = make_float4(active ? coef : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
@@ -957,7 +971,10 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
-    const long long resident = 256LL * RESIDENT_PER_CU;
+    long long resident = 256LL * RESIDENT_PER_CU;
+#ifdef RASTER_EXPERIMENT
+    if (const char *e = getenv("SMIL_RESIDENT")) resident = 256LL * (atoi(e) > 0 && atoi(e) <= RESIDENT_PER_CU ? atoi(e) : RESIDENT_PER_CU);
+#endif
     return (int)(max_items < resident ? max_items : resident);
 }
 
@@ -1029,19 +1046,28 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;
+#ifdef RASTER_EXPERIMENT
+    {
+        uint32_t mask = 0xFFFFFFFFu;
+        if (const char *e = getenv("SMIL_WRAP")) mask = (uint32_t)strtoul(e, nullptr, 0);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wrap_mask), &mask, sizeof(mask), 0, hipMemcpyHostToDevice, stream);
+    }
+#endif
 #ifdef DBG_TIMERS
     {
         static unsigned long long *dbg_dev = nullptr;
-        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 160); (void)hipMemset(dbg_dev, 0, 160); }
-        unsigned long long h[20];
-        (void)hipMemcpy(h, dbg_dev, 160, hipMemcpyDeviceToHost);  // totals of the launches so far
+        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 256); (void)hipMemset(dbg_dev, 0, 256); }
+        unsigned long long h[32];
+        (void)hipMemcpy(h, dbg_dev, 256, hipMemcpyDeviceToHost);  // totals of the launches so far
         fprintf(stderr, "[dbg timers] list %.3e  pass1 sweep %.3e  blend+select %.3e  pass1 staging %.3e  pass3 %.3e cycles (summed over waves); "
                 "first wave exit %.3e, last wave exit %.3e cycles after the first start\n",
                 (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)(h[6] - h[5]), (double)(h[7] - h[5]));
         fprintf(stderr, "[dbg timers] per class: unit time sums %.3e %.3e %.3e %.3e  longest unit %.3e %.3e %.3e %.3e  latest unit start %.3e %.3e %.3e %.3e\n",
                 (double)h[8], (double)h[9], (double)h[10], (double)h[11], (double)h[12], (double)h[13], (double)h[14], (double)h[15],
                 (double)h[16], (double)h[17], (double)h[18], (double)h[19]);
-        (void)hipMemset(dbg_dev, 0, 160);
+        fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e\n",
+                (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25]);
+        (void)hipMemset(dbg_dev, 0, 256);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;
     }

@@ -19,6 +19,7 @@ ap.add_argument("--S", type=int, default=256)
 ap.add_argument("--radius", type=float, default=2.7)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--mode", default="fused", choices=["fused", "fwd"])
+ap.add_argument("--quick", action="store_true", help="timing only (skip the per-tile list statistics)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 tables = model_io.load_model(os.path.join(REPO, "data", "models", args.model + ".npz"))
@@ -41,6 +42,9 @@ for it in range(args.reps + 1):
         engine.silhouette_forward(dm, ndc, args.S)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.reps
+if args.quick:
+    print(f"images {N}  time/launch {dt*1e3:.3f} ms  {dt/N*1e6:.2f} us/image  [SMIL_RESIDENT={os.environ.get('SMIL_RESIDENT')} SMIL_WRAP={os.environ.get('SMIL_WRAP')}]")
+    sys.exit(0)
 ws = dm._ws
 off = ((N * dm.F * 4 + 255) // 256) * 256
 ctr = ws[off:off + 16].view(torch.int32).cpu().numpy()

@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2b", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="override the workload's frames per GPU (tests, rehearsals)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip; default: about 8 images)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-gpu rehearses the multi-rank path on a 1-GPU box")
@@ -181,10 +182,11 @@ def main():
 
     wl = WORKLOADS[args.workload]
     tables = model_io.load_model(os.path.join(REPO, "data", "models", wl["model"] + ".npz"))
-    frames, views, S = wl["frames"], wl["views"], wl["S"]
+    frames, views, S = (args.frames or wl["frames"]), wl["views"], wl["S"]
     window = 10  # reference config.WINDOW_SIZE
-    # weak scaling: every rank holds `frames` frames of one long sequence (shards aligned to windows)
-    fitter = synthetic.make_problem(tables, frames, views, S, dev, radius=wl["radius"], seed=1234 + rank, window=window,
+    # weak scaling: every rank holds `frames` frames of one long sequence (shards aligned to windows); all ranks draw the
+    # sequence from the same seed and keep their own slice
+    fitter = synthetic.make_problem(tables, frames, views, S, dev, radius=wl["radius"], seed=1234, window=window,
                                     frame0=rank * frames, n_frames_total=world * frames)
     n_cpu = 0
     if rank == 0 and world == 1 and args.cpu_frames != 0:
@@ -254,7 +256,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "rehearsal": bool(args.share_gpu or args.backend != "nccl"),
-            "config": {"workload": wl["name"], "frames_per_gpu": frames, "views": views, "image": S, "window": window,
+            "config": {"workload": wl["name"] + (f" [--frames {frames}]" if args.frames else ""), "frames_per_gpu": frames, "views": views, "image": S, "window": window,
                        "weights": synthetic.STAGE1_WEIGHTS, "w_temporal": synthetic.STAGE1_TEMPORAL, "faces_per_pixel": 100,
                        "parallelism": f"frames sharded x{world}, all-reduce of shared-parameter gradients"},
             "final_loss": loss,

@@ -108,6 +108,10 @@ typedef struct {
     float *d_Rs;           /* (B,J,3,3) */
     float *d_vposed;       /* (B,V,3): required iff the model has posedirs */
     float *d_posefeat;     /* (B,9(J-1)): required iff the model has posedirs */
+    float *d_del_v;        /* (B,V,3) or NULL: gradient on the per-frame vertex offsets del_v (smal_torch.py:244-248);
+                              also the gradient on v_shaped / v_template rows of each frame */
+    float *d_Rs_in;        /* (B,J,3,3) or NULL: gradient on the rotation matrices when theta was given as
+                              matrices (Rs_in; smal_torch.py:288-289) */
 } SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
                               logscale_shared, btrans_shared) receive the sum over frames */
 
@@ -153,7 +157,8 @@ typedef struct {
     float blur_radius;        /* NDC^2; reference: log(1/1e-4 - 1) * 1e-4 */
     float sigma;              /* 1e-4 */
     int32_t faces_per_pixel;  /* K = 100 */
-    float z_clip;             /* znear / 2 = 5e-4 */
+    float z_clip;             /* MeshRasterizer's z_clip_value = znear / 2 = 5e-4: faces whose three vertices are all
+                                 nearer than this are culled (clip_faces); straddling faces are not split */
 } SmilRasterSettings;
 
 /* Caller-owned scratch for N images of side S: per-face tile boxes / depth ranges, the tile work list, and the pair-record

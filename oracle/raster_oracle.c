@@ -30,6 +30,12 @@
 #endif
 
 #define K_EPS 1e-8f
+/* MeshRasterizer passes z_clip_value = znear / 2 (renderer/mesh/rasterizer.py; the reference sets znear = 1e-3,
+ * p3d_renderer.py:24,36-38) to clip_faces(): a face whose three vertices are all nearer than that is removed before the
+ * kernel runs.  Faces that straddle the value are split there; that case is NOT restated (geometry within half a
+ * millimetre of the camera plane), they are rasterised whole unless the kernel rule zmin < 1e-8 drops them. */
+static float g_z_clip = 5e-4f;
+void oracle_set_z_clip(float z) { g_z_clip = z; }
 
 typedef struct {
     float z;
@@ -68,7 +74,7 @@ static inline int eval_face(const float *v0, const float *v1, const float *v2, f
     const int outside = (px > xmax) || (px < xmin) || (py > ymax) || (py < ymin) || (zmin < K_EPS);
     const float face_area = edge_fn(v0[0], v0[1], v1[0], v1[1], v2[0], v2[1]);
     const int zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
-    if (zmax < 0.f || outside || zero_area) return 0;
+    if (zmax < 0.f || zmax < g_z_clip || outside || zero_area) return 0;
 
     const float area = edge_fn(v2[0], v2[1], v0[0], v0[1], v1[0], v1[1]) + K_EPS;
     const float b0 = edge_fn(px, py, v1[0], v1[1], v2[0], v2[1]) / area;

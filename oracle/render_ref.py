@@ -49,6 +49,7 @@ def _lib():
             ctypes.c_int, fp, fp]
         lib.oracle_silhouette_backward.restype = ctypes.c_int
         lib.oracle_num_threads.restype = ctypes.c_int
+        lib.oracle_set_z_clip.argtypes = [ctypes.c_float]
         _LIB = lib
     return _LIB
 
@@ -67,6 +68,11 @@ class select_mode:
     def __exit__(self, *exc):
         _lib().oracle_set_select_mode(0)
         return False
+
+
+def set_z_clip(z: float) -> None:
+    """z_clip_value of the rasteriser (default znear / 2 = 5e-4, as the reference's camera gives it)."""
+    _lib().oracle_set_z_clip(ctypes.c_float(float(z)))
 
 
 def num_threads() -> int:

@@ -474,6 +474,7 @@ struct ChainBwdArgs {
     const float *d_posefeat;  // (B,9(J-1)) gradient on vec(Rs[1:] - I) from the pose blend shapes, or NULL
     const int *parents, *depth;
     float *d_theta, *d_logscale, *d_btrans, *d_Jrest;
+    float *d_Rs_out;          // (B,J,9) gradient on the rotation matrices themselves (matrix-valued theta), or NULL
     int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
 };
 
@@ -591,6 +592,8 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                 }
                 if (a.d_posefeat && j > 0)
                     for (int i = 0; i < 9; ++i) dR[i] += a.d_posefeat[fb * 9 * (J - 1) + (size_t)(j - 1) * 9 + i];
+                if (a.d_Rs_out)
+                    for (int i = 0; i < 9; ++i) a.d_Rs_out[o * 9 + i] = dR[i];
                 if (a.d_theta && a.theta) {
                     const float *th = a.theta + o * 3;
                     float dth[3];
@@ -622,8 +625,8 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
-    const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_trans, int V, int J,
-    int nB_used, int regress, int trans_after) {
+    const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_trans,
+    float *__restrict__ d_vshaped, int V, int J, int nB_used, int regress, int trans_after) {
     extern __shared__ float smem[];
     float *sA = smem;            // (J,12)
     float *sDJ = sA + J * 12;    // (J,3) upstream on posed joints
@@ -653,7 +656,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
             } else {
                 tsum[0] += dv[0]; tsum[1] += dv[1]; tsum[2] += dv[2];
             }
-            if (nB_used == 0) continue;
+            if (nB_used == 0 && !d_vshaped) continue;
             const uint32_t ids = skin_idx[v];
             const float4 w4 = skin_w[v];
             const float w[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -674,6 +677,10 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
                     const float *dr = sDR + 3 * row[e];
                     dvp[0] += wv * dr[0]; dvp[1] += wv * dr[1]; dvp[2] += wv * dr[2];
                 }
+            }
+            if (d_vshaped && k0 == 0) {  // = gradient on del_v: v_shaped = v_template + blend + del_v
+                float *o = d_vshaped + ((size_t)b * V + v) * 3;
+                o[0] = dvp[0]; o[1] = dvp[1]; o[2] = dvp[2];
             }
             for (int k = 0; k < BETA_CHUNK; ++k) {
                 if (k0 + k < nB_used) {
@@ -742,7 +749,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
                        m->jreg_cval, g->d_A, V, J, nS_skin, regress);
     SMIL_LAUNCH_CHECK();
     const float *d_posefeat = nullptr;
-    if (m->posedirs && g->d_theta && !in->Rs_in) {
+    if (m->posedirs && ((g->d_theta && !in->Rs_in) || (g->d_Rs_in && in->Rs_in))) {
         // gradient through v_posed -> vec(Rs[1:] - I): d_vposed, then the transposed product with posedirs;
         // the (B,9(J-1)) result lives in the d_Rs scratch behind the per-frame scale / translation gradients
         const int K9 = 9 * (J - 1);
@@ -770,6 +777,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         a.d_newJ = m->static_joints ? g->d_joints : nullptr;
         a.d_posefeat = d_posefeat;
         a.parents = m->parents; a.depth = m->depth;
+        a.d_Rs_out = in->Rs_in ? g->d_Rs_in : nullptr;
         a.d_theta = g->d_theta; a.d_logscale = dls_frame; a.d_btrans = dbt_frame; a.d_Jrest = g->d_Jrest;
         a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;
         a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
@@ -786,14 +794,14 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         int rc = smil_reduce_rows(dbt_frame, g->d_btrans, B, J * 3, stream);
         if (rc) return rc;
     }
-    if (g->d_beta || g->d_trans) {
+    if (g->d_beta || g->d_trans || g->d_del_v) {
         const int nBu = g->d_beta ? in->nB_used : 0;
         float *dbeta_frame = nullptr;
         if (g->d_beta && nBu > 0) dbeta_frame = in->shared_beta ? g->d_A : g->d_beta;  // d_A is free again
         const size_t lds = ((size_t)J * 18 + 16) * sizeof(float);
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(1024), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
-                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, V, J, nBu, regress,
+                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, g->d_del_v, V, J, nBu, regress,
                            in->trans_after_joints ? 1 : 0);
         SMIL_LAUNCH_CHECK();
         if (dbeta_frame && in->shared_beta) {

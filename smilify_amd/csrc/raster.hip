@@ -133,7 +133,8 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
-                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur) {
+                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
+                                                      float z_clip) {
     extern __shared__ uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
     const int n_tiles = tiles_x * tiles_x;
@@ -152,10 +153,12 @@ __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__
             const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
             const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
             const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
-            const float zmin = fminf(fminf(z0, z1), z2);
+            const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
             const float area = edge_fn(x0, y0, x1, y1, x2, y2);
             const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
-            if (finite && !(zmin < K_EPS) && !(area <= K_EPS && area >= -K_EPS)) {
+            // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
+            // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split.
+            if (finite && !(zmin < K_EPS) && !(zmax < z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
                 const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
                 const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
                 // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__
                 }
             }
             tbox[(size_t)n * F + f] = box;
-            fzr[(size_t)n * F + f] = make_float2(zmin, fmaxf(fmaxf(z0, z1), z2));
+            fzr[(size_t)n * F + f] = make_float2(zmin, zmax);
         }
         // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test
         int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
@@ -969,11 +972,23 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 // ---------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Compute units of the current device (256 on MI355X), asked once: the persistent grid is sized to fill them.
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
-    long long resident = 256LL * RESIDENT_PER_CU;
+    long long resident = (long long)device_cus() * RESIDENT_PER_CU;
 #ifdef RASTER_EXPERIMENT
-    if (const char *e = getenv("SMIL_RESIDENT")) resident = 256LL * (atoi(e) > 0 && atoi(e) <= RESIDENT_PER_CU ? atoi(e) : RESIDENT_PER_CU);
+    if (const char *e = getenv("SMIL_RESIDENT")) resident = (long long)device_cus() * (atoi(e) > 0 && atoi(e) <= RESIDENT_PER_CU ? atoi(e) : RESIDENT_PER_CU);
 #endif
     return (int)(max_items < resident ? max_items : resident);
 }
@@ -1021,7 +1036,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     const int n_tiles = tiles_x * tiles_x;
     const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(1024), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
-                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur);
+                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);

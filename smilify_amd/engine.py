@@ -92,6 +92,12 @@ class DeviceModel:
         except Exception:
             pass
 
+    def faces_i32(self) -> torch.Tensor:
+        """The face table as an int32 device tensor (lazily uploaded copy of what smil_model_create received)."""
+        if getattr(self, "_faces_dev", None) is None:
+            self._faces_dev = torch.from_numpy(np.ascontiguousarray(self.tables.faces, np.int32)).to(self.device)
+        return self._faces_dev
+
     def workspace(self, N: int, S: int) -> torch.Tensor:
         need = int(_lib.load().smil_raster_workspace_bytes(self.handle, N, S))
         if self._ws is None or self._ws.numel() < need:
@@ -169,12 +175,17 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
 
 
 def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=True, need_theta=True,
-                 need_logscale=True, need_btrans=True, need_trans=True) -> Dict[str, Optional[torch.Tensor]]:
+                 need_logscale=True, need_btrans=True, need_trans=True, need_vshaped=False,
+                 need_Rs=False) -> Dict[str, Optional[torch.Tensor]]:
     dev = model.device
     inp, fl = saved["_inputs"], saved["_flags"]
     B, J = fl["B"], model.J
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-    g = dict(d_beta=None, d_theta=None, d_logscale=None, d_btrans=None, d_trans=None)
+    g = dict(d_beta=None, d_theta=None, d_logscale=None, d_btrans=None, d_trans=None, d_del_v=None, d_Rs_in=None)
+    if need_vshaped:  # per-frame gradient on v_shaped = on del_v (and, summed over frames, on a custom v_template)
+        g["d_del_v"] = f(B, model.V, 3)
+    if need_Rs and inp["Rs_in"] is not None:
+        g["d_Rs_in"] = f(B, J, 3, 3)
     if need_beta and fl["nB_used"] > 0:
         g["d_beta"] = f(fl["nB_used"]) if fl["shared_beta"] else f(B, fl["nB_used"])
     if need_theta and inp["theta"] is not None:

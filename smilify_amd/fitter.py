@@ -149,6 +149,7 @@ class SMALFitter(nn.Module):
         self.fov = nn.Parameter(self.renderer.cameras.fov.clone())  # (1,) = 60 deg
 
         # device-resident targets (the reference re-uploads them every forward, fitter.py:263-266)
+        self._graph = None
         self._targets_dirty = True
         self._adam: Dict[str, Dict] = {}
         self._adam_step = 0
@@ -166,6 +167,7 @@ class SMALFitter(nn.Module):
         self.renderer.set_camera_parameters(R, T, f, aspect_ratio)
         if fov is not None:
             self.fov = nn.Parameter(self.renderer.cameras.fov.clone())
+        self._graph = None  # a captured iteration holds the old camera tables' addresses
 
     def _refresh_targets(self):
         dev = self.device
@@ -205,6 +207,8 @@ class SMALFitter(nn.Module):
     def __setattr__(self, name, value):
         if name in ("target_visibility", "target_joints", "sil_imgs") and "_targets_dirty" in self.__dict__:
             self.__dict__["_targets_dirty"] = True
+        if name in ("global_mask", "rotation_mask", "renderer", "propagate_scaling") and "_graph" in self.__dict__:
+            self.__dict__["_graph"] = None  # re-assigned tables: the captured iteration read the old buffers
         super().__setattr__(name, value)
 
     def _mask_table(self) -> torch.Tensor:
@@ -453,9 +457,17 @@ class SMALFitter(nn.Module):
 
     # ---- the same epoch as one hipGraph: ~40 kernel launches replayed with a single call --------------------
     def _graph_key(self, weights, w_temp, window):
+        """Everything a captured iteration bakes in besides the parameter buffers: loss weights, which parameters train,
+        the target tensors, and the raw device addresses of the camera tables, the rotation masks and the rasteriser
+        workspace.  A replay happens only while all of them are what they were at capture time."""
         flags = tuple(bool(getattr(self, n).requires_grad) for n in
                       ("betas", "log_beta_scales", "betas_trans", "global_rotation", "joint_rotations", "trans", "fov"))
-        return (tuple(float(w) for w in weights), float(w_temp), window, flags, self._target_signature)
+        cam = self.renderer.cameras
+        ptr = lambda t: None if t is None else (t.data_ptr(), tuple(t.shape))  # noqa: E731
+        ws = self.device_model._ws
+        addresses = (ptr(cam.R), ptr(cam.T), ptr(cam.aspect_ratio), ptr(self.fov.data), ptr(self.global_mask), ptr(self.rotation_mask),
+                     ptr(self.log_beta_scales.data), ptr(self.betas_trans.data), ptr(self.betas.data), None if ws is None else ws.data_ptr())
+        return (tuple(float(w) for w in weights), float(w_temp), window, flags, self._target_signature, addresses)
 
     def fit_step_graph(self, weights, w_temp: float, window: Optional[int] = None):
         """``fit_step`` for a single rank, captured once per (stage, weights) in a hipGraph (``torch.cuda.CUDAGraph``)
@@ -467,7 +479,7 @@ class SMALFitter(nn.Module):
         key = self._graph_key(weights, w_temp, window)
         g = getattr(self, "_graph", None)
         if g is None or g["key"] != key:
-            g = self._capture_step(weights, w_temp, window, key)
+            g = self._capture_step(weights, w_temp, window)
         if g["t_mirror"] != self._adam_step:  # eager steps in between: bring the device counter back in line
             self._adam_t.fill_(self._adam_step)
         self._adam_step += 1
@@ -475,7 +487,7 @@ class SMALFitter(nn.Module):
         g["graph"].replay()
         return g["objs"]
 
-    def _capture_step(self, weights, w_temp, window, key):
+    def _capture_step(self, weights, w_temp, window):
         dev = self.device
         if not hasattr(self, "_adam_t"):
             self._adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -503,7 +515,8 @@ class SMALFitter(nn.Module):
                 lr = h["fov_lr"] if name == "fov" else h["lr"]
                 engine.adam_step_dev(self._param_tensor(name), gr.contiguous(), st["m"], st["v"], lr, self._adam_t, st["t0"],
                                      h["betas"][0], h["betas"][1], h["eps"])
-        self._graph = dict(key=key, graph=graph, objs=objs, t_mirror=self._adam_step)
+        # keyed on the state AFTER the dry run, which may have (re)allocated the rasteriser workspace
+        self._graph = dict(key=self._graph_key(weights, w_temp, window), graph=graph, objs=objs, t_mirror=self._adam_step)
         return self._graph
 
     def _is_shared(self, name: str) -> bool:

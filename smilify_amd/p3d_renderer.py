@@ -7,6 +7,8 @@ reference is visualisation only and is not part of this build: ``render_texture=
 """
 from __future__ import annotations
 
+import hashlib
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -81,10 +83,12 @@ class Renderer(torch.nn.Module):
         self.raster_settings = engine.raster_settings()
         self._topologies = {}
         self._bound_model: Optional[engine.DeviceModel] = None
+        self._bound_faces_ok = {}
 
     def bind_model(self, dm: engine.DeviceModel) -> None:
         """Use the face table already resident with a SMAL model (skips the per-call topology lookup)."""
         self._bound_model = dm
+        self._bound_faces_ok = {}
 
     def set_camera_parameters(self, R, T, fov, aspect_ratio=None):
         """Same contract as reference p3d_renderer.py:72-125 (fov squeezed to 1-D, scalar aspect broadcast)."""
@@ -105,13 +109,25 @@ class Renderer(torch.nn.Module):
         self.cameras = FoVCameras(R, T, fov, aspect_ratio, self.DEFAULT_ZNEAR, self.DEFAULT_ZFAR)
 
     def _device_model(self, faces: torch.Tensor, V: int) -> engine.DeviceModel:
-        dm = self._bound_model
+        """Face table on the GPU for the mesh topology passed to ``forward`` (the reference rasterises whatever faces it is
+        given).  The bound SMAL model's table is used only for that model's own ``faces`` tensor; other topologies are
+        uploaded once and cached by CONTENT (a hash of the index bytes), never by a tensor address that may be recycled
+        (a faces[0] view of an expanded batch is a fresh object per call and is compared by content each time)."""
         f = faces[0] if faces.dim() == 3 else faces
+        dm = self._bound_model
         if dm is not None and dm.V == V and dm.F == f.shape[0]:
-            return dm
-        key = (f.data_ptr(), tuple(f.shape), V)
+            seen = self._bound_faces_ok.get(id(f))  # (weak reference, in-place version): the very same, unmodified tensor
+            if seen is not None and seen[0]() is f and seen[1] == f._version:
+                return dm
+            if torch.equal(f.to(device=self.device, dtype=torch.int32), dm.faces_i32()):
+                if len(self._bound_faces_ok) > 64:
+                    self._bound_faces_ok.clear()
+                self._bound_faces_ok[id(f)] = (weakref.ref(f), f._version)
+                return dm
+        host = np.ascontiguousarray(f.detach().cpu().numpy().astype(np.int32))
+        key = (hashlib.sha1(host.tobytes()).hexdigest(), tuple(host.shape), V)
         if key not in self._topologies:
-            self._topologies[key] = _MeshTopology(f.detach().cpu().numpy(), V, self.device)
+            self._topologies[key] = _MeshTopology(host, V, self.device)
         return self._topologies[key].dm
 
     def forward(self, vertices, points, faces, render_texture=False, joints_only=False):
@@ -126,7 +142,7 @@ class Renderer(torch.nn.Module):
         for name, k in (("R", cam.R.shape[0]), ("T", cam.T.shape[0]), ("fov", cam.fov.numel())):
             if k not in (1, views, N):
                 raise ValueError(f"cameras.{name} has {k} entries for {N} images")
-        dm = None if joints_only else self._device_model(faces.long(), vertices.shape[1])
+        dm = None if joints_only else self._device_model(faces, vertices.shape[1])
         sil, proj = _RenderFunction.apply(dm, cs, self.image_size, self.raster_settings, bool(joints_only), vertices, points, cam.fov)
         if joints_only:
             return None, proj

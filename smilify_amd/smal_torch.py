@@ -6,9 +6,10 @@ Differences that are deliberate and documented:
   (the reference reads the global ``config.SMAL_FILE`` at construction, :92);
 * dense ``weights`` / ``J_regressor`` / ``posedirs`` attributes exist for callers that read them, but the
   kernels use the compact tables of ``model_io``;
-* gradients flow to ``beta, theta (axis-angle), trans, betas_logscale, betas_trans`` through ``verts`` and
-  ``joints``; ``Rs`` and ``v_shaped`` are returned without gradient, and ``del_v`` / rotation-matrix ``theta``
-  receive none;
+* gradients flow to ``beta, theta (axis-angle or (B,J,3,3) matrices), trans, del_v, betas_logscale, betas_trans,
+  v_template`` through ``verts`` and ``joints``; ``Rs`` and ``v_shaped`` are returned without gradient;
+* inputs with a leading dimension of 1 are broadcast over the batch like the torch expressions of the reference do;
+  any other shape mismatch raises instead of reading past a buffer;
 * pose blend shapes (legacy SMAL ``posedirs``) are applied when the model has a non-zero table; every SMIL
   model ships an empty one (reference :182-190) and skips that product entirely.
 """
@@ -33,10 +34,13 @@ class _LbsFunction(torch.autograd.Function):
         rot_in = theta_c is not None and theta_c.dim() == 4
         out = engine.lbs_forward(
             dm, c(beta), None if rot_in else theta_c, trans=c(trans), logscale=c(logscale), btrans=c(btrans), del_v=c(del_v),
-            v_template=c(v_template), Rs_in=theta_c if rot_in else None, propagate_scaling=flags["propagate_scaling"],
+            v_template=c(v_template), Rs_in=theta_c if rot_in else None, logscale_shared=flags["logscale_shared"],
+            btrans_shared=flags["btrans_shared"], propagate_scaling=flags["propagate_scaling"],
             allow_limb_scaling=flags["allow_limb_scaling"])
         ctx.dm, ctx.saved = dm, out
         ctx.has = (beta is not None and beta.shape[-1] > 0, not rot_in, trans is not None, logscale is not None, btrans is not None)
+        ctx.rot_in = rot_in
+        ctx.shared = (flags["logscale_shared"], flags["btrans_shared"])
         v_shaped = out["v_shaped"]
         ctx.mark_non_differentiable(out["Rs"], v_shaped, out["new_J"])
         return out["verts"], out["joints"], out["Rs"], v_shaped, out["new_J"]
@@ -50,8 +54,13 @@ class _LbsFunction(torch.autograd.Function):
             return (None,) * 9
         g = engine.lbs_backward(ctx.dm, ctx.saved, dv, dj, need_beta=need[2] and ctx.has[0], need_theta=need[3] and ctx.has[1],
                                 need_logscale=need[5] and ctx.has[3], need_btrans=need[6] and ctx.has[4],
-                                need_trans=need[4] and ctx.has[2])
-        return None, None, g["d_beta"], g["d_theta"], g["d_trans"], g["d_logscale"], g["d_btrans"], None, None
+                                need_trans=need[4] and ctx.has[2], need_vshaped=need[7] or need[8], need_Rs=need[3] and ctx.rot_in)
+        d_theta = g["d_Rs_in"] if ctx.rot_in else g["d_theta"]
+        d_ls = g["d_logscale"] if g["d_logscale"] is None or not ctx.shared[0] else g["d_logscale"][None]
+        d_bt = g["d_btrans"] if g["d_btrans"] is None or not ctx.shared[1] else g["d_btrans"][None]
+        d_delv = g["d_del_v"] if need[7] else None
+        d_vt = g["d_del_v"].sum(0) if need[8] else None  # a custom template is one (V,3) table shared by the batch
+        return None, None, g["d_beta"], d_theta, g["d_trans"], d_ls, d_bt, d_delv, d_vt
 
 
 class SMAL(nn.Module):
@@ -113,15 +122,43 @@ class SMAL(nn.Module):
 
     def __call__(self, beta, theta, trans=None, del_v=None, betas_logscale=None, betas_trans=None, get_skin=True,
                  v_template=None, propagate_scaling=False):
-        J = self.tables.J
+        J, V = self.tables.J, self.tables.V
         if theta.shape[1] != J:  # reference :282-287: wrong joint count -> zero pose
             theta = torch.zeros(beta.shape[0] if beta.shape[1] > 0 else 1, J, 3, device=self.device)
+        if tuple(theta.shape[1:]) not in ((J, 3), (J, 3, 3)):
+            raise ValueError(f"theta must be (B,{J},3) axis-angle or (B,{J},3,3) rotation matrices, got {tuple(theta.shape)}")
         B = theta.shape[0]
+        if beta.dim() != 2 or beta.shape[0] not in (1, B):
+            raise ValueError(f"beta must be (B,nB) or (1,nB) with B={B}, got {tuple(beta.shape)}")
         if beta.shape[0] != B:
             beta = beta.expand(B, -1)
         if beta.shape[1] > self.tables.nB:
             raise ValueError(f"beta has {beta.shape[1]} columns but the model has {self.tables.nB} shape directions")
-        flags = dict(propagate_scaling=bool(propagate_scaling), allow_limb_scaling=bool(self.config.ALLOW_LIMB_SCALING))
+
+        def rows(name, t, tail):
+            """(tensor laid out as the kernels read it, shared?) for an optional input that is (B,*tail) or broadcasts
+            from (1,*tail) / (*tail) like the torch expressions of the reference (smal_torch.py:244-248,320-340,
+            batch_lbs.py:131-160); anything else would make a kernel read past the buffer, so it raises."""
+            if t is None:
+                return None, False
+            if tuple(t.shape) == tail:
+                t = t[None]
+            if t.dim() != len(tail) + 1 or tuple(t.shape[1:]) != tail or t.shape[0] not in (1, B):
+                raise ValueError(f"{name} must be (B,{','.join(map(str, tail))}) or broadcast from one row, with B={B}; got {tuple(t.shape)}")
+            return t, (t.shape[0] == 1 and B > 1)
+
+        trans, tr_shared = rows("trans", trans, (3,))
+        if tr_shared:
+            trans = trans.expand(B, 3)
+        del_v, dv_shared = rows("del_v", del_v, (V, 3))
+        if dv_shared:
+            del_v = del_v.expand(B, V, 3)
+        betas_logscale, ls_shared = rows("betas_logscale", betas_logscale, (J, 3))
+        betas_trans, bt_shared = rows("betas_trans", betas_trans, (J, 3))
+        if v_template is not None and tuple(v_template.shape) != (V, 3):
+            raise ValueError(f"v_template must be ({V},3), got {tuple(v_template.shape)}")
+        flags = dict(propagate_scaling=bool(propagate_scaling), allow_limb_scaling=bool(self.config.ALLOW_LIMB_SCALING),
+                     logscale_shared=ls_shared, btrans_shared=bt_shared)
         verts, joints, Rs, v_shaped, new_J = _LbsFunction.apply(self._dm, flags, beta, theta, trans, betas_logscale, betas_trans,
                                                                 del_v, v_template)
         self.J_transformed = new_J

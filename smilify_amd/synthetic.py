@@ -41,13 +41,17 @@ def make_problem(tables: model_io.SmilModelTables, frames: int, views: int, S: i
     dev = torch.device(device)
     cfg = FitterConfig.from_tables(tables, WINDOW_SIZE=window)
     J, nB = tables.J, tables.nB
+    # every rank draws the WHOLE sequence from the same seed and keeps its own frames, so that shards of a multi-GPU run
+    # are slices of the problem a single rank would hold (a few MB even at 65 k frames)
+    total = frames if n_frames_total is None else int(n_frames_total)
+    own = slice(frame0, frame0 + frames)
     gen = torch.Generator().manual_seed(seed)
     gen_t = torch.Generator().manual_seed(seed + 10 ** 6)
-    pose0, trans0 = random_pose(frames, J, gen)
-    pose1, trans1 = random_pose(frames, J, gen_t)
+    pose0, trans0 = (x[own] for x in random_pose(total, J, gen))
+    pose1, trans1 = (x[own] for x in random_pose(total, J, gen_t))
     betas0 = 0.5 * torch.randn(nB, generator=gen)
     betas1 = 0.5 * torch.randn(nB, generator=gen_t)
-    ls0 = 0.05 * torch.randn(frames, J, 3, generator=gen)
+    ls0 = (0.05 * torch.randn(total, J, 3, generator=gen))[own]
     R, T = camera_ring(views, radius, device=dev)
     fov = torch.full((1,), 60.0, device=dev)
 
@@ -66,7 +70,7 @@ def make_problem(tables: model_io.SmilModelTables, frames: int, views: int, S: i
         s = engine.silhouette_forward(dm, ndc, S)
         sil[f0 * views:f1 * views, 0] = (s > 0.5).to(torch.uint8)
         tj[f0 * views:f1 * views] = yx
-    noise = torch.randn(frames * views, J, 2, generator=gen_t).to(dev)
+    noise = torch.randn(total * views, J, 2, generator=gen_t)[frame0 * views:(frame0 + frames) * views].to(dev)
     tj = tj + noise
     vis = torch.ones(frames * views, J, dtype=torch.long, device=dev)
     rgb = torch.zeros(frames * views, 3, 1, S)  # placeholder: the fitting path never reads rgb pixels

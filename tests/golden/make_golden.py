@@ -165,6 +165,42 @@ def lbs_goldens(key, pkl_path):
     print(f"lbs_{key}: J={J} nB={nB} loss={loss.item():.6f}")
 
 
+def lbs_extra_goldens(key, pkl_path):
+    """SMAL.__call__ inputs the first set does not touch: per-vertex offsets ``del_v`` (smal_torch.py:244-248),
+    rotation-matrix ``theta`` (:288-289) and one-row inputs that torch broadcasts over the batch (trans (1,3),
+    betas_logscale (1,J,3)); outputs and autograd gradients of the real reference."""
+    install_stubs(pkl_path)
+    from smal_model import batch_lbs
+    from smal_model.smal_torch import SMAL
+
+    smal = SMAL("cpu")
+    J, nB, V = smal.J_regressor.shape[1], smal.num_betas, smal.v_template.shape[0]
+    g = torch.Generator().manual_seed(4242 + len(key))
+    B = 3
+    beta = (0.5 * torch.randn(B, nB, generator=g)).requires_grad_()
+    Rs = batch_lbs.batch_rodrigues(0.3 * torch.randn(B * J, 3, generator=g)).view(B, J, 3, 3).detach().clone().requires_grad_()
+    trans = (0.1 * torch.randn(1, 3, generator=g)).requires_grad_()
+    del_v = (0.01 * torch.randn(B, V, 3, generator=g)).requires_grad_()
+    ls = (0.1 * torch.randn(1, J, 3, generator=g)).requires_grad_()
+    bt = (0.05 * torch.randn(B, J, 3, generator=g)).requires_grad_()
+    verts, joints, Rs_o, v_shaped = smal(beta, Rs, trans=trans, del_v=del_v, betas_logscale=ls, betas_trans=bt)
+    loss = (verts * vertex_probe(verts.shape, 2)).sum() + (joints * vertex_probe(joints.shape, 3)).sum()
+    loss.backward()
+    out = dict(verts=verts.detach().numpy(), joints=joints.detach().numpy(), v_shaped=v_shaped.detach().numpy(), loss=np.float32(loss.item()))
+    for n, t in [("beta", beta), ("Rs", Rs), ("trans", trans), ("del_v", del_v), ("ls", ls), ("bt", bt)]:
+        out[n] = t.detach().numpy()
+        out[f"grad_{n}"] = t.grad.numpy()
+    # one shared (1,V,3) offset for the whole batch, axis-angle pose
+    theta = (0.3 * torch.randn(B, J, 3, generator=g))
+    dv1 = (0.01 * torch.randn(1, V, 3, generator=g)).requires_grad_()
+    verts1, joints1, _, _ = smal(beta.detach(), theta, del_v=dv1)
+    ((verts1 * vertex_probe(verts1.shape, 4)).sum() + (joints1 * vertex_probe(joints1.shape, 5)).sum()).backward()
+    out.update(b_theta=theta.numpy(), b_del_v=dv1.detach().numpy(), b_verts=verts1.detach().numpy(), b_joints=joints1.detach().numpy(),
+               b_grad_del_v=dv1.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, f"lbs_extra_{key}.npz"), **out)
+    print(f"lbs_extra_{key}: loss={loss.item():.6f}")
+
+
 def fitter_goldens(key, pkl_path, S=64, N=3):
     cfg, dd = install_stubs(pkl_path)
     import smal_fitter.fitter as ref_fitter
@@ -226,6 +262,91 @@ def fitter_goldens(key, pkl_path, S=64, N=3):
     print(f"fitter_{key}: loss={loss.item():.6f}", {k: round(v.item(), 6) for k, v in objs.items()})
 
 
+def export_golden(N=3):
+    """Fit-result interchange formats written / read by the REAL reference code:
+
+    * ``checkpoint_ref/<frame:04>/st1_ep7.pkl`` - the per-frame parameter dict ``SMALFitter.generate_visualization``
+      hands to ``ImageExporter.export`` (fitter.py:241-261,507; optimize_to_joints.py:48-63: ``pkl.dump``), built with the
+      reference's own expressions from a reference ``SMALFitter``; ``checkpoint_ref/expected.npz`` holds that fitter's
+      parameters after the reference's ``load_checkpoint`` (fitter.py:352-371) has read the files back.
+    * ``animation_ref.npz`` / ``animation_ref.json`` - written by the reference ``AnimationRecorder``
+      (smal_fitter/neuralSMIL/animation_export.py:101-193) from ``animation_ref_inputs.npz``.
+    """
+    import json
+    import pickle as pkl
+    import shutil
+
+    key, pkl_path = "stick", MODELS["stick"]
+    cfg, dd = install_stubs(pkl_path)
+    import smal_fitter.fitter as ref_fitter
+
+    class _Cams:
+        fov = torch.full((N,), 60.0)
+
+    class FakeRenderer(torch.nn.Module):
+        def __init__(self, image_size, device):
+            super().__init__()
+            self.image_size, self.cameras = image_size, _Cams()
+
+    ref_fitter.Renderer = FakeRenderer
+    J = len(dd["J_names"])
+    S = 16
+    g = torch.Generator().manual_seed(31337)
+    data = (torch.zeros(N, 3, S, S), torch.zeros(N, 1, S, S), torch.zeros(N, J, 2), torch.ones(N, J).long())
+    fitter = ref_fitter.SMALFitter("cpu", data, N, -1, False)
+    with torch.no_grad():
+        fitter.global_rotation += 0.1 * torch.randn(N, 3, generator=g)
+        fitter.joint_rotations += 0.1 * torch.randn(N, J - 1, 3, generator=g)
+        fitter.trans += 0.1 * torch.randn(N, 3, generator=g)
+        fitter.betas += 0.3 * torch.randn(fitter.betas.shape, generator=g)
+        fitter.log_beta_scales += 0.05 * torch.randn(N, J, 3, generator=g)
+        fitter.betas_trans += 0.02 * torch.randn(N, J, 3, generator=g)
+    fitter.fov = torch.nn.Parameter(torch.tensor([55.0, 60.0, 65.0])[:N])
+    batch_range = list(range(N))
+    batch_params = {  # the reference's expressions (fitter.py:241-256), evaluated on the reference's own module
+        "global_rotation": fitter.global_rotation[batch_range] * fitter.global_mask,
+        "joint_rotations": fitter.joint_rotations[batch_range] * fitter.rotation_mask,
+        "betas": fitter.betas.expand(len(batch_range), fitter.n_betas),
+        "trans": fitter.trans[batch_range],
+        "fov": fitter.fov[batch_range],
+        "log_betascale": fitter.log_beta_scales.expand(len(batch_range), fitter.joint_rotations.shape[1] + 1, 3),
+        "betas_trans": fitter.betas_trans.expand(len(batch_range), fitter.joint_rotations.shape[1] + 1, 3),
+    }
+    root = os.path.join(OUT, "checkpoint_ref")
+    shutil.rmtree(root, ignore_errors=True)
+    for batch_id in batch_range:
+        img_parameters = {k: v[batch_id].cpu().data.numpy() for (k, v) in batch_params.items()}  # fitter.py:507
+        os.makedirs(os.path.join(root, "{0:04}".format(batch_id)))
+        with open(os.path.join(root, "{0:04}".format(batch_id), "st1_ep7.pkl"), "wb") as f:
+            pkl.dump(img_parameters, f)  # optimize_to_joints.py:56-60
+    fresh = ref_fitter.SMALFitter("cpu", data, N, -1, False)
+    with torch.no_grad():
+        fresh.load_checkpoint(root, "st1_ep7")
+    np.savez_compressed(os.path.join(root, "expected.npz"), **{n: p.detach().numpy() for n, p in fresh.named_parameters()},
+                        written_betas=fitter.betas.detach().numpy())
+    print("checkpoint_ref:", sorted(img_parameters), "loaded betas", fresh.betas.detach().numpy())
+
+    from smal_fitter.neuralSMIL.animation_export import AnimationRecorder
+
+    nJ, nBt, F = 6, 4, 5
+    g = torch.Generator().manual_seed(99)
+    frames = dict(global_rot=torch.randn(F, 1, 3, generator=g), joint_rot=torch.randn(F, 1, nJ - 1, 3, generator=g),
+                  trans=torch.randn(F, 1, 3, generator=g), betas=torch.randn(F, 1, nBt, generator=g),
+                  log_beta_scales=torch.randn(F, 1, nJ, 3, generator=g), betas_trans=torch.randn(F, 1, nJ, 3, generator=g),
+                  mesh_scale=torch.rand(F, 1, 1, generator=g) + 0.5, cam_rot=torch.randn(F, 1, 3, 3, generator=g),
+                  cam_trans=torch.randn(F, 1, 3, generator=g), fov=45.0 + torch.randn(F, 1, 1, generator=g))
+    base = os.path.join(OUT, "animation_ref")
+    rec = AnimationRecorder(output_path=base, rotation_representation="axis_angle", n_joints=nJ, n_betas=nBt,
+                            joint_names=[f"J_{i}" for i in range(nJ)], parents=[-1] + list(range(nJ - 1)), fps=25.0,
+                            static_joint_locs=True, ignore_hardcoded_body=True, source_checkpoint="ckpt.pth", source_input="clip.mp4",
+                            model_id="golden")
+    for i in range(F):
+        rec.record({k: v[i] for k, v in frames.items()})
+    out = rec.write()
+    np.savez_compressed(os.path.join(OUT, "animation_ref_inputs.npz"), **{k: v.numpy() for k, v in frames.items()})
+    print("animation_ref:", sorted(np.load(out["npz"]).files), json.load(open(out["json"]))["schema_version"])
+
+
 def posedirs_golden():
     """Pose blend shapes: no SMIL model ships a non-empty table, so a small synthetic model is pickled in the
     reference's schema, loaded by the REAL reference SMAL, and given a random posedirs table."""
@@ -262,6 +383,11 @@ def posedirs_golden():
 
 def main():
     os.makedirs(os.path.join(REPO, "data", "models"), exist_ok=True)
+    if "--extra" in sys.argv:  # only the files added in round 2 (the earlier ones stay byte-identical)
+        for key, p in MODELS.items():
+            lbs_extra_goldens(key, p)
+        export_golden()
+        return
     posedirs_golden()
     for key, p in MODELS.items():
         t = model_io.load_model(p)
@@ -269,6 +395,8 @@ def main():
         print("converted", p, "V", t.V, "F", t.F, "J", t.J, "nB", t.nB)
         lbs_goldens(key, p)
         fitter_goldens(key, p, S=64 if key == "stick" else 48)
+        lbs_extra_goldens(key, p)
+    export_golden()
 
 
 if __name__ == "__main__":

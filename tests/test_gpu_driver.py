@@ -116,3 +116,32 @@ def test_reference_style_driver_loop(tables):
     ref.begin_stage(2e-2)
     objs = ref.fit_step([25.0, 0, 0, 0, 0, 0], 500.0, window=W)
     assert abs(float(objs[:9].sum()) - losses[0][0]) <= 1e-4 * abs(losses[0][0])
+
+
+def _run_bench(*flags):
+    import json
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks_and_shards_like_one_rank():
+    """``python bench.py --gpus 2`` without a launcher starts torch.distributed.run as a child and relays rank 0's single
+    JSON line; two ranks (gloo, sharing this box's one GPU) over 2 x 16 frames end at the loss one rank reaches on the
+    same 32 frames: frames shard, the shared-parameter gradients are all-reduced, the temporal halo is exchanged."""
+    common = ["--workload", "tiny", "--steps", "3", "--warmup", "0", "--cpu-frames", "0"]
+    two = _run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", *common)
+    one = _run_bench("--gpus", "1", "--frames", "32", *common)
+    assert two["n_gpus"] == 2 and two["rehearsal"] is True and one["n_gpus"] == 1
+    assert two["config"]["frames_per_gpu"] == 16 and one["config"]["frames_per_gpu"] == 32
+    for k in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
+        assert k in two, k
+    assert "cpu_baseline" not in two
+    assert abs(two["final_loss"] - one["final_loss"]) <= 2e-4 * abs(one["final_loss"]), (two["final_loss"], one["final_loss"])

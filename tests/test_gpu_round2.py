@@ -1,0 +1,192 @@
+"""GPU tests of the drop-in surface added in round 2 (``pytest -m gpu``): ``del_v`` / rotation-matrix ``theta`` /
+one-row (broadcast) inputs of ``SMAL.__call__`` against vectors of the real reference, the reference-written per-frame
+checkpoint, hipGraph invalidation, the z_clip cull and the renderer's topology cache."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, vertex_probe
+from oracle import render_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("key", ["stick", "mouse"])
+def test_smal_del_v_rotation_matrices_and_broadcast_inputs_match_reference(key, golden, tables):
+    """reference smal_torch.py:244-248 (del_v), :288-289 (theta given as (B,J,3,3) matrices), and the inputs torch
+    broadcasts over the batch there (trans (1,3), betas_logscale (1,J,3)): outputs and every gradient of the REAL
+    reference's autograd."""
+    from smilify_amd.smal_torch import SMAL
+
+    g = golden(f"lbs_extra_{key}")
+    smal = SMAL(DEV, tables=tables(key))
+    leaf = {n: torch.from_numpy(g[n]).to(DEV).requires_grad_() for n in ("beta", "Rs", "trans", "del_v", "ls", "bt")}
+    assert leaf["trans"].shape[0] == 1 and leaf["ls"].shape[0] == 1 and leaf["Rs"].dim() == 4
+    verts, joints, Rs_o, v_shaped = smal(leaf["beta"], leaf["Rs"], trans=leaf["trans"], del_v=leaf["del_v"], betas_logscale=leaf["ls"],
+                                         betas_trans=leaf["bt"])
+    np.testing.assert_allclose(verts.detach().cpu().numpy(), g["verts"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(joints.detach().cpu().numpy(), g["joints"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(v_shaped.cpu().numpy(), g["v_shaped"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(Rs_o.cpu().numpy(), g["Rs"], rtol=0, atol=1e-7)
+    loss = (verts * vertex_probe(verts.shape, 2).to(DEV)).sum() + (joints * vertex_probe(joints.shape, 3).to(DEV)).sum()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-4 * abs(float(g["loss"])) + 1e-4
+    loss.backward()
+    for n, t in leaf.items():
+        want = g[f"grad_{n}"]
+        assert t.grad is not None and tuple(t.grad.shape) == want.shape, n
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(t.grad.cpu().numpy() / scale, want / scale, rtol=0, atol=3e-4, err_msg=f"{key}/{n}")
+    # one (1,V,3) offset shared by the batch, axis-angle pose
+    dv1 = torch.from_numpy(g["b_del_v"]).to(DEV).requires_grad_()
+    v1, j1, _, _ = smal(leaf["beta"].detach(), torch.from_numpy(g["b_theta"]).to(DEV), del_v=dv1)
+    np.testing.assert_allclose(v1.detach().cpu().numpy(), g["b_verts"], rtol=1e-4, atol=5e-6)
+    ((v1 * vertex_probe(v1.shape, 4).to(DEV)).sum() + (j1 * vertex_probe(j1.shape, 5).to(DEV)).sum()).backward()
+    want = g["b_grad_del_v"]
+    np.testing.assert_allclose(dv1.grad.cpu().numpy() / np.abs(want).max(), want / np.abs(want).max(), rtol=0, atol=3e-4)
+
+
+def test_smal_rejects_shapes_that_would_read_past_a_buffer(tables):
+    from smilify_amd.smal_torch import SMAL
+
+    t = tables("synthetic")
+    smal = SMAL(DEV, tables=t)
+    B = 3
+    beta, theta = torch.zeros(B, t.nB, device=DEV), torch.zeros(B, t.J, 3, device=DEV)
+    for kw in (dict(trans=torch.zeros(2, 3, device=DEV)), dict(del_v=torch.zeros(2, t.V, 3, device=DEV)),
+               dict(del_v=torch.zeros(B, t.V - 1, 3, device=DEV)), dict(betas_logscale=torch.zeros(2, t.J, 3, device=DEV)),
+               dict(betas_trans=torch.zeros(B, t.J - 1, 3, device=DEV)), dict(v_template=torch.zeros(t.V + 1, 3, device=DEV))):
+        with pytest.raises(ValueError):
+            smal(beta, theta, **kw)
+    with pytest.raises(ValueError):
+        smal(torch.zeros(2, t.nB, device=DEV), theta)
+    # a custom template receives the batch-summed vertex gradient
+    vt = torch.from_numpy(t.v_template).to(DEV).requires_grad_()
+    verts, _, _, _ = smal(beta, theta, v_template=vt)
+    verts.sum().backward()
+    assert vt.grad.shape == (t.V, 3) and torch.allclose(vt.grad, torch.full_like(vt.grad, float(B)), atol=1e-4)
+
+
+def test_load_checkpoint_reads_what_the_reference_wrote(tables):
+    """tests/golden/checkpoint_ref: per-frame pickles in the reference exporter's layout and key set
+    (optimize_to_joints.py:48-63, fitter.py:241-261,507); expected.npz = the reference's own load_checkpoint result."""
+    from smilify_amd import synthetic
+
+    root = os.path.join(GOLDEN, "checkpoint_ref")
+    exp = np.load(os.path.join(root, "expected.npz"))
+    t = tables("stick")
+    N = exp["trans"].shape[0]
+    f = synthetic.make_problem(t, N, 1, 32, DEV, seed=1, window=N)
+    f.load_checkpoint(root, "st1_ep7")
+    for n in ("global_rotation", "joint_rotations", "trans", "betas"):
+        np.testing.assert_allclose(getattr(f, n).detach().cpu().numpy(), exp[n], rtol=0, atol=1e-7, err_msg=n)
+    # the reference averages the per-frame scale tables into ONE (J,3) table (fitter.py:371)
+    np.testing.assert_allclose(f.log_beta_scales.detach().cpu().numpy().reshape(exp["log_beta_scales"].shape), exp["log_beta_scales"], atol=1e-7)
+    loss, _ = f(list(range(N)), synthetic.STAGE1_WEIGHTS, 1)  # still a working fitter
+    assert torch.isfinite(loss)
+    # and what this build exports has the reference's key set, shapes and (for untouched parameters) values
+    want = pickle.load(open(os.path.join(root, "0001", "st1_ep7.pkl"), "rb"))
+    got = f.export_parameters(1)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert np.asarray(got[k]).shape == np.asarray(want[k]).shape, k
+    np.testing.assert_allclose(got["joint_rotations"], want["joint_rotations"], atol=1e-7)
+    np.testing.assert_allclose(got["trans"], want["trans"], atol=1e-7)
+
+
+def test_graph_replay_is_invalidated_by_camera_mask_and_workspace_changes(tables):
+    """A captured iteration bakes in device addresses; after set_cameras / a re-assigned mask / a regrown workspace the
+    next fit_step_graph must re-capture and agree with the eager step."""
+    from smilify_amd import synthetic
+    from smilify_amd.cameras import look_at_view_transform
+
+    t = tables("synthetic")
+
+    def make():
+        f = synthetic.make_problem(t, 4, 2, 40, DEV, radius=2.3, seed=9, window=2)
+        f.begin_stage(synthetic.STAGE1_LR)
+        return f
+
+    fe, fg = make(), make()
+    w, wt = synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL
+
+    def both():
+        a = fe.fit_step(w, wt).clone()
+        b = fg.fit_step_graph(w, wt).clone()
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=1e-6)
+
+    both()
+    both()
+    first = fg._graph["graph"]
+    R, T = look_at_view_transform(2.6, 25.0, np.array([30.0, 200.0]), device=DEV)
+    for f in (fe, fg):
+        f.set_cameras(R, T)
+    assert fg._graph is None
+    both()
+    assert fg._graph["graph"] is not first
+    second = fg._graph["graph"]
+    mask = torch.ones(t.J - 1, 3, device=DEV)
+    mask[2:] = 0.0
+    for f in (fe, fg):
+        f.rotation_mask = mask.clone()
+    both()
+    assert fg._graph["graph"] is not second
+    third = fg._graph["graph"]
+    both()
+    assert fg._graph["graph"] is third          # nothing changed: replayed
+    fg.device_model._ws = None                  # as a larger Renderer call on the same model would do: workspace replaced
+    both()
+    assert fg._graph["graph"] is not third
+
+
+def test_z_clip_culls_faces_entirely_nearer_than_half_znear(tables):
+    """MeshRasterizer's z_clip_value = znear / 2 (5e-4): a mesh lying entirely between the camera plane and z_clip renders
+    nothing; with the cull disabled (z_clip = 0) the same vertices do render.  Same rule in the oracle."""
+    from smilify_amd import engine as eng
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 32
+    g = torch.Generator().manual_seed(0)
+    ndc = torch.empty(1, t.V, 3)
+    ndc[..., :2] = 0.6 * (torch.rand(1, t.V, 2, generator=g) - 0.5)
+    ndc[..., 2] = 1e-4 + 3e-4 * torch.rand(1, t.V, generator=g)       # every vertex in (1e-4, 4e-4) < 5e-4
+    assert float(eng.silhouette_forward(dm, ndc.to(DEV), S).abs().max()) == 0.0
+    ref, _ = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    assert float(np.abs(ref).max()) == 0.0
+    rs = eng.raster_settings()
+    rs.z_clip = 0.0
+    got = eng.silhouette_forward(dm, ndc.to(DEV), S, rs).cpu().numpy()
+    render_ref.set_z_clip(0.0)
+    try:
+        ref0, _ = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    finally:
+        render_ref.set_z_clip(5e-4)
+    assert ref0.sum() > 1.0 and np.abs(got - ref0).mean() < 1e-4
+
+
+def test_renderer_topology_cache_is_keyed_by_content(tables):
+    from smilify_amd.p3d_renderer import Renderer
+    from smilify_amd.smal_torch import SMAL
+
+    t = tables("synthetic")
+    smal = SMAL(DEV, tables=t)
+    rend = Renderer(32, DEV)
+    rend.bind_model(smal.device_model)
+    verts, joints, _, _ = smal(torch.zeros(1, t.nB, device=DEV), torch.zeros(1, t.J, 3, device=DEV))
+    sil_a, _ = rend(verts, joints, smal.faces)
+    assert rend._device_model(smal.faces, t.V) is smal.device_model and not rend._topologies
+    # int32 copies (a fresh temporary per call in the reference's calling code) hit the bound model by content
+    assert rend._device_model(smal.faces.to(torch.int32), t.V) is smal.device_model
+    # same (V, F) counts, different triangles: must NOT be rendered with the bound model's table
+    other = smal.faces.clone()
+    other[: t.F // 2] = other[: t.F // 2].flip(0)[:, [0, 2, 1]]
+    other[::3] = other[0]
+    dm_other = rend._device_model(other, t.V)
+    assert dm_other is not smal.device_model and len(rend._topologies) == 1
+    assert rend._device_model(other.clone().to(torch.int32), t.V) is dm_other and len(rend._topologies) == 1
+    sil_b, _ = rend(verts, joints, other)
+    assert (sil_a - sil_b).abs().max() > 1e-3

@@ -108,7 +108,8 @@ struct RasterArgs {
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
     // scratch per resident workgroup
-    uint32_t *slist;         // F face ids of the current tile
+    uint32_t *slist;         // F face ids of the current tile (ascending id) ...
+    uint32_t *slist2;        // ... and the same ids ordered near to far by the first radix digit of their nearest vertex depth
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
     uint32_t *sz;            // depth bits
@@ -119,6 +120,7 @@ struct RasterArgs {
     float *clf;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
+    int stop_after;          // RASTER_EXPERIMENT builds: ablation (0 list, 1 + staging, 2 + pair sweep, 3 + blend / select; else all)
 };
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
@@ -273,7 +275,9 @@ __device__ __forceinline__ float sq2(float x, float y) { return __fmaf_rn(x, x, 
 
 // Branch-free: every lane computes everything; `cand` says whether the pair exists.
 __device__ __forceinline__ void eval_pair(const FaceRec &f, float px, float py, float dxp, float dyp, float blur, PairEval &e) {
-    const bool in_bb = !(px > f.xmax || px < f.xmin || py > f.ymax || py < f.ymin);
+    // inside [xmin, xmax] x [ymin, ymax] <=> the median of (p, lo, hi) is p itself (two instructions per axis; a masked
+    // pixel sits at 3e38 and fails; face coordinates are finite, the setup kernel drops the others)
+    const bool in_bb = (__builtin_amdgcn_fmed3f(px, f.xmin, f.xmax) == px) & (__builtin_amdgcn_fmed3f(py, f.ymin, f.ymax) == py);
     e.w0 = fmaf(f.A0, dxp, fmaf(f.B0, dyp, f.C0));
     e.w1 = fmaf(f.A1, dxp, fmaf(f.B1, dyp, f.C1));
     e.w2 = fmaf(f.A2, dxp, fmaf(f.B2, dyp, f.C2));
@@ -323,13 +327,18 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
 // tile kernel
 // ---------------------------------------------------------------------------------------------
 #define GCHUNK 64            // faces whose gradient accumulators are live in pass 3 (a multiple of DCHUNK)
+#define GCOPIES 2            // private copies of those accumulators (measured: 1 -> 2 copies -3 %, 4 copies lose it again to zeroing and flushing)
 struct alignas(16) DenseLds {
     union {
         float rec[DCHUNK * FSTR];    // pass 1: staged face records
-        struct {                     // passes 2 / 3 (fp64: ds_add_f64 runs at full rate on gfx950, ds_add_f32 at ~3
-            double gacc[GCHUNK * 6]; //              cycles per active lane)
-            double plog[WAVE];       // pass 2: sum of log2(1 - p_k)
-        };
+        struct {
+            // pass 3: gradient accumulators of GCHUNK faces x 3 vertices, (x, y) packed as two 32-bit fixed-point numbers
+            // in one 64-bit word so that one ds_add_u64 adds both; GCOPIES private copies indexed by lane & (GCOPIES - 1)
+            // keep the consecutive lanes of one face's run of records off each other's address (measured: the four
+            // 13-way conflicting ds_add_f64 per record this replaces were more than half of pass 3)
+            unsigned long long gacc[GCOPIES][GCHUNK * 3];
+            double plog[WAVE];       // pass 2: sum of log2(1 - p_k) (fp64: ds_add_f64 runs at full rate on gfx950,
+        };                           //         ds_add_f32 at ~3 cycles per active lane)
     };
     // select: [bucket / 2][pixel], two 16-bit counts per word; the first digit is counted by pass 1
     uint32_t hist[(1 << SEL_BITS) / 2 * WAVE];
@@ -338,9 +347,9 @@ struct alignas(16) DenseLds {
         float4 pgrad[WAVE];          // later: {gradient coefficient, threshold depth bits, last kept list position, -}
     };
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
-    int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run
+    int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run (list phase: bucket counters)
+    int bstart[(1 << SEL_BITS) + 1]; // first list position of every depth bucket of the near-to-far list
 };
-static_assert(sizeof(double) * (GCHUNK * 6 + WAVE) <= sizeof(float) * DCHUNK * FSTR, "pass 2/3 accumulators must fit the record buffer");
 
 // Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
 // VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
@@ -430,6 +439,34 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
     kmin = lo;
     kmax = hi;
     return cnt;
+}
+
+// Near-to-far order for the tile's list: a counting sort of the faces by the first radix digit (the same digit the
+// records' depths are histogrammed by) of their NEAREST vertex depth.  A record's depth is at least its face's nearest
+// vertex depth, so once every face of digit <= d has been processed the per-pixel record counts of digits <= d are final:
+// pass 1 uses that to stop collecting records for pixels that already hold K nearer ones (the reference keeps the K = 100
+// nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
+// Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
+// recovers through `out`.  bstart[d] = first position of bucket d, bstart[2^b1] = n.
+__device__ __forceinline__ void sort_list_near_to_far(const float2 *__restrict__ fzr_n, const uint32_t *list, uint32_t *out, int n,
+                                                      uint32_t kmin, int shift1, int b1, DenseLds &lds, int lane) {
+    const int n_buckets = 1 << b1;
+    lds.start[lane] = 0;
+    __syncthreads();
+    auto digit_of = [&](uint32_t f) { return (int)(((__float_as_uint(fzr_n[f].x) - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
+    for (int i = lane; i < n; i += WAVE) atomicAdd(&lds.start[digit_of(list[i])], 1);
+    __syncthreads();
+    const int c = lane < n_buckets ? lds.start[lane] : 0;
+    const int incl = wave_scan_add(c);
+    __syncthreads();
+    if (lane <= n_buckets) lds.bstart[lane] = lane < n_buckets ? incl - c : n;
+    lds.start[lane] = incl - c;  // running cursor of every bucket
+    __syncthreads();
+    for (int i = lane; i < n; i += WAVE) {
+        const uint32_t f = list[i];
+        out[atomicAdd(&lds.start[digit_of(f)], 1)] = f;
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list,
@@ -536,6 +573,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
     const int lane = threadIdx.x;
     uint32_t *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
+    uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     uint32_t *const sz = a.sz + rec0, *const smeta = a.smeta + rec0;
@@ -586,14 +624,22 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         uint32_t kmin, kmax;  // bounds of the depth keys of this tile
         const int list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
         const bool may_truncate = list_total > K;
-        const int n_chunks = (list_total + DCHUNK - 1) / DCHUNK;
         // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
         // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
         const uint32_t krange = kmax - kmin;
         const int nbits0 = krange ? 32 - __clz(krange) : 0;
         const int b1 = min(SEL_BITS, nbits0), shift1 = nbits0 - b1;
-        __syncthreads();  // the list stores are visible to the staging loads below
+        __syncthreads();  // the list stores are visible to the loads below
+        // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
+        const uint32_t *lst = slist;
+        if (may_truncate) {
+            sort_list_near_to_far(a.fzr + (size_t)n * a.F, slist, slist2, list_total, kmin, shift1, b1, lds, lane);
+            lst = slist2;
+        }
         TMARK(0)
+#ifdef RASTER_EXPERIMENT
+        if (a.stop_after == 0) continue;
+#endif
 
         // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
         // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
@@ -613,23 +659,58 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             // ---------------- pass 1: every pair inside a face's pixel box, once --------------------------------
             int vbase = 0;  // records written so far (wave-uniform)
             bool fits = true;
+            // Pixels that cannot keep any further record ("closed"): they already hold K records in depth digits that are
+            // final, i.e. below the digit of the first face not yet processed.  Lane = pixel keeps its count of final records.
+            int final_digits = 0, final_cnt = 0;
+            unsigned long long open_px = __ballot(in_img && mine);
+            int ox0 = sx0, ox1 = sx1, oy0 = sy0, oy1 = sy1;  // bounding box of the open pixels
+            int chunks_done = 0;
             for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
+                if (may_truncate) {
+                    // digit of this chunk's first face = number of buckets that start at or before it, minus one
+                    const int d0 = __popcll(__ballot(lane < (1 << b1) && lds.bstart[lane] <= c0)) - 1;
+                    if (d0 > final_digits) {  // wave-uniform: digits [final_digits, d0) have just become final
+                        for (int d = final_digits; d < d0; ++d) {
+                            const uint32_t hw = lds.hist[(d >> 1) * WAVE + lane];
+                            final_cnt += (int)((d & 1) ? hw >> 16 : hw & 0xFFFFu);
+                        }
+                        final_digits = d0;
+                        open_px &= ~__ballot(final_cnt >= K);
+                        if (open_px == 0ull) break;  // every pixel of the (sub-)tile is closed: the remaining faces are all farther
+                        unsigned int cols = 0u;
+                        oy0 = 8; oy1 = -1;
+                        for (int y = 0; y < TILE; ++y) {
+                            const unsigned int row = (unsigned int)(open_px >> (8 * y)) & 0xFFu;
+                            cols |= row;
+                            if (row) { oy0 = min(oy0, y); oy1 = y; }
+                        }
+                        ox0 = (int)__builtin_ctz(cols); ox1 = 31 - (int)__builtin_clz(cols);
+                    }
+                }
                 const int m = min(DCHUNK, list_total - c0);
-                stage_faces(a, vn, slist, c0, m, lds.rec, lane, cx, cy);
+                stage_faces(a, vn, lst, c0, m, lds.rec, lane, cx, cy);
                 if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
+                chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
+#ifdef RASTER_EXPERIMENT
+                if (a.stop_after == 1) continue;
+#endif
                 // lane = staged face: pixel box of its blurred bounding box inside this sub-tile (same rounding slack as the
                 // setup kernel: a superset; eval_pair applies the exact test)
-                int cf = 0, packed = 0;
+                int cf = 0, packed = 0, packed2 = 0;
                 if (lane < m) {
                     const FaceRec &fr = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FSTR);
                     const int xi_lo = (int)ceilf(((fr.xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((fr.xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
                     const int yi_lo = (int)ceilf(((fr.ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((fr.ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-                    const int bx0 = max(a.S - 1 - xi_hi - tx * TILE, sx0), bx1 = min(a.S - 1 - xi_lo - tx * TILE, sx1);
-                    const int by0 = max(a.S - 1 - yi_hi - ty * TILE, sy0), by1 = min(a.S - 1 - yi_lo - ty * TILE, sy1);
+                    const int bx0 = max(a.S - 1 - xi_hi - tx * TILE, ox0), bx1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
+                    const int by0 = max(a.S - 1 - yi_hi - ty * TILE, oy0), by1 = min(a.S - 1 - yi_lo - ty * TILE, oy1);
                     if (bx0 <= bx1 && by0 <= by1) {
-                        cf = (bx1 - bx0 + 1) * (by1 - by0 + 1);
-                        packed = (bx0 << 13) | (by0 << 16) | ((bx1 - bx0) << 19);
+                        const int bw = bx1 - bx0 + 1;
+                        cf = bw * (by1 - by0 + 1);
+                        // what a pair needs to find its pixel: pair r of the box sits in box row r / bw, computed as
+                        // (r * inv) >> 16 with inv = floor(65536 / bw) + 1 (exact for r < 64, bw <= 8), and its pixel is
+                        // first + r + (r / bw) * (8 - bw)
+                        packed2 = (65536 / bw + 1) | ((8 - bw) << 17) | ((by0 * TILE + bx0) << 20);
                     }
                 }
                 const int incl = wave_scan_add(cf);
@@ -648,12 +729,12 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 if (cf > 0) {
                     atomicOr(reinterpret_cast<uint32_t *>(lds.start) + (off >> 5), 1u << (off & 31));
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nonempty >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nonempty, 0u));
-                    reinterpret_cast<uint32_t *>(lds.psel)[rank] = (uint32_t)packed | ((uint32_t)lane << 22);
+                    lds.psel[rank] = make_uint2((uint32_t)packed | ((uint32_t)lane << 13), (uint32_t)packed2);
                 }
                 lds_fence();
                 const uint32_t fl_lo = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane) & 63];
                 const uint32_t fl_hi = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane + 1) & 63];
-                const int pk_rank = (int)reinterpret_cast<const uint32_t *>(lds.psel)[lane & (DCHUNK - 1)];
+                const uint2 pk_rank = lds.psel[lane & (DCHUNK - 1)];
                 lds_fence();
 #ifdef DBG_TIMERS
                 { const unsigned long long now_ = __builtin_readcyclecounter(); tstage_ += now_ - tlast; tlast = now_; }
@@ -666,21 +747,22 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const int r = min((int)(carry + below + own) - 1, DCHUNK - 1);
                     carry += (uint32_t)(__popc(wlo) + __popc(whi));
                     const bool valid = q0 + lane < n_pairs;
-                    const int pk = __shfl(pk_rank, max(r, 0), WAVE);
-                    const int fs = (pk >> 22) & (DCHUNK - 1);
-                    const int rr = q0 + lane - (pk & 0x1FFF);
-                    const int bw = ((pk >> 19) & 7) + 1;
-                    const int dy = (int)((float)rr * __builtin_amdgcn_rcpf((float)bw) + 1e-3f);  // rr < 64, bw <= 8: exact
-                    const int p = (((((pk >> 16) & 7) + dy) << 3) + ((pk >> 13) & 7) + (rr - dy * bw)) & 63;
+                    const uint32_t pk = (uint32_t)__shfl((int)pk_rank.x, max(r, 0), WAVE), pk2 = (uint32_t)__shfl((int)pk_rank.y, max(r, 0), WAVE);
+                    const int fs = (int)((pk >> 13) & (DCHUNK - 1));
+                    const uint32_t rr = (uint32_t)(q0 + lane) - (pk & 0x1FFFu);
+                    const uint32_t dy = __umul24(rr, pk2 & 0x1FFFFu) >> 16;
+                    const int p = (int)((__umul24(dy, (pk2 >> 17) & 7u) + rr + (pk2 >> 20)) & 63u);
                     const float4 pt = lds.pixt[p];
                     const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FSTR);
                     PairEval e;
                     eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
-                    const bool cand = valid && e.cand;
+                    const bool cand = valid && e.cand && ((open_px >> p) & 1ull);
                     const unsigned long long cm = __ballot(cand);
                     if (cm == 0ull) continue;
                     // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
-                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(pair_depth(fr, e)), kmin), kmax)) : 3.0e38f;
+                    // ... and never nearer than the face's nearest vertex (rounding of the convex combination), so that a record's
+                    // digit is at least its face's: the closing rule above relies on it
+                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(fmaxf(pair_depth(fr, e), fminf(fminf(fr.z0, fr.z1), fr.z2))), kmin), kmax)) : 3.0e38f;
                     const uint32_t zb = __float_as_uint(z);
                     const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (cand) {
@@ -706,10 +788,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 __syncthreads();
                 continue;
             }
-            if (lane == 0) scfirst[n_chunks] = (uint32_t)vbase;
+            if (lane == 0) scfirst[chunks_done] = (uint32_t)vbase;  // (chunks behind an early exit hold no records)
             STAT(21, vbase) STAT(26, 1) STAT(27, list_total)
             __syncthreads();  // also: record stores of other lanes are visible from here on
             TMARK(1)
+#ifdef RASTER_EXPERIMENT
+            if (a.stop_after == 1 || a.stop_after == 2) { p_lo += span; continue; }
+#endif
 
             // ---------------- select + pass 2 ---------------------------------------------------------------------
             // K-th smallest depth of every pixel that has more than K candidates, and log2 of every kept blend factor summed
@@ -737,6 +822,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
             int n_cmp = 0;
+            float rmax2 = 0.f;  // largest |closest point - pixel|^2 over the records: bounds the gradient sums of pass 3
             if (vbase > 0) {
                 struct Rec { uint32_t z, mt; float rx, ry; };
                 auto load_recs = [&](Rec (&r)[DGROUP], int g0) {
@@ -757,6 +843,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         const bool sure = valid & ((ps[u].y == 0u) | (d1 < ps[u].x));
                         const bool maybe = valid & (ps[u].y > 0u) & (d1 == ps[u].x);
                         const float dist = sq2(r[u].rx, r[u].ry);
+                        rmax2 = fmaxf(rmax2, dist);  // (the clamped tail repeats a record: harmless)
                         const float lf = __log2f(1.0f - face_prob(((r[u].mt >> 22) & 1u) ? -dist : dist, a.inv_sigma));
                         if (sure & (lf != 0.f)) atomicAdd(&lds.plog[r[u].mt & 63u], (double)lf);
                         if (any_trunc) {  // wave-uniform
@@ -804,12 +891,12 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     // select on the list position among the records whose depth equals the pixel's threshold
                     lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
                     __syncthreads();
-                    int pbits = 32 - __clz(max(list_total - 1, 1));
+                    int pbits = 32 - __clz(max(a.F - 1, 1));  // the tie key is the face id (the list is in near-to-far order)
                     uint32_t ppre = 0u;
                     int pneed = split ? need : 0, peq = 0;
                     auto pos_key = [&](uint32_t idx, uint32_t mt) {
                         // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
-                        return at(ckey, idx) == __float_as_uint(lds.pgrad[mt & 63u].y) ? ((mt >> 6) & 0xFFFFu) : 0xFFFFFFFFu;
+                        return at(ckey, idx) == __float_as_uint(lds.pgrad[mt & 63u].y) ? lst[(mt >> 6) & 0xFFFFu] : 0xFFFFFFFFu;
                     };
                     while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
                         const int b = min(SEL_BITS, pbits);
@@ -835,14 +922,22 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     for (int u = 0; u < DGROUP; ++u) {
                         const float4 pg = lds.pgrad[mt[u] & 63u];
                         const uint32_t zt_ = __float_as_uint(pg.y);
-                        const bool keep = (g0 + u * WAVE + lane < n_cmp) &
-                                          ((kk[u] < zt_) | ((kk[u] == zt_) & ((int)((mt[u] >> 6) & 0xFFFFu) <= __float_as_int(pg.z))));
+                        // a record AT the threshold depth of a pixel whose tie group straddles K is kept up to the cut in face id
+                        // (rare: the id is fetched only then)
+                        const bool in_range = g0 + u * WAVE + lane < n_cmp;
+                        const int cut = __float_as_int(pg.z);
+                        int fid = 0;
+                        if (in_range & (kk[u] == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[(mt[u] >> 6) & 0xFFFFu];
+                        const bool keep = in_range & ((kk[u] < zt_) | ((kk[u] == zt_) & (fid <= cut)));
                         if (keep & (lf[u] != 0.f)) atomicAdd(&lds.plog[mt[u] & 63u], (double)lf[u]);
                     }
                 }
                 __syncthreads();
             }
             TMARK(2)
+#ifdef RASTER_EXPERIMENT
+            if (a.stop_after == 3) { p_lo += span; continue; }
+#endif
             STAT(22, n_cmp) STAT(23, __popcll(__ballot(trunc))) STAT(24, __popcll(__ballot(lds.plog[lane] != 0.0)))
             const float alpha = exp2f((float)lds.plog[lane]);
             TMARK(3)
@@ -875,20 +970,31 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             STAT(25, __popcll(__ballot(active)))
             if (MODE != MODE_FWD && __ballot(active) != 0ull) {
                 float *dn = a.d_ndc + (size_t)n * a.V * 2;
-                lds.pgrad[lane] = make_float4(active ? coef : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
+                // Fixed point for the LDS accumulators.  One accumulator component receives at most one record per pixel,
+                // each of magnitude <= 2 |r| |coef_pixel| p_k max(t, 1 - t) <= 2 r_max |coef_pixel|, so no partial sum
+                // exceeds bound = 2 r_max sum |coef_pixel|.  With scale = the power of two that maps `bound` into [2^29, 2^30)
+                // every rounded contribution sum stays below 2^31 (plus at most 64 half-units of rounding), the scaling is
+                // exact, and the resolution is bound / 2^30: ~1e-9 of the tile's largest possible gradient sum, below the
+                // fp32 rounding of the global atomics the sums end in.  Integer sums are order independent.
+                const float csum = wave_sum(active ? fabsf(coef) : 0.f);
+                const float bound = 2.0f * sqrtf(wave_max(rmax2)) * csum;
+                const float fx_scale = (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
+                const float fx_inv = fx_scale > 0.f ? 1.0f / fx_scale : 0.f;
+                lds.pgrad[lane] = make_float4(active ? coef * fx_scale : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
                 __syncthreads();
                 constexpr int GR = GCHUNK / DCHUNK;
-                for (int ch = 0; ch < n_chunks; ch += GR) {
-                    const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[min(ch + GR, n_chunks)];
+                const uint32_t copy_off = (uint32_t)(lane & (GCOPIES - 1)) * (GCHUNK * 3);
+                for (int ch = 0; ch < chunks_done; ch += GR) {
+                    const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[min(ch + GR, chunks_done)];
                     if (i_beg == i_end) continue;
                     // vertex ids of this chunk's faces: requested now, used by the flush
                     const int fch = ch * DCHUNK + lane;
                     int vi0 = 0, vi1 = 0, vi2 = 0;
                     if (fch < list_total) {
-                        const int f = (int)slist[fch];
+                        const int f = (int)lst[fch];
                         vi0 = a.faces[3 * f]; vi1 = a.faces[3 * f + 1]; vi2 = a.faces[3 * f + 2];
                     }
-                    for (int i_ = lane; i_ < GCHUNK * 6; i_ += WAVE) lds.gacc[i_] = 0.0;
+                    for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
                     __syncthreads();
                     struct GRec { uint32_t z, mt; float rx, ry, t; };
                     auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
@@ -911,19 +1017,29 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             const uint32_t zt_ = __float_as_uint(pg[u].y);
                             const bool inside = ((mt >> 22) & 1u) != 0u;
                             const float dist = sq2(r[u].rx, r[u].ry);
-                            float gd = pg[u].x * face_prob(inside ? -dist : dist, a.inv_sigma);  // d L / d (signed dist)
-                            gd = inside ? -gd : gd;                                               // d L / d (unsigned squared distance)
-                            const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & (pos <= __float_as_int(pg[u].z))));
+                            float gd = pg[u].x * face_prob(inside ? -dist : dist, a.inv_sigma);  // scale * d L / d (signed dist)
+                            gd = inside ? -gd : gd;                                               // ... / d (unsigned squared distance)
+                            const int cut = __float_as_int(pg[u].z);
+                            int fid = 0;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
+                            if (valid & (r[u].z == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[pos];
+                            const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & (fid <= cut)));
                             const float t = r[u].t;
                             const int edge = (int)(mt >> 23);
-                            const int ia = edge == 2 ? 2 : 0, ib = edge == 0 ? 2 : 4;  // accumulator slots of the edge's end points
+                            const int va = edge == 2 ? 1 : 0, vb = edge == 0 ? 1 : 2;  // end points of the closest edge
                             const float ex = 2.0f * r[u].rx * gd, ey = 2.0f * r[u].ry * gd;
+                            const float bx = t * ex, by = t * ey;
+#ifdef RASTER_EXPERIMENT
+                            if (a.stop_after == 4) { if (keep && ex + ey + t == 123.456f) lds.gacc[0][0] = 1ull; continue; }  // no LDS atomics
+#endif
                             if (keep) {
-                                double *acc = lds.gacc + (pos % GCHUNK) * 6;
-                                atomicAdd(acc + ia, (double)((1.0f - t) * ex));
-                                atomicAdd(acc + ia + 1, (double)((1.0f - t) * ey));
-                                atomicAdd(acc + ib, (double)(t * ex));
-                                atomicAdd(acc + ib + 1, (double)(t * ey));
+                                // (x, y) -> x * 2^32 + y as 64-bit two's complement: a negative y borrows one from the high word
+                                auto pack = [](float x, float y) {
+                                    const int qx = __float2int_rn(x), qy = __float2int_rn(y);
+                                    return ((unsigned long long)(uint32_t)(qx + (qy >> 31)) << 32) | (unsigned long long)(uint32_t)qy;
+                                };
+                                unsigned long long *acc = &lds.gacc[0][0] + copy_off + (uint32_t)(pos % GCHUNK) * 3u;
+                                atomicAdd(acc + va, pack(ex - bx, ey - by));
+                                atomicAdd(acc + vb, pack(bx, by));
                             }
                         }
                     };
@@ -938,14 +1054,18 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         }
                     }
                     __syncthreads();
-                    if (fch < list_total) {  // flush: one global atomic per touched vertex component
-                        const double *acc = lds.gacc + lane * 6;
-                        if (acc[0] != 0.0) atomicAdd(&dn[2 * vi0], (float)acc[0]);
-                        if (acc[1] != 0.0) atomicAdd(&dn[2 * vi0 + 1], (float)acc[1]);
-                        if (acc[2] != 0.0) atomicAdd(&dn[2 * vi1], (float)acc[2]);
-                        if (acc[3] != 0.0) atomicAdd(&dn[2 * vi1 + 1], (float)acc[3]);
-                        if (acc[4] != 0.0) atomicAdd(&dn[2 * vi2], (float)acc[4]);
-                        if (acc[5] != 0.0) atomicAdd(&dn[2 * vi2 + 1], (float)acc[5]);
+                    if (fch < list_total) {  // flush: sum the copies, unpack, one global atomic per touched vertex component
+                        const int vi[3] = {vi0, vi1, vi2};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            unsigned long long tot = 0ull;
+#pragma unroll
+                            for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][lane * 3 + k];
+                            const int qy = (int)(uint32_t)tot;
+                            const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
+                            if (qx != 0) atomicAdd(&dn[2 * vi[k]], (float)qx * fx_inv);
+                            if (qy != 0) atomicAdd(&dn[2 * vi[k] + 1], (float)qy * fx_inv);
+                        }
                     }
                     __syncthreads();
                 }
@@ -993,10 +1113,10 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: F face ids, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (five record + three compact) words
+// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (five record + three compact) words
 #define N_STREAMS 8
 static inline size_t scratch_bytes(int grid, int F) {
-    return (size_t)grid * (align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+    return (size_t)grid * (2 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
 
@@ -1045,6 +1165,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += 256;
         a.slist = (uint32_t *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
+        a.slist2 = (uint32_t *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
         ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
         const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(uint32_t);
@@ -1061,7 +1183,9 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;
+    a.stop_after = 99;
 #ifdef RASTER_EXPERIMENT
+    if (const char *e = getenv("SMIL_STOP")) a.stop_after = atoi(e);
     {
         uint32_t mask = 0xFFFFFFFFu;
         if (const char *e = getenv("SMIL_WRAP")) mask = (uint32_t)strtoul(e, nullptr, 0);

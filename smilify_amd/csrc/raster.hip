@@ -54,7 +54,8 @@
 #define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
 #define REC_PAD 64          // slack so that a clamped read stays inside the allocation
-#define RESIDENT_PER_CU 14  // single-wave workgroups per CU (10.5 KB LDS each: 15 would fit, no faster; 122 VGPRs allow 16)
+#define RESIDENT_PER_CU 16  // single-wave workgroups per CU: what 128 VGPRs and 9.9 KB of LDS per workgroup allow (measured 10 ... 14: every
+                            // further workgroup still shortens the launch)
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
@@ -78,10 +79,14 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 // a fifth of the whole launch must not start them last.
 // Two arrays of N * tiles entries hold two classes each (one filled from the front, one from the back).
 #define N_CLASSES 4
-#define CLASS_T0 65536        // class 0 is always dealt out in quarters (SPLIT0_LOG)
+#ifndef CLASS_T0
+#define CLASS_T0 65536        // class 0 can be dealt out in pieces (SPLIT0_LOG)
+#endif
 #define CLASS_T1 16384
 #define CLASS_T2 4096
-#define SPLIT0_LOG 2
+#ifndef SPLIT0_LOG
+#define SPLIT0_LOG 0          // log2 of the pieces every class-0 tile is dealt out in (0: whole; with near-to-far lists and closing the
+#endif                        // tiles with the longest lists finish early, and pieces only repeat their list walk: measured 2 -> 0: mouse -9 %)
 #define COUNT_TILES_MAX 8192  // per-tile face counts live in LDS (4 bytes each); larger images queue everything in the last class
 struct RasterCounters {
     unsigned int n_class[N_CLASSES];
@@ -338,18 +343,18 @@ struct alignas(16) DenseLds {
             // 13-way conflicting ds_add_f64 per record this replaces were more than half of pass 3)
             unsigned long long gacc[GCOPIES][GCHUNK * 3];
             double plog[WAVE];       // pass 2: sum of log2(1 - p_k) (fp64: ds_add_f64 runs at full rate on gfx950,
-        };                           //         ds_add_f32 at ~3 cycles per active lane)
+                                     //         ds_add_f32 at ~3 cycles per active lane)
+            float4 pgrad[WAVE];      // after pass 1: {gradient coefficient, threshold depth bits, tie cut (face id), -}
+        };
     };
     // select: [bucket / 2][pixel], two 16-bit counts per word; the first digit is counted by pass 1
     uint32_t hist[(1 << SEL_BITS) / 2 * WAVE];
-    union {
-        float4 pixt[WAVE];           // pass 1: px, py, px - cx, py - cy
-        float4 pgrad[WAVE];          // later: {gradient coefficient, threshold depth bits, last kept list position, -}
-    };
+    float2 pixt[WAVE];               // pass 1: pixel centre (px, py) in NDC
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run (list phase: bucket counters)
     int bstart[(1 << SEL_BITS) + 1]; // first list position of every depth bucket of the near-to-far list
 };
+static_assert(sizeof(DenseLds) * RESIDENT_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
 
 // Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
 // VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
@@ -588,8 +593,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
     // the launch finishes in a fraction of one tile's serial time.
     const unsigned int split_log = n_items * 8u <= gridDim.x ? 3u : (n_items * 4u <= gridDim.x ? 2u : (n_items * 2u <= gridDim.x ? 1u : 0u));
-    // The heaviest class is always dealt out in quarters: one such tile alone takes a good part of what a whole 512-image
-    // launch takes per workgroup.
+    // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
+    // near to far).
     const unsigned int split0_log = SPLIT0_LOG;
     const unsigned int units0 = nc0 << split0_log;
     const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
@@ -651,7 +656,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             const int sx0 = span >= 8 ? 0 : (p_lo & 7), sx1 = span >= 8 ? 7 : ((p_lo & 7) + span - 1);  // ... and columns
             // pixels outside the image or the sub-tile get a position no bbox can contain
             const float px = (in_img && mine) ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
-            lds.pixt[lane] = make_float4(px, py, px - cx, py - cy);
+            lds.pixt[lane] = make_float2(px, py);
             if (may_truncate)
                 for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
@@ -752,7 +757,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const uint32_t rr = (uint32_t)(q0 + lane) - (pk & 0x1FFFu);
                     const uint32_t dy = __umul24(rr, pk2 & 0x1FFFFu) >> 16;
                     const int p = (int)((__umul24(dy, (pk2 >> 17) & 7u) + rr + (pk2 >> 20)) & 63u);
-                    const float4 pt = lds.pixt[p];
+                    const float2 pc = lds.pixt[p];
+                    const float4 pt = make_float4(pc.x, pc.y, pc.x - cx, pc.y - cy);
                     const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FSTR);
                     PairEval e;
                     eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);

@@ -197,8 +197,10 @@ def main():
     hook = (lambda shared, objs: optimize.allreduce_shared(shared, objs, host_staged=staged)) if world > 1 else None
 
     def step():
-        first, last = fitter.boundary_rows()
-        hp, hn = optimize.exchange_halos(first, last, rank, world, host_staged=staged)
+        hp = hn = None
+        if world > 1:  # temporal halo: each shard's first / last parameter row
+            first, last = fitter.boundary_rows()
+            hp, hn = optimize.exchange_halos(first, last, rank, world, host_staged=staged)
         return fitter.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=window, halo_prev=hp, halo_next=hn,
                                shared_grad_hook=hook)
 

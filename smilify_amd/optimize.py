@@ -126,14 +126,21 @@ def configure_stage(fitter, stage_id: int, full_visibility: torch.Tensor) -> Non
 
 
 def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, world: int = 1, group=None,
-             on_epoch: Optional[Callable[[int, int, torch.Tensor], None]] = None, max_epochs: Optional[int] = None):
-    """Run the staged optimisation on this rank's shard; returns the per-epoch loss terms of the last stage."""
+             on_epoch: Optional[Callable[[int, int, torch.Tensor], None]] = None, max_epochs: Optional[int] = None,
+             use_graph: bool = True):
+    """Run the staged optimisation on this rank's shard; returns the per-epoch loss terms of the last stage.
+
+    Single rank: every stage captures its iteration (losses, backward, Adam) once in a hipGraph and replays it per epoch
+    (``SMALFitter.fit_step_graph``) - the device-side schedule of SURVEY.md 8(f) row 4; ``use_graph=False`` launches
+    the kernels one by one instead (identical results).  Several ranks: the eager step, because the shared-parameter
+    gradients pass through the RCCL all-reduce between backward and the optimiser step."""
     cfg = fitter.config
     stages = stages or stages_from_config(cfg)
     full_vis = fitter.target_visibility.clone()
     hook = None
     if world > 1:
         hook = lambda shared, objs: allreduce_shared(shared, objs, group)  # noqa: E731
+    graph = use_graph and world == 1
     history = []
     for stage_id, st in enumerate(stages):
         configure_stage(fitter, stage_id, full_vis)
@@ -141,10 +148,15 @@ def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, wo
         epochs = st.epochs if max_epochs is None else min(st.epochs, max_epochs)
         history = []
         for epoch in range(epochs):
-            first, last = fitter.boundary_rows()
-            halo_prev, halo_next = exchange_halos(first, last, rank, world, group)
-            objs = fitter.fit_step(st.weights, st.w_temp, window=cfg.WINDOW_SIZE, halo_prev=halo_prev, halo_next=halo_next,
-                                   shared_grad_hook=hook)
+            if graph:
+                objs = fitter.fit_step_graph(st.weights, st.w_temp, window=cfg.WINDOW_SIZE).clone()
+            else:
+                halo_prev = halo_next = None
+                if world > 1:
+                    first, last = fitter.boundary_rows()
+                    halo_prev, halo_next = exchange_halos(first, last, rank, world, group)
+                objs = fitter.fit_step(st.weights, st.w_temp, window=cfg.WINDOW_SIZE, halo_prev=halo_prev, halo_next=halo_next,
+                                       shared_grad_hook=hook)
             history.append(objs)
             if on_epoch is not None:
                 on_epoch(stage_id, epoch, objs)

@@ -145,3 +145,58 @@ def test_bench_launches_its_own_ranks_and_shards_like_one_rank():
         assert k in two, k
     assert "cpu_baseline" not in two
     assert abs(two["final_loss"] - one["final_loss"]) <= 2e-4 * abs(one["final_loss"]), (two["final_loss"], one["final_loss"])
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_two_stage_schedule_follows_the_reference_trajectory(use_graph, tables):
+    """optimize.optimize (one hipGraph per stage, or eager) against the reference's loop restated on the oracle
+    (optimize_to_joints.py:111-175): per stage a fresh torch.optim.Adam(betas=(0.5, 0.999)) over every parameter with fov in
+    its own lr = 1 group; stage 0 freezes joint rotations / betas / limb scales and masks the visibility to the torso
+    joints; every epoch = sum over windows of the window mean + temporal terms, one backward, one step."""
+    from conftest import oracle_model
+    from oracle import fitter_ref
+    from smilify_amd import optimize, synthetic
+
+    t = tables("synthetic")
+    frames, S, W = 4, 32, 2
+    f = synthetic.make_problem(t, frames, 1, S, DEV, radius=2.2, seed=21, window=W)
+    f.config.TORSO_JOINTS = [0, 1, 4]
+    f.config.OPT_WEIGHTS = [[25.0, 10.0], [0.0, 500.0], [0.0, 1.0], [0.0, 1.0], [0.0, 100.0], [0.0, 0.1], [500.0, 100.0], [3, 3], [2e-2, 5e-3]]
+    cpu = lambda x: x.detach().cpu().clone()  # noqa: E731
+    m = oracle_model(t)
+    params = dict(betas=cpu(f.betas), log_beta_scales=cpu(f.log_beta_scales), betas_trans=cpu(f.betas_trans), global_rotation=cpu(f.global_rotation),
+                  trans=cpu(f.trans), joint_rotations=cpu(f.joint_rotations), fov=cpu(f.fov))
+    targets = dict(sil=cpu(f.sil_imgs).float(), joints=cpu(f.target_joints), visibility=cpu(f.target_visibility))
+    cams = dict(R=cpu(f.renderer.cameras.R), T=cpu(f.renderer.cameras.T))
+    mean_b, prec = f.mean_betas.cpu(), f.betas_prec.cpu()
+    windows = [list(range(s0, min(frames, s0 + W))) for s0 in range(0, frames, W)]
+    stages = optimize.stages_from_config(f.config)
+
+    want = []
+    full_vis = targets["visibility"].clone()
+    for stage_id, st in enumerate(stages):
+        frozen = ("joint_rotations", "betas", "log_beta_scales") if stage_id == 0 else ()
+        for k, p in params.items():
+            p.requires_grad_(k != "betas_trans" and k not in frozen)
+        vis = full_vis.clone()
+        if stage_id == 0:
+            vis = torch.zeros_like(full_vis)
+            vis[:, f.config.TORSO_JOINTS] = full_vis[:, f.config.TORSO_JOINTS]
+        tg = dict(targets, visibility=vis)
+        opt = torch.optim.Adam([{"params": [p for k, p in params.items() if k != "fov"], "lr": st.lr}, {"params": [params["fov"]], "lr": 1.0}],
+                               lr=st.lr, betas=(0.5, 0.999))
+        for _ in range(st.epochs):
+            opt.zero_grad()
+            total, _, _ = fitter_ref.fit_iteration_loss(m, params, windows, st.weights, st.w_temp, tg, cams, S, mean_b, prec)
+            total.backward()
+            opt.step()
+            want.append(float(total))
+
+    got = []
+    optimize.optimize(f, stages, on_epoch=lambda s_, e_, objs: got.append(float(objs[:9].sum())), use_graph=use_graph)
+    np.testing.assert_allclose(got, want, rtol=2e-4)
+    assert (f._graph is not None) == use_graph
+    for name in ("global_rotation", "joint_rotations", "trans", "betas", "fov", "log_beta_scales"):
+        a, b = getattr(f, name).detach().cpu().numpy(), params[name].detach().numpy().reshape(getattr(f, name).shape)
+        d = np.abs(a - b)
+        assert np.median(d) < 2e-4 and np.mean(d < 3e-3) > 0.97, (name, np.median(d), d.max())

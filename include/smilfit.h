@@ -78,6 +78,9 @@ typedef struct {
     const float *v_template;    /* (V,3) override or NULL */
     int32_t propagate_scaling;  /* batch_lbs.py:163-168 */
     int32_t allow_limb_scaling; /* config.ALLOW_LIMB_SCALING (batch_lbs.py:123) */
+    const float *theta_mask;    /* (J,3) or NULL: theta is used as theta * mask (global_mask / rotation_mask of
+                                   SMALFitter.forward, fitter.py:242-243) without a masked copy; d_theta is the gradient
+                                   with respect to the MASKED pose */
 } SmilLbsInputs;
 
 typedef struct {
@@ -112,6 +115,8 @@ typedef struct {
                               also the gradient on v_shaped / v_template rows of each frame */
     float *d_Rs_in;        /* (B,J,3,3) or NULL: gradient on the rotation matrices when theta was given as
                               matrices (Rs_in; smal_torch.py:288-289) */
+    int32_t accumulate_shared_beta; /* shared_beta only: ADD the sum over frames to d_beta (caller zeroes it or holds
+                              other terms there) instead of overwriting it */
 } SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
                               logscale_shared, btrans_shared) receive the sum over frames */
 
@@ -140,6 +145,16 @@ typedef struct {
 /* pts (frames,P,3) world -> ndc (N,P,3) = (x_ndc, y_ndc, z_view); yx (N,P,2) = (y_s, x_s) px. Either
  * output may be NULL. */
 int smil_project(const SmilCameras *cam, const float *pts, int32_t P, float *ndc, float *yx, void *stream);
+
+/* Two point sets through the same cameras in one launch (the vertices for the rasteriser and the joints for the 2-D
+ * loss of one fit iteration); arguments per set as smil_project. */
+int smil_project2(const SmilCameras *cam, const float *pts_a, int32_t Pa, float *ndc_a, float *yx_a, const float *pts_b,
+                  int32_t Pb, float *ndc_b, float *yx_b, void *stream);
+
+/* smil_project_backward for two point sets in one launch (d_pts of both overwritten; d_fov_img added to). */
+int smil_project_backward2(const SmilCameras *cam, const float *pts_a, int32_t Pa, const float *d_ndc_a, const float *d_yx_a,
+                           float *d_pts_a, const float *pts_b, int32_t Pb, const float *d_ndc_b, const float *d_yx_b,
+                           float *d_pts_b, float *d_fov_img, void *stream);
 
 /* Backward of smil_project.  d_ndc (N,P,2) and/or d_yx (N,P,2) -> d_pts (frames,P,3) (summed over
  * views; overwritten unless accumulate) and d_fov_img (N,): per-image raw sums
@@ -225,6 +240,15 @@ int smil_prior_losses(const SmilFitConfig *cfg, const float *pose, const float *
 
 /* out[i][c] = in[i][c] * mask[c]  (masked pose fed to smil_lbs_forward) */
 int smil_mask_rows(const float *in, const float *mask, int64_t rows, int32_t cols, float *out, void *stream);
+
+/* smil_prior_losses + the silhouette objective (objs[5] += sum_n pix_scale[n] * loss_img[n]; loss_img NULL to skip;
+ * fitter.py:332-333) + the reduction of the per-image fov sums of smil_project_backward to d_fov (cam->nFov,),
+ * overwritten (d_fov NULL to skip): the tail of one fit iteration in ONE launch. */
+int smil_fit_epilogue(const SmilFitConfig *cfg, const float *pose, const float *trans, const float *betas,
+                      const float *mean_betas, const float *betas_prec, const float *mask, const float *halo_prev,
+                      const float *halo_next, float *objs, float *d_pose, float *d_trans, float *d_betas, int32_t accumulate,
+                      const float *loss_img, const float *pix_scale, int32_t n_img, const SmilCameras *cam,
+                      const float *d_fov_img, float *d_fov, void *stream);
 
 /* 2-D joint loss (fitter.py:283,292-296).  proj / d_proj (N*views,J,2) in (y,x) px over ALL model joints;
  * canon (Jc,) = config.CANONICAL_MODEL_JOINTS (NULL: the first Jc joints); target (N*views,Jc,2);

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("SMILFIT_LIB") or os.path.join(_HERE, "lib", "libsmilf
 
 EXPORTS = [
     "smil_model_create", "smil_model_destroy", "smil_model_dims", "smil_last_error", "smil_version",
-    "smil_lbs_forward", "smil_lbs_backward", "smil_project", "smil_project_backward", "smil_fov_reduce",
+    "smil_lbs_forward", "smil_lbs_backward", "smil_project", "smil_project2", "smil_project_backward", "smil_project_backward2",
+    "smil_fov_reduce", "smil_fit_epilogue",
     "smil_raster_workspace_bytes", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
     "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_adam_step_multi", "smil_adam_step_dev", "smil_profile_enable",
@@ -49,7 +50,7 @@ class LbsInputs(Structure):
                 ("theta", c_void_p), ("Rs_in", c_void_p), ("logscale", c_void_p), ("logscale_shared", c_int32),
                 ("btrans", c_void_p), ("btrans_shared", c_int32), ("trans", c_void_p), ("trans_after_joints", c_int32),
                 ("del_v", c_void_p),
-                ("v_template", c_void_p), ("propagate_scaling", c_int32), ("allow_limb_scaling", c_int32)]
+                ("v_template", c_void_p), ("propagate_scaling", c_int32), ("allow_limb_scaling", c_int32), ("theta_mask", c_void_p)]
 
 
 class LbsOutputs(Structure):
@@ -58,7 +59,8 @@ class LbsOutputs(Structure):
 
 class LbsGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("d_verts", "d_joints", "d_beta", "d_theta", "d_logscale", "d_btrans",
-                                        "d_trans", "d_A", "d_Jrest", "d_Rs", "d_vposed", "d_posefeat", "d_del_v", "d_Rs_in")]
+                                        "d_trans", "d_A", "d_Jrest", "d_Rs", "d_vposed", "d_posefeat", "d_del_v", "d_Rs_in")] + [
+        ("accumulate_shared_beta", c_int32)]
 
 
 class Cameras(Structure):
@@ -104,6 +106,11 @@ def load():
     lib.smil_project_backward.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int32, c_void_p]
     lib.smil_fov_reduce.argtypes = [POINTER(Cameras), c_void_p, c_void_p, c_void_p]
+    lib.smil_project2.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.smil_project_backward2.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.smil_fit_epilogue.argtypes = [POINTER(FitConfig)] + [c_void_p] * 12 + [c_int32, c_void_p, c_void_p, c_int32, POINTER(Cameras),
+                                                                                 c_void_p, c_void_p, c_void_p]
     lib.smil_raster_workspace_bytes.argtypes = [c_void_p, c_int32, c_int32]
     lib.smil_raster_workspace_bytes.restype = c_size_t
     lib.smil_silhouette_forward.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,

@@ -15,17 +15,16 @@ __device__ __forceinline__ int window_size_of(const SmilFitConfig &c, int local_
 
 // element e of frame i: [0,3) global rotation, [3,3J) joint rotations, [3J,3J+3) translation.
 // pose is the combined (N,J,3) parameter buffer, mask the combined (J,3) mask.
-__global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const float *__restrict__ pose,
-                                                      const float *__restrict__ trans, const float *__restrict__ mask_tab,
-                                                      const float *__restrict__ halo_prev, const float *__restrict__ halo_next,
-                                                      float *__restrict__ objs, float *__restrict__ d_pose,
-                                                      float *__restrict__ d_t, int accumulate) {
-    __shared__ float red[16];
+__device__ __forceinline__ void prior_losses_body(const SmilFitConfig &c, const float *__restrict__ pose,
+                                                  const float *__restrict__ trans, const float *__restrict__ mask_tab,
+                                                  const float *__restrict__ halo_prev, const float *__restrict__ halo_next,
+                                                  float *__restrict__ objs, float *__restrict__ d_pose,
+                                                  float *__restrict__ d_t, int accumulate, int block, int n_blocks, float *red) {
     const int P3 = 3 * c.J;
     const int E = P3 + 3;
     const long long total = (long long)c.N * E;
     float o_limit = 0.f, o_pose = 0.f, o_splay = 0.f, o_tj = 0.f, o_tg = 0.f, o_tt = 0.f;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = (long long)block * blockDim.x + threadIdx.x; idx < total; idx += (long long)n_blocks * blockDim.x) {
         const int i = (int)(idx / E), e = (int)(idx - (long long)i * E);
         const float bw = (float)window_size_of(c, i);
         const int gi = c.frame0 + i;
@@ -92,6 +91,15 @@ __global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const flo
     v = block_sum(o_tt, red);    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&objs[8], v);
 }
 
+__global__ void __launch_bounds__(256) k_prior_losses(SmilFitConfig c, const float *__restrict__ pose,
+                                                      const float *__restrict__ trans, const float *__restrict__ mask_tab,
+                                                      const float *__restrict__ halo_prev, const float *__restrict__ halo_next,
+                                                      float *__restrict__ objs, float *__restrict__ d_pose,
+                                                      float *__restrict__ d_t, int accumulate) {
+    __shared__ float red[16];
+    prior_losses_body(c, pose, trans, mask_tab, halo_prev, halo_next, objs, d_pose, d_t, accumulate, blockIdx.x, gridDim.x, red);
+}
+
 __global__ void __launch_bounds__(256) k_mask_rows(const float *__restrict__ in, const float *__restrict__ mask, long long n,
                                                    int cols, float *__restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -108,9 +116,9 @@ extern "C" int smil_mask_rows(const float *in, const float *mask, int64_t rows, 
 }
 
 // shape prior (fitter.py:321-330): per window mean(((beta - mean) @ prec)^2); identical for every window
-__global__ void k_betas_prior(SmilFitConfig c, const float *__restrict__ betas, const float *__restrict__ mean_betas,
-                              const float *__restrict__ prec, float *__restrict__ objs, float *__restrict__ d_betas) {
-    __shared__ float diff[SMIL_MAX_BETAS], res[SMIL_MAX_BETAS];
+__device__ __forceinline__ void betas_prior_body(const SmilFitConfig &c, const float *__restrict__ betas, const float *__restrict__ mean_betas,
+                                                 const float *__restrict__ prec, float *__restrict__ objs, float *__restrict__ d_betas,
+                                                 float *diff, float *res) {
     const int nB = c.nB, t = threadIdx.x;
     const int w = c.window > 0 ? c.window : c.N_total;
     // windows whose first frame lies in this rank's shard
@@ -134,6 +142,12 @@ __global__ void k_betas_prior(SmilFitConfig c, const float *__restrict__ betas, 
         for (int k = 0; k < nB; ++k) s += res[k] * res[k];
         atomicAdd(&objs[4], n_win * c.w_betas * s / (float)nB);
     }
+}
+
+__global__ void k_betas_prior(SmilFitConfig c, const float *__restrict__ betas, const float *__restrict__ mean_betas,
+                              const float *__restrict__ prec, float *__restrict__ objs, float *__restrict__ d_betas) {
+    __shared__ float diff[SMIL_MAX_BETAS], res[SMIL_MAX_BETAS];
+    betas_prior_body(c, betas, mean_betas, prec, objs, d_betas, diff, res);
 }
 
 extern "C" int smil_prior_losses(const SmilFitConfig *cfg, const float *pose, const float *trans, const float *betas,
@@ -161,6 +175,91 @@ extern "C" int smil_prior_losses(const SmilFitConfig *cfg, const float *pose, co
         hipLaunchKernelGGL(k_betas_prior, dim3(1), dim3(64), 0, stream, c, betas, mean_betas, betas_prec, objs, d_betas);
         SMIL_LAUNCH_CHECK();
     }
+    return SMIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Everything that closes a fit iteration's loss / gradient evaluation in ONE launch (blocks take roles): the prior terms,
+// the shape prior, the silhouette objective sum_n scale[n] loss_img[n] (fitter.py:332-333 after the fused rasteriser) and
+// the reduction of the per-image fov sums to d_fov.  Replaces four dependent ~5 us launches at the end of every iteration.
+// ---------------------------------------------------------------------------------------------
+struct EpilogueArgs {
+    SmilFitConfig c;
+    const float *pose, *trans, *betas, *mean_betas, *prec, *mask, *halo_prev, *halo_next;
+    float *objs, *d_pose, *d_trans, *d_betas;
+    int accumulate, prior_blocks, do_betas;
+    const float *loss_img, *pix_scale;
+    int n_img, sil_blocks;
+    SmilCameras cam;
+    const float *d_fov_img;
+    float *d_fov;
+};
+
+__global__ void __launch_bounds__(256) k_fit_epilogue(EpilogueArgs a) {
+    __shared__ float red[16];
+    __shared__ float diff[SMIL_MAX_BETAS], res[SMIL_MAX_BETAS];
+    int blk = (int)blockIdx.x;
+    if (blk < a.prior_blocks) {
+        prior_losses_body(a.c, a.pose, a.trans, a.mask, a.halo_prev, a.halo_next, a.objs, a.d_pose, a.d_trans, a.accumulate, blk,
+                          a.prior_blocks, red);
+        return;
+    }
+    blk -= a.prior_blocks;
+    if (a.do_betas) {
+        if (blk == 0) { betas_prior_body(a.c, a.betas, a.mean_betas, a.prec, a.objs, a.d_betas, diff, res); return; }
+        blk -= 1;
+    }
+    if (blk < a.sil_blocks) {
+        float acc = 0.f;
+        for (int n = blk * blockDim.x + threadIdx.x; n < a.n_img; n += a.sil_blocks * blockDim.x) acc += a.loss_img[n] * a.pix_scale[n];
+        const float v = block_sum(acc, red);
+        if (threadIdx.x == 0 && v != 0.f) atomicAdd(&a.objs[5], v);
+        return;
+    }
+    blk -= a.sil_blocks;
+    if (a.d_fov && blk < a.cam.nFov) {  // same arithmetic as k_fov_reduce (project.hip)
+        float acc = 0.f;
+        for (int n = blk + threadIdx.x * a.cam.nFov; n < a.cam.N; n += blockDim.x * a.cam.nFov) acc += a.d_fov_img[n];
+        const float r = block_sum(acc, red);
+        if (threadIdx.x == 0) {
+            const float t = tanf((a.cam.fov[blk] * 0.017453292519943295f) / 2.0f);
+            a.d_fov[blk] = -(0.008726646259971648f) * (1.0f + t * t) / t * r;
+        }
+    }
+}
+
+extern "C" int smil_fit_epilogue(const SmilFitConfig *cfg, const float *pose, const float *trans, const float *betas,
+                                 const float *mean_betas, const float *betas_prec, const float *mask, const float *halo_prev,
+                                 const float *halo_next, float *objs, float *d_pose, float *d_trans, float *d_betas, int32_t accumulate,
+                                 const float *loss_img, const float *pix_scale, int32_t n_img, const SmilCameras *cam,
+                                 const float *d_fov_img, float *d_fov, void *stream_) {
+    SMIL_REQUIRE(cfg && pose && trans && mask && objs && d_pose && d_trans, "smil_fit_epilogue: null argument");
+    SMIL_REQUIRE(cfg->N > 0 && cfg->J > 1 && cfg->N_total >= cfg->frame0 + cfg->N, "smil_fit_epilogue: bad sizes");
+    SMIL_REQUIRE(cfg->frame0 == 0 || halo_prev || cfg->w_temp <= 0.f, "smil_fit_epilogue: halo_prev required for a shard that does not start the sequence");
+    SMIL_REQUIRE(cfg->frame0 + cfg->N == cfg->N_total || halo_next || cfg->w_temp <= 0.f,
+                 "smil_fit_epilogue: halo_next required for a shard that does not end the sequence");
+    SMIL_REQUIRE(!loss_img || (pix_scale && n_img > 0), "smil_fit_epilogue: silhouette objective needs pix_scale and n_img");
+    SMIL_REQUIRE(!d_fov || (cam && d_fov_img && cam->nFov > 0 && cam->N % cam->nFov == 0), "smil_fit_epilogue: fov reduction needs the cameras and per-image sums");
+    EpilogueArgs a;
+    a.c = *cfg;
+    a.pose = pose; a.trans = trans; a.betas = betas; a.mean_betas = mean_betas; a.prec = betas_prec; a.mask = mask;
+    a.halo_prev = (!halo_prev && a.c.frame0 > 0) ? pose : halo_prev;  // (only reachable with w_temp <= 0: never read where it matters)
+    a.halo_next = (!halo_next && a.c.frame0 + a.c.N < a.c.N_total) ? pose : halo_next;
+    a.objs = objs; a.d_pose = d_pose; a.d_trans = d_trans; a.d_betas = d_betas; a.accumulate = accumulate;
+    a.do_betas = (a.c.w_betas > 0.f && a.c.nB > 0) ? 1 : 0;
+    if (a.do_betas) {
+        SMIL_REQUIRE(betas && mean_betas && betas_prec && d_betas, "smil_fit_epilogue: shape prior tables missing");
+        SMIL_REQUIRE(a.c.nB <= SMIL_MAX_BETAS, "smil_fit_epilogue: nB too large");
+    }
+    const long long total = (long long)a.c.N * (3 * a.c.J + 3);
+    a.prior_blocks = (int)std::min<long long>(512, (total + 255) / 256);
+    a.loss_img = loss_img; a.pix_scale = pix_scale; a.n_img = loss_img ? n_img : 0;
+    a.sil_blocks = loss_img ? std::min(64, ceil_div(n_img, 256)) : 0;
+    if (cam) a.cam = *cam; else { a.cam = SmilCameras(); a.cam.nFov = 0; }
+    a.d_fov_img = d_fov_img; a.d_fov = d_fov;
+    const int grid = a.prior_blocks + a.do_betas + a.sil_blocks + (d_fov ? a.cam.nFov : 0);
+    hipLaunchKernelGGL(k_fit_epilogue, dim3(grid), dim3(256), 0, (hipStream_t)stream_, a);
+    SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
 

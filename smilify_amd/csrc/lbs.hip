@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_rest_joints(const int *__restrict__ row
 // reads level d-1).
 // ---------------------------------------------------------------------------------------------
 struct PoseArgs {
-    const float *theta, *Rs_in, *logscale, *btrans, *J_rest;
+    const float *theta, *theta_mask, *Rs_in, *logscale, *btrans, *J_rest;
     const int *parents, *depth;
     float *Rs, *G, *A, *new_J, *joints_static;
     const float *joints_trans;  // added to the static joints (SMALFitter semantics) or NULL
@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) 
                     for (int i = 0; i < 9; ++i) R[i] = a.Rs_in[((size_t)b * J + j) * 9 + i];
                 } else {
                     const float *th = a.theta + ((size_t)b * J + j) * 3;
-                    rodrigues_fwd(th[0], th[1], th[2], R);
+                    const float *mk = a.theta_mask ? a.theta_mask + 3 * j : nullptr;
+                    rodrigues_fwd(mk ? th[0] * mk[0] : th[0], mk ? th[1] * mk[1] : th[1], mk ? th[2] * mk[2] : th[2], R);
                 }
                 if (a.Rs)
                     for (int i = 0; i < 9; ++i) a.Rs[((size_t)b * J + j) * 9 + i] = R[i];
@@ -375,7 +376,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
     SMIL_LAUNCH_CHECK();
     {
         PoseArgs a;
-        a.theta = in->theta; a.Rs_in = in->Rs_in;
+        a.theta = in->theta; a.theta_mask = in->theta_mask; a.Rs_in = in->Rs_in;
         a.use_scale = (in->logscale && in->allow_limb_scaling) ? 1 : 0;
         a.logscale = in->logscale; a.btrans = in->btrans; a.J_rest = out->J_rest;
         a.parents = m->parents; a.depth = m->depth;
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(1024) k_skin_bwd_transforms(
 }
 
 struct ChainBwdArgs {
-    const float *theta, *Rs, *logscale, *btrans, *J_rest, *G, *d_A, *d_newJ;
+    const float *theta, *theta_mask, *Rs, *logscale, *btrans, *J_rest, *G, *d_A, *d_newJ;
     const float *d_posefeat;  // (B,9(J-1)) gradient on vec(Rs[1:] - I) from the pose blend shapes, or NULL
     const int *parents, *depth;
     float *d_theta, *d_logscale, *d_btrans, *d_Jrest;
@@ -596,8 +597,9 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                     for (int i = 0; i < 9; ++i) a.d_Rs_out[o * 9 + i] = dR[i];
                 if (a.d_theta && a.theta) {
                     const float *th = a.theta + o * 3;
+                    const float *mk = a.theta_mask ? a.theta_mask + 3 * j : nullptr;
                     float dth[3];
-                    rodrigues_bwd(th[0], th[1], th[2], dR, dth);
+                    rodrigues_bwd(mk ? th[0] * mk[0] : th[0], mk ? th[1] * mk[1] : th[1], mk ? th[2] * mk[2] : th[2], dR, dth);
                     a.d_theta[o * 3] = dth[0]; a.d_theta[o * 3 + 1] = dth[1]; a.d_theta[o * 3 + 2] = dth[2];
                 }
             }
@@ -625,7 +627,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
-    const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_trans,
+    const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_beta_shared, float *__restrict__ d_trans,
     float *__restrict__ d_vshaped, int V, int J, int nB_used, int regress, int trans_after) {
     extern __shared__ float smem[];
     float *sA = smem;            // (J,12)
@@ -693,6 +695,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
             if (k0 + k < nB_used) {
                 const float r = block_sum(bsum[k], red);
                 if (threadIdx.x == 0 && d_beta_frame) d_beta_frame[(size_t)b * nB_used + k0 + k] = r;
+                if (threadIdx.x == 0 && d_beta_shared && r != 0.f) atomicAdd(&d_beta_shared[k0 + k], r);  // sum over frames
             }
         }
         if (k0 == 0 && d_trans) {
@@ -736,7 +739,6 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     SMIL_REQUIRE(g->d_verts || g->d_joints, "smil_lbs_backward: no upstream gradient");
     SMIL_REQUIRE(g->d_A && g->d_Jrest && g->d_Rs, "smil_lbs_backward: scratch buffers missing");
     SMIL_REQUIRE(sv->v_shaped && sv->J_rest && sv->G && sv->A && sv->Rs, "smil_lbs_backward: saved forward tensors missing");
-    SMIL_REQUIRE(!(g->d_beta && in->shared_beta) || in->nB_used <= J * 12, "smil_lbs_backward: nB_used exceeds the d_A scratch");
     const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
     const int regress = m->static_joints ? 0 : 1;
     const int use_scale = (in->logscale && in->allow_limb_scaling) ? 1 : 0;
@@ -772,7 +774,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     if (g->d_btrans) dbt_frame = in->btrans_shared ? scratch + (size_t)B * J * 3 : g->d_btrans;
     {
         ChainBwdArgs a;
-        a.theta = in->Rs_in ? nullptr : in->theta; a.Rs = sv->Rs;
+        a.theta = in->Rs_in ? nullptr : in->theta; a.theta_mask = in->theta_mask; a.Rs = sv->Rs;
         a.logscale = in->logscale; a.btrans = in->btrans; a.J_rest = sv->J_rest; a.G = sv->G; a.d_A = g->d_A;
         a.d_newJ = m->static_joints ? g->d_joints : nullptr;
         a.d_posefeat = d_posefeat;
@@ -796,18 +798,23 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     }
     if (g->d_beta || g->d_trans || g->d_del_v) {
         const int nBu = g->d_beta ? in->nB_used : 0;
-        float *dbeta_frame = nullptr;
-        if (g->d_beta && nBu > 0) dbeta_frame = in->shared_beta ? g->d_A : g->d_beta;  // d_A is free again
+        // shared betas: every frame's block adds its term to the one (nB,) gradient (float atomics, like the rasteriser's
+        // vertex gradients); per-frame betas: one row per frame
+        float *dbeta_frame = nullptr, *dbeta_shared = nullptr;
+        if (g->d_beta && nBu > 0) {
+            if (in->shared_beta) {
+                dbeta_shared = g->d_beta;
+                if (!g->accumulate_shared_beta) SMIL_HIP(hipMemsetAsync(g->d_beta, 0, (size_t)nBu * sizeof(float), stream));
+            } else {
+                dbeta_frame = g->d_beta;
+            }
+        }
         const size_t lds = ((size_t)J * 18 + 16) * sizeof(float);
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(1024), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
-                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, g->d_trans, g->d_del_v, V, J, nBu, regress,
+                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, dbeta_shared, g->d_trans, g->d_del_v, V, J, nBu, regress,
                            in->trans_after_joints ? 1 : 0);
         SMIL_LAUNCH_CHECK();
-        if (dbeta_frame && in->shared_beta) {
-            int rc = smil_reduce_rows(dbeta_frame, g->d_beta, B, nBu, stream);
-            if (rc) return rc;
-        }
     }
     return SMIL_OK;
 }

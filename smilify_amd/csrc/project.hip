@@ -33,55 +33,88 @@ __device__ __forceinline__ CamParams load_camera(const SmilCameras &c, int n) {
     return p;
 }
 
-// grid (ceil(P/256), N)
-__global__ void __launch_bounds__(256) k_project(SmilCameras c, const float *__restrict__ pts, int P,
-                                                 float *__restrict__ ndc, float *__restrict__ yx) {
-    const int n = blockIdx.y;
-    const int b = n / c.views;
-    const CamParams cp = load_camera(c, n);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const float *X = pts + ((size_t)b * P + p) * 3;
+// One or two point sets (e.g. the vertices -> NDC for the rasteriser and the joints -> screen for the 2-D loss) per launch.
+struct ProjectSet {
+    const float *pts;  // (frames,P,3)
+    float *ndc, *yx;   // (N,P,3) / (N,P,2), either may be NULL
+    int P, blocks;     // points per frame; thread blocks (of 256 points) this set occupies in grid.x
+};
+
+__device__ __forceinline__ void project_point(const SmilCameras &c, const CamParams &cp, const ProjectSet &s, int b, int n, int p) {
+    const float *X = s.pts + ((size_t)b * s.P + p) * 3;
     const float x = X[0], y = X[1], z = X[2];
     const float vx = x * cp.R[0] + y * cp.R[3] + z * cp.R[6] + cp.T[0];
     const float vy = x * cp.R[1] + y * cp.R[4] + z * cp.R[7] + cp.T[1];
     const float vz = x * cp.R[2] + y * cp.R[5] + z * cp.R[8] + cp.T[2];
     const float xn = vx * cp.k00 / vz;
     const float yn = vy * cp.k11 / vz;
-    const size_t o = (size_t)n * P + p;
-    if (ndc) { ndc[o * 3] = xn; ndc[o * 3 + 1] = yn; ndc[o * 3 + 2] = vz; }
-    if (yx) {
+    const size_t o = (size_t)n * s.P + p;
+    if (s.ndc) { s.ndc[o * 3] = xn; s.ndc[o * 3 + 1] = yn; s.ndc[o * 3 + 2] = vz; }
+    if (s.yx) {
         const float h = 0.5f * (float)c.S;
-        yx[o * 2] = h - h * yn;
-        yx[o * 2 + 1] = h - h * xn;
+        s.yx[o * 2] = h - h * yn;
+        s.yx[o * 2 + 1] = h - h * xn;
     }
 }
 
+// grid (blocks of set 0 + blocks of set 1, N)
+__global__ void __launch_bounds__(256) k_project(SmilCameras c, ProjectSet s0, ProjectSet s1) {
+    const int n = blockIdx.y;
+    const int b = n / c.views;
+    const CamParams cp = load_camera(c, n);
+    const bool second = (int)blockIdx.x >= s0.blocks;
+    const ProjectSet &s = second ? s1 : s0;
+    const int p = ((int)blockIdx.x - (second ? s0.blocks : 0)) * blockDim.x + threadIdx.x;
+    if (p < s.P) project_point(c, cp, s, b, n, p);
+}
+
+static int check_cameras(const SmilCameras *cam, const char *who) {
+    SMIL_REQUIRE(cam, "%s: null camera argument", who);
+    SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && cam->S > 0, "%s: bad sizes N=%d views=%d S=%d", who, cam->N,
+                 cam->views, cam->S);
+    SMIL_REQUIRE(cam->R && cam->T && cam->fov && cam->nR > 0 && cam->nT > 0 && cam->nFov > 0, "%s: camera tables missing", who);
+    SMIL_REQUIRE(!cam->aspect || cam->nAspect > 0, "%s: aspect table empty", who);
+    return SMIL_OK;
+}
+
 extern "C" int smil_project(const SmilCameras *cam, const float *pts, int32_t P, float *ndc, float *yx, void *stream) {
-    SMIL_REQUIRE(cam && pts, "smil_project: null argument");
-    SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && P > 0 && cam->S > 0,
-                 "smil_project: bad sizes N=%d views=%d P=%d S=%d", cam->N, cam->views, P, cam->S);
-    SMIL_REQUIRE(cam->R && cam->T && cam->fov && cam->nR > 0 && cam->nT > 0 && cam->nFov > 0, "smil_project: camera tables missing");
-    SMIL_REQUIRE(!cam->aspect || cam->nAspect > 0, "smil_project: aspect table empty");
-    dim3 grid(ceil_div(P, 256), cam->N);
-    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, (hipStream_t)stream, *cam, pts, P, ndc, yx);
+    if (int rc = check_cameras(cam, "smil_project")) return rc;
+    SMIL_REQUIRE(pts && P > 0, "smil_project: bad points argument (P=%d)", P);
+    const ProjectSet s0 = {pts, ndc, yx, P, ceil_div(P, 256)}, none = {nullptr, nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(k_project, dim3(s0.blocks, cam->N), dim3(256), 0, (hipStream_t)stream, *cam, s0, none);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
 
-// grid (ceil(P/256), frames): each thread owns one world point and walks the views of its frame, so
+extern "C" int smil_project2(const SmilCameras *cam, const float *pts_a, int32_t Pa, float *ndc_a, float *yx_a, const float *pts_b,
+                             int32_t Pb, float *ndc_b, float *yx_b, void *stream) {
+    if (int rc = check_cameras(cam, "smil_project2")) return rc;
+    SMIL_REQUIRE(pts_a && Pa > 0 && pts_b && Pb > 0, "smil_project2: bad points arguments (Pa=%d Pb=%d)", Pa, Pb);
+    const ProjectSet s0 = {pts_a, ndc_a, yx_a, Pa, ceil_div(Pa, 256)}, s1 = {pts_b, ndc_b, yx_b, Pb, ceil_div(Pb, 256)};
+    hipLaunchKernelGGL(k_project, dim3(s0.blocks + s1.blocks, cam->N), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+struct ProjectBwdSet {
+    const float *pts, *d_ndc, *d_yx;  // (frames,P,3), (N,P,2) or NULL, (N,P,2) or NULL
+    float *d_pts;                     // (frames,P,3)
+    int P, blocks, accumulate;
+};
+
+// grid (blocks of set 0 + blocks of set 1, frames): each thread owns one world point and walks the views of its frame, so
 // d_pts needs no atomics; the per-image fov term is block-reduced and added once per block.
-__global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, const float *__restrict__ pts, int P,
-                                                     const float *__restrict__ d_ndc, const float *__restrict__ d_yx,
-                                                     float *__restrict__ d_pts, float *__restrict__ d_fov_img,
-                                                     int accumulate) {
+__global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, ProjectBwdSet s0, ProjectBwdSet s1, float *__restrict__ d_fov_img) {
     __shared__ float red[16];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool second = (int)blockIdx.x >= s0.blocks;
+    const ProjectBwdSet &s = second ? s1 : s0;
+    const int P = s.P;
+    const int p = ((int)blockIdx.x - (second ? s0.blocks : 0)) * blockDim.x + threadIdx.x;
     const bool live = p < P;
     float x = 0.f, y = 0.f, z = 0.f;
     if (live) {
-        const float *X = pts + ((size_t)b * P + p) * 3;
+        const float *X = s.pts + ((size_t)b * P + p) * 3;
         x = X[0]; y = X[1]; z = X[2];
     }
     float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -97,11 +130,11 @@ __global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, const float 
             const float xn = vx * cp.k00 * iz, yn = vy * cp.k11 * iz;
             const size_t o = (size_t)n * P + p;
             float dxn = 0.f, dyn = 0.f;
-            if (d_ndc) { dxn = d_ndc[o * 2]; dyn = d_ndc[o * 2 + 1]; }
-            if (d_yx) {
+            if (s.d_ndc) { dxn = s.d_ndc[o * 2]; dyn = s.d_ndc[o * 2 + 1]; }
+            if (s.d_yx) {
                 const float h = 0.5f * (float)c.S;
-                dyn -= h * d_yx[o * 2];
-                dxn -= h * d_yx[o * 2 + 1];
+                dyn -= h * s.d_yx[o * 2];
+                dxn -= h * s.d_yx[o * 2 + 1];
             }
             const float dvx = dxn * cp.k00 * iz, dvy = dyn * cp.k11 * iz;
             const float dvz = -(xn * dxn + yn * dyn) * iz;
@@ -115,9 +148,9 @@ __global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, const float 
             if (threadIdx.x == 0 && r != 0.f) atomicAdd(&d_fov_img[n], r);
         }
     }
-    if (live && d_pts) {
-        float *o = d_pts + ((size_t)b * P + p) * 3;
-        if (accumulate) { o[0] += gx; o[1] += gy; o[2] += gz; }
+    if (live && s.d_pts) {
+        float *o = s.d_pts + ((size_t)b * P + p) * 3;
+        if (s.accumulate) { o[0] += gx; o[1] += gy; o[2] += gz; }
         else { o[0] = gx; o[1] = gy; o[2] = gz; }
     }
 }
@@ -127,9 +160,20 @@ extern "C" int smil_project_backward(const SmilCameras *cam, const float *pts, i
     SMIL_REQUIRE(cam && pts, "smil_project_backward: null argument");
     SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && P > 0, "smil_project_backward: bad sizes");
     SMIL_REQUIRE(d_ndc || d_yx, "smil_project_backward: no upstream gradient");
-    dim3 grid(ceil_div(P, 256), cam->N / cam->views);
-    hipLaunchKernelGGL(k_project_bwd, grid, dim3(256), 0, (hipStream_t)stream, *cam, pts, P, d_ndc, d_yx, d_pts, d_fov_img,
-                       accumulate);
+    const ProjectBwdSet s0 = {pts, d_ndc, d_yx, d_pts, P, ceil_div(P, 256), accumulate}, none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(k_project_bwd, dim3(s0.blocks, cam->N / cam->views), dim3(256), 0, (hipStream_t)stream, *cam, s0, none, d_fov_img);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
+extern "C" int smil_project_backward2(const SmilCameras *cam, const float *pts_a, int32_t Pa, const float *d_ndc_a, const float *d_yx_a,
+                                      float *d_pts_a, const float *pts_b, int32_t Pb, const float *d_ndc_b, const float *d_yx_b,
+                                      float *d_pts_b, float *d_fov_img, void *stream) {
+    SMIL_REQUIRE(cam && pts_a && pts_b && d_pts_a && d_pts_b, "smil_project_backward2: null argument");
+    SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && Pa > 0 && Pb > 0, "smil_project_backward2: bad sizes");
+    SMIL_REQUIRE((d_ndc_a || d_yx_a) && (d_ndc_b || d_yx_b), "smil_project_backward2: no upstream gradient");
+    const ProjectBwdSet s0 = {pts_a, d_ndc_a, d_yx_a, d_pts_a, Pa, ceil_div(Pa, 256), 0}, s1 = {pts_b, d_ndc_b, d_yx_b, d_pts_b, Pb, ceil_div(Pb, 256), 0};
+    hipLaunchKernelGGL(k_project_bwd, dim3(s0.blocks + s1.blocks, cam->N / cam->views), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1, d_fov_img);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }

@@ -52,7 +52,9 @@
 #define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
 #define DGROUP 4            // 64-record rows per buffer in the dense walks (two buffers)
 #define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
+#ifndef REC_CAP
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
+#endif
 #define REC_PAD 64          // slack so that a clamped read stays inside the allocation
 #define RESIDENT_PER_CU 16  // single-wave workgroups per CU: what 128 VGPRs and 9.9 KB of LDS per workgroup allow (measured 10 ... 14: every
                             // further workgroup still shortens the launch)
@@ -141,9 +143,17 @@ __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
-                                                      float z_clip) {
+                                                      float z_clip, float *__restrict__ d_ndc_zero, const float *__restrict__ loss_src,
+                                                      float *__restrict__ loss_dst) {
     extern __shared__ uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
+    // the fused entry point's per-image initialisation rides along (saves a 100 MB memset and a copy launch per iteration):
+    // the vertex gradient of this image starts at zero, its loss at sum |0 - target|
+    if (d_ndc_zero) {
+        float2 *z = reinterpret_cast<float2 *>(d_ndc_zero) + (size_t)n * V;
+        for (int i = threadIdx.x; i < V; i += blockDim.x) z[i] = make_float2(0.f, 0.f);
+    }
+    if (loss_dst && threadIdx.x == 0) loss_dst[n] = loss_src[n];
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
     const int n_words = counted ? n_tiles : (n_tiles + 31) >> 5;
@@ -1136,7 +1146,8 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
 }
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
-                         void *workspace, hipStream_t stream, RasterArgs &a) {
+                         void *workspace, hipStream_t stream, RasterArgs &a, float *d_ndc_zero = nullptr,
+                         const float *loss_src = nullptr, float *loss_dst = nullptr) {
     SMIL_REQUIRE(m && verts_ndc && rs && workspace, "raster: null argument");
     SMIL_REQUIRE(N > 0 && S > 0 && S <= TILE * 256, "raster: bad sizes N=%d S=%d", N, S);
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
@@ -1162,7 +1173,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     const int n_tiles = tiles_x * tiles_x;
     const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(1024), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
-                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip);
+                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
@@ -1309,11 +1320,9 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
                                         float *sil_out, void *workspace, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     RasterArgs a;
-    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a);
-    if (rc) return rc;
     SMIL_REQUIRE(target && target_sum && pix_scale && loss_img && d_ndc, "smil_silhouette_l1_fused: null argument");
-    SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
-    SMIL_HIP(hipMemcpyAsync(loss_img, target_sum, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a, d_ndc, target_sum, loss_img);
+    if (rc) return rc;
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
     if (target_is_u8) a.target_u8 = (const uint8_t *)target; else a.target = (const float *)target;
     a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;

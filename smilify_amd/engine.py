@@ -143,7 +143,8 @@ def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL) -> _lib.Ra
 # ----------------------------------------------------------------------------------------------
 def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btrans=None, del_v=None,
                 v_template=None, Rs_in=None, shared_beta=False, logscale_shared=False, btrans_shared=False,
-                propagate_scaling=False, allow_limb_scaling=True, trans_after_joints=False) -> Dict[str, torch.Tensor]:
+                propagate_scaling=False, allow_limb_scaling=True, trans_after_joints=False, theta_mask=None) -> Dict[str, torch.Tensor]:
+    """``theta_mask`` (J,3): the kernels use ``theta * mask`` without a masked copy being made (SMALFitter's rotation masks)."""
     dev = model.device
     B = int((theta if theta is not None else Rs_in).shape[0])
     J, V = model.J, model.V
@@ -155,7 +156,7 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     if model.has_posedirs:
         out["v_posed"] = f(B, V, 3)
     inp = dict(beta=beta, theta=theta, Rs_in=Rs_in, logscale=logscale, btrans=btrans, trans=trans, del_v=del_v,
-               v_template=v_template)
+               v_template=v_template, theta_mask=theta_mask)
     i = _lib.LbsInputs()
     i.B, i.shared_beta, i.nB_used = B, int(shared_beta), nB_used
     i.logscale_shared, i.btrans_shared = int(logscale_shared), int(btrans_shared)
@@ -176,7 +177,8 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
 
 def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=True, need_theta=True,
                  need_logscale=True, need_btrans=True, need_trans=True, need_vshaped=False,
-                 need_Rs=False) -> Dict[str, Optional[torch.Tensor]]:
+                 need_Rs=False, d_beta_accum: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
+    """``d_beta_accum`` (shared betas only): the sum over frames is ADDED to this (nB,) tensor instead of a fresh one."""
     dev = model.device
     inp, fl = saved["_inputs"], saved["_flags"]
     B, J = fl["B"], model.J
@@ -186,8 +188,12 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
         g["d_del_v"] = f(B, model.V, 3)
     if need_Rs and inp["Rs_in"] is not None:
         g["d_Rs_in"] = f(B, J, 3, 3)
+    accumulate_beta = False
     if need_beta and fl["nB_used"] > 0:
-        g["d_beta"] = f(fl["nB_used"]) if fl["shared_beta"] else f(B, fl["nB_used"])
+        if fl["shared_beta"] and d_beta_accum is not None:
+            g["d_beta"], accumulate_beta = d_beta_accum, True
+        else:
+            g["d_beta"] = f(fl["nB_used"]) if fl["shared_beta"] else f(B, fl["nB_used"])
     if need_theta and inp["theta"] is not None:
         g["d_theta"] = f(B, J, 3)
     if need_logscale and inp["logscale"] is not None and fl["allow_limb_scaling"]:
@@ -216,6 +222,7 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
     gs.d_joints = None if d_joints is None else d_joints.data_ptr()
     for k, t in {**g, **scratch}.items():
         setattr(gs, k, None if t is None else t.data_ptr())
+    gs.accumulate_shared_beta = int(accumulate_beta)
     _lib.check(_lib.load().smil_lbs_backward(model.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(gs), _stream()),
                "smil_lbs_backward")
     return g
@@ -247,6 +254,41 @@ def project_backward(cams: CameraSet, pts: torch.Tensor, d_ndc=None, d_yx=None, 
     _lib.check(_lib.load().smil_project_backward(ctypes.byref(c), _ptr(pts), P, _ptr(d_ndc), _ptr(d_yx), _ptr(d_pts),
                                                  _ptr(d_fov_img), int(accumulate), _stream()), "smil_project_backward")
     return d_pts, d_fov_img
+
+
+def project_verts_and_joints(cams: CameraSet, verts: torch.Tensor, joints: torch.Tensor):
+    """One launch: verts (frames,V,3) -> NDC (N,V,3) for the rasteriser, joints (frames,J,3) -> (y,x) pixels (N,J,2)."""
+    frames, V, J = verts.shape[0], verts.shape[1], joints.shape[1]
+    N = frames * cams.views
+    ndc = torch.empty(N, V, 3, dtype=torch.float32, device=verts.device)
+    yx = torch.empty(N, J, 2, dtype=torch.float32, device=verts.device)
+    c = cams.struct(N)
+    _lib.check(_lib.load().smil_project2(ctypes.byref(c), _ptr(verts), V, _ptr(ndc), None, _ptr(joints), J, None, _ptr(yx), _stream()),
+               "smil_project2")
+    return ndc, yx
+
+
+def project_backward_verts_and_joints(cams: CameraSet, verts, d_ndc, joints, d_yx, d_fov_img):
+    """One launch: the backward of ``project_verts_and_joints``; returns (d_verts, d_joints), adds to d_fov_img."""
+    V, J = verts.shape[1], joints.shape[1]
+    N = verts.shape[0] * cams.views
+    d_verts, d_joints = torch.empty_like(verts), torch.empty_like(joints)
+    c = cams.struct(N)
+    _lib.check(_lib.load().smil_project_backward2(ctypes.byref(c), _ptr(verts), V, _ptr(d_ndc), None, _ptr(d_verts), _ptr(joints), J, None,
+                                                  _ptr(d_yx), _ptr(d_joints), _ptr(d_fov_img), _stream()), "smil_project_backward2")
+    return d_verts, d_joints
+
+
+def fit_epilogue(cfg, pose, trans, betas, mean_betas, betas_prec, mask, objs, d_pose, d_trans, d_betas, halo_prev=None, halo_next=None,
+                 accumulate=True, loss_img=None, pix_scale=None, cams: Optional[CameraSet] = None, d_fov_img=None, d_fov=None):
+    """prior_losses + sil_objective + fov_reduce in one launch (the tail of a fit iteration)."""
+    n_img = 0 if loss_img is None else loss_img.numel()
+    c = None if cams is None else cams.struct(d_fov_img.numel())
+    _lib.check(_lib.load().smil_fit_epilogue(ctypes.byref(cfg), _ptr(pose), _ptr(trans), _ptr(betas), _ptr(mean_betas), _ptr(betas_prec),
+                                             _ptr(mask), _ptr(halo_prev), _ptr(halo_next), _ptr(objs), _ptr(d_pose), _ptr(d_trans),
+                                             _ptr(d_betas), int(accumulate), _ptr(loss_img), _ptr(pix_scale), n_img,
+                                             None if c is None else ctypes.byref(c), _ptr(d_fov_img), _ptr(d_fov), _stream()),
+               "smil_fit_epilogue")
 
 
 def fov_reduce(cams: CameraSet, d_fov_img: torch.Tensor) -> torch.Tensor:

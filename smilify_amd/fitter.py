@@ -212,7 +212,23 @@ class SMALFitter(nn.Module):
         super().__setattr__(name, value)
 
     def _mask_table(self) -> torch.Tensor:
-        return torch.cat([self.global_mask.reshape(1, 3), self.rotation_mask.reshape(-1, 3)], 0).contiguous()
+        """(J,3) = [global_mask ; rotation_mask], rebuilt only when a mask tensor was replaced or edited in place."""
+        key = (self.global_mask.data_ptr(), self.global_mask._version, self.rotation_mask.data_ptr(), self.rotation_mask._version)
+        cached = self.__dict__.get("_mask_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, torch.cat([self.global_mask.reshape(1, 3), self.rotation_mask.reshape(-1, 3)], 0).float().contiguous())
+            self.__dict__["_mask_cache"] = cached
+        return cached[1]
+
+    def _pix_scale(self, fc, views: int, S: int) -> torch.Tensor:
+        """Per-image weight of the silhouette term (w_reproj / (window size * views * S^2)): depends on the loss weights and
+        the window layout only, so it is computed once per configuration, not once per iteration."""
+        key = (fc.N, views, S, fc.w_reproj, fc.window, fc.frame0, fc.N_total)
+        cached = self.__dict__.get("_pix_scale_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, engine.pix_scale(fc, views, S, self.device))
+            self.__dict__["_pix_scale_cache"] = cached
+        return cached[1]
 
     def _rows(self, p: torch.Tensor, idx: Optional[torch.Tensor], n_sel: int):
         """(tensor, shared?) for a parameter that is either one shared row or one row per frame."""
@@ -254,15 +270,17 @@ class SMALFitter(nn.Module):
         pose = sel(self._pose.detach()).contiguous()
         trans = sel(self.trans.detach()).contiguous()
         mask = self._mask_table()
-        theta = engine.mask_rows(pose, mask)
         ls, ls_shared = self._rows(self.log_beta_scales, idx, n)
         bt, bt_shared = self._rows(self.betas_trans, idx, n)
         betas = self.betas.detach().contiguous()
         fc = engine.fit_config(n, J, nB, win, [w_j2d, w_reproj, w_betas, w_pose, w_limit, w_splay], w_temp, frame0, n_total,
                                cfg.JOINT_LIMIT, self.global_rotation.requires_grad, self.joint_rotations.requires_grad,
                                self.trans.requires_grad)
-        objs = torch.zeros(N_OBJS, dtype=torch.float32, device=dev)
-        d_betas = torch.zeros(nB, dtype=torch.float32, device=dev)
+        # everything the kernels ADD into lives in one buffer with one zero fill: loss terms, the shared shape gradient,
+        # the per-image fov sums
+        n_img = n * views
+        arena = torch.zeros(N_OBJS + nB + n_img, dtype=torch.float32, device=dev)
+        objs, d_betas, d_fov_img = arena[:N_OBJS], arena[N_OBJS:N_OBJS + nB], arena[N_OBJS + nB:]
 
         # cameras: one table row per view, per image or shared; fov may be the trainable parameter
         cam = self.renderer.cameras
@@ -284,50 +302,63 @@ class SMALFitter(nn.Module):
 
         need_render = (w_j2d > 0) or (w_reproj > 0)
         g_lbs = None
-        d_fov = torch.zeros_like(fov)
+        d_fov = loss_img = pscale = d_fov_sel = None
         if need_render:
-            lbs = engine.lbs_forward(dm, betas, theta, trans=trans, logscale=ls, btrans=bt, shared_beta=True,
+            # the rotation masks are applied inside the pose kernels (theta_mask): no masked copy of the pose
+            lbs = engine.lbs_forward(dm, betas, pose, trans=trans, logscale=ls, btrans=bt, shared_beta=True,
                                      logscale_shared=ls_shared, btrans_shared=bt_shared, propagate_scaling=self.propagate_scaling,
-                                     allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True)
-            d_fov_img = torch.zeros(n * views, dtype=torch.float32, device=dev)
-            d_verts = d_joints = None
-            if w_j2d > 0:
+                                     allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True, theta_mask=mask)
+            both = w_j2d > 0 and w_reproj > 0
+            ndc = yx = d_yx = d_ndc = d_verts = d_joints = None
+            if both:  # vertices -> NDC and joints -> pixels in one launch
+                ndc, yx = engine.project_verts_and_joints(cams, lbs["verts"], lbs["joints"])
+            elif w_j2d > 0:
                 _, yx = engine.project(cams, lbs["joints"], want_ndc=False)
+            else:
+                ndc, _ = engine.project(cams, lbs["verts"], want_yx=False)
+            if w_j2d > 0:
                 tj = self._tj_dev if idx is None else self._tj_dev.index_select(0, img_idx)
                 vis = self._vis_dev if idx is None else self._vis_dev.index_select(0, img_idx)
                 d_yx = torch.empty_like(yx)
                 Jc = self._canon_dev.numel()
                 engine.joint_loss(fc, views, Jc, None if self._canon_identity else self._canon_dev, yx, tj.contiguous(),
                                   vis.contiguous(), objs, d_yx)
-                d_joints, _ = engine.project_backward(cams, lbs["joints"], d_yx=d_yx, d_fov_img=d_fov_img)
             if w_reproj > 0:
-                ndc, _ = engine.project(cams, lbs["verts"], want_yx=False)
                 tgt = self._sil_dev if idx is None else self._sil_dev.index_select(0, img_idx).contiguous()
                 tsum = self._sil_sum if idx is None else self._sil_sum.index_select(0, img_idx).contiguous()
-                pscale = engine.pix_scale(fc, views, S, dev)
+                pscale = self._pix_scale(fc, views, S)
                 loss_img, d_ndc, _ = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings)
-                engine.sil_objective(loss_img, pscale, objs)
-                d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img)
-            d_fov_sel = engine.fov_reduce(cams, d_fov_img)
-            if fov.numel() in (1, views) or idx is None:
-                d_fov = d_fov_sel
+            if both:
+                d_verts, d_joints = engine.project_backward_verts_and_joints(cams, lbs["verts"], d_ndc, lbs["joints"], d_yx, d_fov_img)
+            elif w_j2d > 0:
+                d_joints, _ = engine.project_backward(cams, lbs["joints"], d_yx=d_yx, d_fov_img=d_fov_img)
             else:
-                d_fov.index_add_(0, img_idx, d_fov_sel)
+                d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img)
+            d_fov_sel = torch.empty(cams.fov.numel(), dtype=torch.float32, device=dev)
+            # the shared shape gradient is accumulated straight into d_betas (where the shape prior adds its own)
             g_lbs = engine.lbs_backward(dm, lbs, d_verts, d_joints, need_beta=self.betas.requires_grad,
                                         need_logscale=self.log_beta_scales.requires_grad,
-                                        need_btrans=self.betas_trans.requires_grad, need_trans=self.trans.requires_grad)
+                                        need_btrans=self.betas_trans.requires_grad, need_trans=self.trans.requires_grad,
+                                        d_beta_accum=d_betas)
         if g_lbs is not None and g_lbs["d_theta"] is not None:
             d_pose = g_lbs["d_theta"]
             d_trans = g_lbs["d_trans"] if g_lbs["d_trans"] is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
-            if g_lbs["d_beta"] is not None:
-                d_betas += g_lbs["d_beta"]
             accumulate = True
         else:
             d_pose = torch.empty(n, J, 3, dtype=torch.float32, device=dev)
             d_trans = torch.zeros(n, 3, dtype=torch.float32, device=dev)
             accumulate = False
-        engine.prior_losses(fc, pose, trans, betas, self.mean_betas, self.betas_prec, mask, objs, d_pose, d_trans, d_betas,
-                            halo_prev=halo_prev, halo_next=halo_next, accumulate=accumulate)
+        # priors + temporal terms + silhouette objective + fov reduction: one launch
+        engine.fit_epilogue(fc, pose, trans, betas, self.mean_betas, self.betas_prec, mask, objs, d_pose, d_trans, d_betas,
+                            halo_prev=halo_prev, halo_next=halo_next, accumulate=accumulate, loss_img=loss_img, pix_scale=pscale,
+                            cams=cams if d_fov_sel is not None else None, d_fov_img=d_fov_img if d_fov_sel is not None else None,
+                            d_fov=d_fov_sel)
+        if d_fov_sel is not None and (fov.numel() in (1, views) or idx is None):
+            d_fov = d_fov_sel
+        else:
+            d_fov = torch.zeros_like(fov)
+            if d_fov_sel is not None:  # per-image fov, window of frames: scatter the selected images' gradients
+                d_fov.index_add_(0, img_idx, d_fov_sel)
 
         def scatter(rows, like):
             if idx is None:

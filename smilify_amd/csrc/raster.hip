@@ -61,7 +61,14 @@
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
-// -DDBG_TIMERS: per-phase cycle sums of the tile kernel (printed by the next launch); off in normal builds
+// -DDBG_TIMERS: per-phase cycle sums and work counters of the tile kernel (printed by the next launch); off in normal
+// builds (tools/dbg builds libsmilfit_dbg.so with it).  The marks only read the cycle counter into registers; the one
+// place that touches memory is TIMERS_FLUSH / STAT: lane 0 of a single-wave workgroup issuing returning-free global
+// atomics on a 256-byte buffer, outside any divergent region and with no barrier or spin depending on their completion -
+// nothing another wave waits for, so they cannot deadlock the persistent loop (the kernel's exit condition is the work
+// counter alone).
+// -DRASTER_EXPERIMENT: ablation knobs read from the environment by the host side (SMIL_STOP, SMIL_WRAP, SMIL_RESIDENT);
+// results are garbage under SMIL_WRAP / SMIL_STOP by design - timing experiments only, never in libsmilfit.so.
 #ifdef DBG_TIMERS
 #define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0;
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
@@ -805,7 +812,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 continue;
             }
             if (lane == 0) scfirst[chunks_done] = (uint32_t)vbase;  // (chunks behind an early exit hold no records)
-            STAT(21, vbase) STAT(26, 1) STAT(27, list_total)
+            STAT(21, vbase) STAT(26, 1) STAT(27, list_total) STAT(28, chunks_done) STAT(29, (list_total + DCHUNK - 1) / DCHUNK) STAT(30, __popcll(open_px))
             __syncthreads();  // also: record stores of other lanes are visible from here on
             TMARK(1)
 #ifdef RASTER_EXPERIMENT
@@ -1221,8 +1228,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         fprintf(stderr, "[dbg timers] per class: unit time sums %.3e %.3e %.3e %.3e  longest unit %.3e %.3e %.3e %.3e  latest unit start %.3e %.3e %.3e %.3e\n",
                 (double)h[8], (double)h[9], (double)h[10], (double)h[11], (double)h[12], (double)h[13], (double)h[14], (double)h[15],
                 (double)h[16], (double)h[17], (double)h[18], (double)h[19]);
-        fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e\n",
-                (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25]);
+        fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e; chunks walked %.4e of %.4e, pixels still open at the end %.4e\n",
+                (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25], (double)h[28], (double)h[29], (double)h[30]);
         (void)hipMemset(dbg_dev, 0, 256);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;

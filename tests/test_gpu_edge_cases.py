@@ -301,3 +301,22 @@ def test_random_configurations_against_oracle(seed, tables):
         cos = (gotg * want).sum() / (np.linalg.norm(gotg) * np.linalg.norm(want) + 1e-30)
         rel = np.linalg.norm(gotg - want) / np.linalg.norm(want)
         assert cos > 0.99999 and rel < 2e-3, (msg, cos, rel)
+
+
+def test_more_tiles_than_the_setup_kernel_counts(tables):
+    """768^2 = 9216 tiles per image: above COUNT_TILES_MAX the setup kernel keeps a touched-tile bitmap instead of per-tile
+    costs and queues every tile in one class; the result must not depend on that."""
+    eng = _eng()
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 768
+    ndc = _scene(t, 1, S, 2.6, 12)
+    ref, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    got = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
+    d = np.abs(got - ref)
+    assert ref.sum() > 1000 and d.mean() < 2e-6 and np.mean(d > 1e-4) < 1e-3, (ref.sum(), d.mean(), np.mean(d > 1e-4))
+    gs = torch.ones(1, S, S) / (S * S)
+    with render_ref.select_mode(1):
+        want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
+    gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
+    assert np.linalg.norm(gotg - want) / np.linalg.norm(want) < 2e-3

@@ -82,7 +82,7 @@ __global__ void k_shape_blend(const float *__restrict__ vt, const float *__restr
 
 // rest joints: J = J_static or J_regressor^T v_shaped (CSR gather)               (smal_torch.py:257-264)
 // One wave per joint (strided over the block's waves), lanes over the non-zeros of its regressor row.
-__global__ void __launch_bounds__(256) k_rest_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
+__global__ void __launch_bounds__(1024) k_rest_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      const float *__restrict__ val, const float *__restrict__ v_shaped,
                                                      const float *__restrict__ J_static, float *__restrict__ J_rest, int V, int J,
                                                      int is_static) {
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) k_skin_fwd(const float *__restrict__ A, c
 // posed joints by regression from the posed vertices                           (smal_torch.py:348-351)
 // trans_after != NULL: the vertices already carry the frame translation but the reference regresses the
 // joints from the untranslated vertices and adds the translation afterwards (fitter.py:280-281).
-__global__ void __launch_bounds__(256) k_regress_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
+__global__ void __launch_bounds__(1024) k_regress_joints(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                         const float *__restrict__ val, const float *__restrict__ verts,
                                                         const float *__restrict__ trans_after, float *__restrict__ joints, int V,
                                                         int J) {
@@ -371,7 +371,8 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
                            out->v_shaped, 3 * V, in->nB_used, in->shared_beta ? 0 : in->nB_used);
         SMIL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rest_joints, dim3(nS), dim3(256), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
+    hipLaunchKernelGGL(k_rest_joints, dim3(nS), dim3(1024), 0, stream,  // 16 waves: 3-4 joints each (latency of a single frame)
+                       m->jreg_rowptr, m->jreg_col, m->jreg_val,
                        out->v_shaped, m->J_static, out->J_rest, V, J, m->static_joints ? 1 : 0);
     SMIL_LAUNCH_CHECK();
     {
@@ -408,7 +409,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
         SMIL_LAUNCH_CHECK();
     }
     if (!m->static_joints) {
-        hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(256), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
+        hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(1024), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
                            out->verts, (in->trans_after_joints && in->trans) ? in->trans : nullptr, out->joints, V, J);
         SMIL_LAUNCH_CHECK();
     }

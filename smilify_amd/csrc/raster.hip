@@ -50,8 +50,12 @@
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
 #define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
+#ifndef DGROUP
 #define DGROUP 4            // 64-record rows per buffer in the dense walks (two buffers)
+#endif
+#ifndef KGROUP
 #define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
+#endif
 #ifndef REC_CAP
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
 #endif

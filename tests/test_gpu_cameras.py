@@ -112,3 +112,36 @@ def test_renderer_aspect_branch(scalar_aspect, tables):
     sil_o, _ = oren(verts.detach().cpu(), joints.detach().cpu(), smal.faces.cpu())
     d = (sil.detach().cpu() - sil_o).abs().numpy()
     assert sil_o.sum() > 10 and d.mean() < 5e-6 and d.max() < 2e-3, (float(sil_o.sum()), d.mean(), d.max())
+
+
+def test_batched_multiview_joint_projection(tables):
+    """The neural multi-view path's use of the renderer (reference multiview_smil_regressor.py:1623-1705): LBS once per
+    frame, joints projected through frames x views cameras in one call.  Image n = frame * views + view; gradients of the
+    projected joints flow back to the (per-frame) joints summed over the views."""
+    from smilify_amd.p3d_renderer import Renderer
+
+    t = tables("synthetic")
+    S, B, V = 128, 3, 4
+    cal = _calibrations(V, S, seed=9)
+    R, T, fov, aspect = _fov_cameras(cal, S)
+    g = torch.Generator().manual_seed(5)
+    joints = (0.4 * torch.randn(B, t.J, 3, generator=g)).to(DEV).requires_grad_()
+    rend = Renderer(S, DEV, views=V)
+    rend.set_camera_parameters(R, T, fov, aspect_ratio=aspect)
+    none, proj = rend(joints, joints, None, joints_only=True)
+    assert none is None and proj.shape == (B * V, t.J, 2)
+    Jn = joints.detach().cpu().numpy().astype(np.float64)
+    for b in range(B):
+        for v, (R_cv, t_cv, K) in enumerate(cal):
+            u, vv = _pinhole(Jn[b], R_cv, t_cv, K)
+            np.testing.assert_allclose(proj[b * V + v, :, 0].detach().cpu().numpy(), vv, atol=1e-2)
+            np.testing.assert_allclose(proj[b * V + v, :, 1].detach().cpu().numpy(), u, atol=1e-2)
+    w = torch.randn(B * V, t.J, 2, generator=g).to(DEV)
+    (proj * w).sum().backward()
+    jo = joints.detach().cpu().clone().requires_grad_()
+    tot = 0.0
+    for v in range(V):
+        po = render_ref.project_points_screen(jo, R[v:v + 1].expand(B, 3, 3), T[v:v + 1].expand(B, 3), fov[v:v + 1].expand(B), S, aspect[v:v + 1].expand(B))
+        tot = tot + (po * w.cpu()[v::V]).sum()
+    tot.backward()
+    np.testing.assert_allclose(joints.grad.cpu().numpy(), jo.grad.numpy(), rtol=2e-4, atol=2e-3)

@@ -90,7 +90,8 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 // Work items (touched tiles) are queued in four cost classes by the number of (face, pixel) pairs the tile will evaluate
 // (the sum of its faces' pixel boxes), and handed out heaviest class first: a persistent kernel whose longest items take
 // a fifth of the whole launch must not start them last.
-// Two arrays of N * tiles entries hold two classes each (one filled from the front, one from the back).
+// Per partition two arrays of ceil(N / N_PARTS) * tiles entries hold two classes each (one filled from the front, one
+// from the back).
 #define N_CLASSES 4
 #ifndef CLASS_T0
 #define CLASS_T0 65536        // class 0 can be dealt out in pieces (SPLIT0_LOG)
@@ -101,9 +102,15 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #define SPLIT0_LOG 0          // log2 of the pieces every class-0 tile is dealt out in (0: whole; with near-to-far lists and closing the
 #endif                        // tiles with the longest lists finish early, and pieces only repeat their list walk: measured 2 -> 0: mouse -9 %)
 #define COUNT_TILES_MAX 8192  // per-tile face counts live in LDS (4 bytes each); larger images queue everything in the last class
+// XCD-aware dealing.  Each of the 8 XCDs of an MI355X has its own 4 MB L2, and the tiles of one image read the same
+// per-image tables (projected vertices, face tile boxes, depth ranges: ~180 KB on STICK).  Images are therefore dealt to
+// N_PARTS work-list partitions (image % N_PARTS); a workgroup drains the partition of the XCD it runs on first
+// (HW_REG_XCC_ID - placement is whatever the dispatcher chose, only speed depends on it) and then helps the others, so an
+// image's tables are fetched into one L2 instead of eight while the launch is busy, and the tail still balances.
+#define N_PARTS 8
 struct RasterCounters {
-    unsigned int n_class[N_CLASSES];
-    unsigned int next;
+    unsigned int n_class[N_PARTS][N_CLASSES];
+    struct { unsigned int next, pad[15]; } deal[N_PARTS];  // one cache line per partition's cursor
 };
 
 struct RasterArgs {
@@ -111,8 +118,8 @@ struct RasterArgs {
     const int *faces;        // (F,3)
     const uint32_t *tbox;    // (N,F) tile box of every face
     const uint32_t *gbox;    // (N, ceil(F/64)) union of the tile boxes of 64 consecutive faces
-    const uint32_t *items;   // work lists: [0, cap) classes 0 (front) / 1 (back), [cap, 2 cap) classes 2 / 3
-    uint32_t item_cap;       // N * tiles
+    const uint32_t *items;   // work lists, per partition q at 2 q cap: [0, cap) classes 0 (front) / 1 (back), [cap, 2 cap) classes 2 / 3
+    uint32_t item_cap;       // entries of one array of ONE partition: ceil(N / N_PARTS) * tiles
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
@@ -247,7 +254,8 @@ __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__
 #pragma unroll
     for (int k = 0; k < N_CLASSES; ++k) off[k] = mine[k] ? atomicAdd(&s_cnt[k], mine[k]) : 0u;
     __syncthreads();
-    if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr->n_class[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    const int part = n % N_PARTS;
+    if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr->n_class[part][threadIdx.x], s_cnt[threadIdx.x]) : 0u;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < N_CLASSES; ++k) off[k] += s_base[k];
@@ -259,7 +267,7 @@ __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__
         for (int k = 0; k < N_CLASSES; ++k)
             if (c == k) slot = off[k]++;
         // classes 0 and 2 grow from the front of their array, 1 and 3 from the back
-        const uint32_t idx = (uint32_t)(c >> 1) * item_cap + ((c & 1) ? item_cap - 1u - slot : slot);
+        const uint32_t idx = (uint32_t)(2 * part + (c >> 1)) * item_cap + ((c & 1) ? item_cap - 1u - slot : slot);
         items[idx] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
     }
 }
@@ -609,22 +617,31 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
-    const unsigned int nc0 = a.ctr->n_class[0], nc1 = a.ctr->n_class[1], nc2 = a.ctr->n_class[2], nc3 = a.ctr->n_class[3];
-    const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
+    unsigned int n_items_all = 0;
+    for (int q = 0; q < N_PARTS; ++q)
+        for (int c = 0; c < N_CLASSES; ++c) n_items_all += a.ctr->n_class[q][c];
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
     // the launch finishes in a fraction of one tile's serial time.
-    const unsigned int split_log = n_items * 8u <= gridDim.x ? 3u : (n_items * 4u <= gridDim.x ? 2u : (n_items * 2u <= gridDim.x ? 1u : 0u));
+    const unsigned int split_log = n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u));
     // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
     // near to far).
     const unsigned int split0_log = SPLIT0_LOG;
-    const unsigned int units0 = nc0 << split0_log;
-    const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
     const float fS = (float)a.S;
+    unsigned int xcc;  // the XCD this workgroup runs on: which partition it drains first
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= (unsigned int)(N_PARTS - 1);
 
     TIMERS_INIT
-    while (true) {
+    for (unsigned int turn = 0; turn < N_PARTS; ++turn) {
+    const unsigned int part = (xcc + turn) & (unsigned int)(N_PARTS - 1);
+    const unsigned int nc0 = a.ctr->n_class[part][0], nc1 = a.ctr->n_class[part][1], nc2 = a.ctr->n_class[part][2], nc3 = a.ctr->n_class[part][3];
+    const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
+    const unsigned int units0 = nc0 << split0_log;
+    const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
+    const uint32_t *const items = a.items + (size_t)part * 2u * a.item_cap;
+    while (n_units > 0u) {
         unsigned int unit = 0;
-        if (lane == 0) unit = atomicAdd(&a.ctr->next, 1u);
+        if (lane == 0) unit = atomicAdd(&a.ctr->deal[part].next, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= n_units) break;
 #ifdef DBG_TIMERS
@@ -635,10 +652,10 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         const unsigned int item = (u_ >> sl) + (heavy ? 0u : nc0);
         const int p_begin = (int)(u_ & ((1u << sl) - 1u)) * (WAVE >> sl), p_end = p_begin + (WAVE >> sl);
         // heaviest class first
-        const uint32_t code = item < nc0 ? a.items[item]
-                            : item < nc0 + nc1 ? a.items[a.item_cap - 1u - (item - nc0)]
-                            : item < nc0 + nc1 + nc2 ? a.items[a.item_cap + (item - nc0 - nc1)]
-                            : a.items[2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2)];
+        const uint32_t code = item < nc0 ? items[item]
+                            : item < nc0 + nc1 ? items[a.item_cap - 1u - (item - nc0)]
+                            : item < nc0 + nc1 + nc2 ? items[a.item_cap + (item - nc0 - nc1)]
+                            : items[2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2)];
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
@@ -1111,6 +1128,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         }
 #endif
     }
+    }  // next partition
     TIMERS_FLUSH
 }
 
@@ -1151,7 +1169,8 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
     // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), per-workgroup scratch
-    return align256((size_t)N * m->F * sizeof(uint32_t)) + 256 + align256((size_t)2 * N * tiles * sizeof(uint32_t)) +
+    return align256((size_t)N * m->F * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
+           align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint32_t)) +
            align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) + 256 +
            scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
@@ -1171,10 +1190,10 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     uint32_t *tbox = (uint32_t *)ws;
     ws += align256((size_t)N * m->F * sizeof(uint32_t));
     RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
-    ws += 256;
+    ws += align256(sizeof(RasterCounters));
     uint32_t *items = (uint32_t *)ws;
-    const uint32_t item_cap = (uint32_t)N * (uint32_t)(tiles_x * tiles_x);
-    ws += align256((size_t)2 * item_cap * sizeof(uint32_t));
+    const uint32_t item_cap = (uint32_t)ceil_div(N, N_PARTS) * (uint32_t)(tiles_x * tiles_x);
+    ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(uint32_t));
     float2 *fzr = (float2 *)ws;
     ws += align256((size_t)N * m->F * sizeof(float2));
     uint32_t *gbox = (uint32_t *)ws;

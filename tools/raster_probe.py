@@ -47,7 +47,7 @@ if args.quick:
     sys.exit(0)
 ws = dm._ws
 off = ((N * dm.F * 4 + 255) // 256) * 256
-ctr = ws[off:off + 16].view(torch.int32).cpu().numpy()
+ctr = ws[off:off + 128].view(torch.int32).cpu().numpy().reshape(8, 4).sum(0)  # (partition, cost class) counters
 n_work = int(ctr[:4].sum())
 tb = ws[: N * dm.F * 4].view(torch.int32).reshape(N, dm.F).cpu().numpy().astype(np.uint32)
 tx0, ty0, tx1, ty1 = tb & 255, (tb >> 8) & 255, (tb >> 16) & 255, tb >> 24

@@ -404,6 +404,15 @@ __device__ __forceinline__ const T &at(const T *base, uint32_t i) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
 }
 
+// Record-stream accesses: written once, read once or twice, never shared between workgroups.
+#ifdef STREAM_NT
+template <typename T> __device__ __forceinline__ T ld_stream(const T *base, uint32_t i) { return __builtin_nontemporal_load(&at(base, i)); }
+template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_t i, T v) { __builtin_nontemporal_store(v, &at(base, i)); }
+#else
+template <typename T> __device__ __forceinline__ T ld_stream(const T *base, uint32_t i) { return at(base, i); }
+template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_t i, T v) { at(base, i) = v; }
+#endif
+
 // Single-wave workgroups: lanes exchange data through LDS without s_barrier, but the compiler must not forward a lane's
 // own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
 // outstanding global stores (vmcnt), which in pass 1 would stall every sweep step on the previous step's record stores.
@@ -810,11 +819,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const uint32_t zb = __float_as_uint(z);
                     const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (cand) {
-                        at(sz, slot) = zb;
-                        at(smeta, slot) = (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23);
-                        at(srx, slot) = e.rx;
-                        at(sry, slot) = e.ry;
-                        at(st, slot) = e.t;
+                        st_stream(sz, slot, zb);
+                        st_stream(smeta, slot, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23));
+                        st_stream(srx, slot, e.rx);
+                        st_stream(sry, slot, e.ry);
+                        st_stream(st, slot, e.t);
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
@@ -873,7 +882,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
                         const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
-                        r[u].z = at(sz, idx); r[u].mt = at(smeta, idx); r[u].rx = at(srx, idx); r[u].ry = at(sry, idx);
+                        r[u].z = ld_stream(sz, idx); r[u].mt = ld_stream(smeta, idx); r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx);
                     }
                 };
                 auto blend_recs = [&](const Rec (&r)[DGROUP], int g0) {
@@ -1045,8 +1054,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
-                            r[u].z = at(sz, idx); r[u].mt = at(smeta, idx);
-                            r[u].rx = at(srx, idx); r[u].ry = at(sry, idx); r[u].t = at(st, idx);
+                            r[u].z = ld_stream(sz, idx); r[u].mt = ld_stream(smeta, idx);
+                            r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx); r[u].t = ld_stream(st, idx);
                         }
                     };
                     auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {

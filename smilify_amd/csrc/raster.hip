@@ -611,6 +611,65 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
     __syncthreads();
 }
 
+// One refinement step of the radix select over the compact stream, which SHRINKS as it goes.  Among the records of pixel p
+// (still selecting: psel[p].y > 0) the bits of the key above `nbits` are compared with the prefix psel[p].x chosen so far:
+//   below it  -> the record lies in a lower bucket of the digit picked last: it is among the K nearest for certain, its log
+//                factor goes to the pixel's sum and the record leaves the stream;
+//   equal     -> it stays (compacted IN PLACE: the write position never passes the read position, and every lane has
+//                loaded its record before any lane of the same step stores) and its next `b` bits are histogrammed;
+//   above     -> dropped.
+// Returns the number of records left.  Every later sweep thus reads only the records that are still undecided (a tenth per
+// digit) instead of the whole compact stream, and the final pass only sees the last bucket.
+__device__ __forceinline__ int refine_sweep(DenseLds &lds, uint32_t *ckey, uint32_t *cmeta, float *clf, int n_rec, int nbits, int b,
+                                            int lane, uint32_t pre, int need) {
+    const int shift = nbits - b;
+    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+    __syncthreads();
+    int n_out = 0;
+    struct CRec { uint32_t kk, mt; float lf; };
+    auto load_recs = [&](CRec (&r)[KGROUP], int g0) {
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_rec - 1);
+            r[u].kk = at(ckey, idx); r[u].mt = at(cmeta, idx); r[u].lf = at(clf, idx);
+        }
+    };
+    auto sift_recs = [&](const CRec (&r)[KGROUP], int g0) {
+        uint2 ps[KGROUP];  // all LDS gathers first: one latency, not one per row
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) ps[u] = lds.psel[r[u].mt & 63u];
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t pxl = r[u].mt & 63u;
+            const bool live = (g0 + u * WAVE + lane < n_rec) & (ps[u].y > 0u);
+            const uint32_t top = r[u].kk >> nbits;
+            const bool sure = live & (top < ps[u].x), stay = live & (top == ps[u].x);
+            if (sure & (r[u].lf != 0.f)) atomicAdd(&lds.plog[pxl], (double)r[u].lf);
+            const unsigned long long sm = __ballot(stay);
+            const uint32_t slot = (uint32_t)n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+            if (stay) {
+                at(ckey, slot) = r[u].kk; at(cmeta, slot) = r[u].mt; at(clf, slot) = r[u].lf;
+                const uint32_t bucket = (r[u].kk >> shift) & ((1u << b) - 1u);
+                atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+            }
+            n_out += __popcll(sm);
+        }
+    };
+    if (n_rec > 0) {  // double-buffered: the next KGROUP rows are in flight while this one is sifted
+        CRec ra[KGROUP], rb[KGROUP];
+        load_recs(ra, 0);
+        for (int g0 = 0; g0 < n_rec; g0 += 2 * KGROUP * WAVE) {
+            load_recs(rb, g0 + KGROUP * WAVE);
+            sift_recs(ra, g0);
+            load_recs(ra, g0 + 2 * KGROUP * WAVE);
+            sift_recs(rb, g0 + KGROUP * WAVE);
+        }
+    }
+    __syncthreads();
+    return n_out;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
@@ -929,10 +988,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     nbits -= b2;
                     __syncthreads();
                 }
-                auto depth_key = [&](uint32_t idx, uint32_t) { return at(ckey, idx); };
                 while (nbits > 0 && __ballot(need > 0) != 0ull) {
                     const int b = min(SEL_BITS, nbits);
-                    select_sweep(lds, cmeta, n_cmp, nbits, b, lane, pre, need, depth_key);
+                    n_cmp = refine_sweep(lds, ckey, cmeta, clf, n_cmp, nbits, b, lane, pre, need);
                     pick_digit(lds.hist, lane, b, pre, need, n_eq);
                     nbits -= b;
                     __syncthreads();
@@ -960,7 +1018,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     }
                     if (split) tie_cut = (int)ppre;
                 }
-                // the compact records that made it: depth below the threshold, or at it up to the tie cut
+                // the compact records still in the stream (those of the last bucket examined) that made it: depth below the
+                // threshold, or at it up to the tie cut
                 lds.pgrad[lane] = make_float4(0.f, __uint_as_float(trunc ? pre : 0u), __int_as_float(tie_cut), 0.f);
                 __syncthreads();
                 for (int g0 = 0; g0 < n_cmp; g0 += DGROUP * WAVE) {

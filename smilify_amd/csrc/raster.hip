@@ -512,34 +512,68 @@ __device__ __forceinline__ void sort_list_near_to_far(const float2 *__restrict__
     __syncthreads();
 }
 
-__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list,
-                                            int c0, int m, float *rec, int lane, float cx, float cy) {
-    if (lane < m) {
-        const int f = (int)list[c0 + lane];
+// Staging of a chunk of DCHUNK = 32 faces by all 64 lanes: lanes l and l + 32 share face l.  The LOW lane builds the affine
+// forms (rows 1-3 of the record) and the pixel ROWS the face's blurred box covers inside the open part of the tile; the
+// HIGH lane the bounding box (row 0), the edge data (rows 4-7) and the pixel COLUMNS; the columns then cross over (one
+// ds_bpermute each) and the low lane leaves with the face's pair count `cf` and the word pairs decode their pixel from.
+// Both lanes load the same nine vertex floats (one transaction).  Pixel index i (flipped axis) has centre -1 + (2i+1)/S:
+// centres inside [lo, hi] are ceil(v_lo) .. floor(v_hi) with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding
+// (a superset; eval_pair applies the exact test).
+static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
+__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list, int c0, int m,
+                                            float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
+                                            int oy0, int oy1, int &cf, int &packed2) {
+    const int slot = lane & (DCHUNK - 1);
+    const bool hi = lane >= DCHUNK;
+    int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
+    if (slot < m) {
+        const int f = (int)list[c0 + slot];
         const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
         const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
         const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
         const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
-        FaceRec r;
-        r.xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur; r.xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
-        r.ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur; r.ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
-        // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
-        const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
-        // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
-        const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
-        r.A0 = (y2 - y1) * s0; r.B0 = -(x2 - x1) * s0; r.C0 = edge_fn(cx, cy, x1, y1, x2, y2) * s0;
-        r.A1 = (y0 - y2) * s1; r.B1 = -(x0 - x2) * s1; r.C1 = edge_fn(cx, cy, x2, y2, x0, y0) * s1;
-        r.A2 = (y1 - y0) * s2; r.B2 = -(x1 - x0) * s2; r.C2 = edge_fn(cx, cy, x0, y0, x1, y1) * s2;
-        r.z0 = z0; r.z1 = z1; r.z2 = z2;
-        r.x0c = x0 - cx; r.y0c = y0 - cy; r.x1c = x1 - cx; r.y1c = y1 - cy;
-        r.e01x = x1 - x0; r.e01y = y1 - y0; r.e02x = x2 - x0; r.e02y = y2 - y0; r.e12x = x2 - x1; r.e12y = y2 - y1;
-        const float l01 = r.e01x * r.e01x + r.e01y * r.e01y, l02 = r.e02x * r.e02x + r.e02y * r.e02y,
-                    l12 = r.e12x * r.e12x + r.e12y * r.e12y;
-        r.rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
-        r.rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
-        r.rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
-        r.i0 = i0; r.i1 = i1; r.i2 = i2;
-        *reinterpret_cast<FaceRec *>(rec + lane * FSTR) = r;
+        float4 *r = reinterpret_cast<float4 *>(rec + slot * FSTR);
+        if (!hi) {
+            // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
+            const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
+            // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
+            const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
+            r[1] = make_float4((y2 - y1) * s0, -(x2 - x1) * s0, edge_fn(cx, cy, x1, y1, x2, y2) * s0, (y0 - y2) * s1);
+            r[2] = make_float4(-(x0 - x2) * s1, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);
+            r[3] = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
+            const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
+            const int yi_lo = (int)ceilf(((ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+            b0 = max(a.S - 1 - yi_hi - ty * TILE, oy0);
+            b1 = min(a.S - 1 - yi_lo - ty * TILE, oy1);
+        } else {
+            const float xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur, xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
+            const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
+            r[0] = make_float4(xmin, xmax, ymin, ymax);
+            const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
+            const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
+            const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
+            const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
+            const float rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
+            r[4] = make_float4(x0 - cx, y0 - cy, x1 - cx, y1 - cy);
+            r[5] = make_float4(e01x, e01y, rl01, e02x);
+            r[6] = make_float4(e02y, rl02, e12x, e12y);
+            r[7] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
+            const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+            b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
+            b1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
+        }
+    }
+    const int bx0 = __shfl(b0, slot + DCHUNK, WAVE), bx1 = __shfl(b1, slot + DCHUNK, WAVE);  // (all lanes: no divergent ds_bpermute)
+    cf = 0;
+    packed2 = 0;
+    if (!hi && slot < m && bx0 <= bx1 && b0 <= b1) {
+        const int bw = bx1 - bx0 + 1;
+        cf = bw * (b1 - b0 + 1);
+        // what a pair needs to find its pixel: pair r of the box sits in box row r / bw, computed as (r * inv) >> 16 with
+        // inv = floor(65536 / bw) + 1 (exact for r < 64, bw <= 8; the reciprocal is exact for 1, 2, 4, 8 and 0.003 away from
+        // an integer at worst otherwise), and its pixel is first + r + (r / bw) * (8 - bw)
+        const int inv = (int)(65536.0f * __builtin_amdgcn_rcpf((float)bw)) + 1;
+        packed2 = inv | ((8 - bw) << 17) | ((b0 * TILE + bx0) << 20);
     }
 }
 
@@ -799,31 +833,14 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     }
                 }
                 const int m = min(DCHUNK, list_total - c0);
-                stage_faces(a, vn, lst, c0, m, lds.rec, lane, cx, cy);
+                int cf, packed2, packed = 0;
+                stage_faces(a, vn, lst, c0, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, cf, packed2);
                 if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
 #ifdef RASTER_EXPERIMENT
                 if (a.stop_after == 1) continue;
 #endif
-                // lane = staged face: pixel box of its blurred bounding box inside this sub-tile (same rounding slack as the
-                // setup kernel: a superset; eval_pair applies the exact test)
-                int cf = 0, packed = 0, packed2 = 0;
-                if (lane < m) {
-                    const FaceRec &fr = *reinterpret_cast<const FaceRec *>(lds.rec + lane * FSTR);
-                    const int xi_lo = (int)ceilf(((fr.xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((fr.xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-                    const int yi_lo = (int)ceilf(((fr.ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((fr.ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-                    const int bx0 = max(a.S - 1 - xi_hi - tx * TILE, ox0), bx1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
-                    const int by0 = max(a.S - 1 - yi_hi - ty * TILE, oy0), by1 = min(a.S - 1 - yi_lo - ty * TILE, oy1);
-                    if (bx0 <= bx1 && by0 <= by1) {
-                        const int bw = bx1 - bx0 + 1;
-                        cf = bw * (by1 - by0 + 1);
-                        // what a pair needs to find its pixel: pair r of the box sits in box row r / bw, computed as
-                        // (r * inv) >> 16 with inv = floor(65536 / bw) + 1 (exact for r < 64, bw <= 8), and its pixel is
-                        // first + r + (r / bw) * (8 - bw)
-                        packed2 = (65536 / bw + 1) | ((8 - bw) << 17) | ((by0 * TILE + bx0) << 20);
-                    }
-                }
                 const int incl = wave_scan_add(cf);
                 const int off = incl - cf;          // first pair of this face in the chunk's pair list
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);

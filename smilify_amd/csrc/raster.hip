@@ -21,9 +21,9 @@
 //              the boxes end to end, and the wave sweeps that pair list 64 at a time (a start-bit map gives each pair its
 //              face with two v_mbcnt and one ds_bpermute; face record and pixel coordinates are gathered from LDS).
 //              Accepted pairs are ballot-compacted into the workgroup's record streams - depth, {pixel | list position |
-//              inside | edge}, rx, ry, t: five words, structure of arrays - in global memory (reused for every tile).  The
+//              inside | edge}, rx, ry: four words, structure of arrays - in global memory (reused for every tile).  The
 //              first radix digit of every depth is histogrammed on the way (the tile's depth range is known from the list).
-//      blend   one sweep over the records (16 of the 20 bytes).  A record of a pixel with <= K candidates, or whose first
+//      blend   one sweep over the records (their 16 bytes; 12 where no pixel is truncated).  A record of a pixel with <= K candidates, or whose first
 //              digit lies below the digit that holds the pixel's K-th depth, is kept for certain: log2 of its factor is
 //              added to the pixel's sum (fp64 LDS atomics).  A record inside that digit goes on to a compact stream {key,
 //              meta, log} and has its second digit counted; one above it is dropped.
@@ -139,7 +139,7 @@ struct RasterArgs {
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
     uint32_t *sz;            // depth bits
     uint32_t *smeta;         // pixel | list position << 6 | inside << 22 | closest edge << 23
-    float *srx, *sry, *st;   // closest point minus pixel, clamped edge parameter
+    float *srx, *sry;        // closest point minus pixel (the clamped edge parameter is recomputed by pass 3)
     // records that survive the first selection digit: key (depth bits - tile minimum), meta, log2 of the blend factor
     uint32_t *ckey, *cmeta;
     float *clf;
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     uint32_t *const sz = a.sz + rec0, *const smeta = a.smeta + rec0;
-    float *const srx = a.srx + rec0, *const sry = a.sry + rec0, *const st = a.st + rec0;
+    float *const srx = a.srx + rec0, *const sry = a.sry + rec0;
     uint32_t *const ckey = a.ckey + rec0, *const cmeta = a.cmeta + rec0;
     float *const clf = a.clf + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
@@ -899,7 +899,6 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         st_stream(smeta, slot, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23));
                         st_stream(srx, slot, e.rx);
                         st_stream(sry, slot, e.ry);
-                        st_stream(st, slot, e.t);
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
@@ -958,7 +957,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
                         const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
-                        r[u].z = ld_stream(sz, idx); r[u].mt = ld_stream(smeta, idx); r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx);
+                        r[u].z = any_trunc ? ld_stream(sz, idx) : 0u;  // (wave-uniform: depths only matter where a pixel is truncated)
+                        r[u].mt = ld_stream(smeta, idx); r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx);
                     }
                 };
                 auto blend_recs = [&](const Rec (&r)[DGROUP], int g0) {
@@ -1119,19 +1119,25 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     // vertex ids of this chunk's faces: requested now, used by the flush
                     const int fch = ch * DCHUNK + lane;
                     int vi0 = 0, vi1 = 0, vi2 = 0;
+                    // ... and their projected vertices, from which a record's edge parameter t is recomputed (4 bytes less
+                    // written and read per record than storing it); the table lives where the selection histograms were
+                    float2 *const fv = reinterpret_cast<float2 *>(lds.hist);  // [GCHUNK][3]
                     if (fch < list_total) {
                         const int f = (int)lst[fch];
                         vi0 = a.faces[3 * f]; vi1 = a.faces[3 * f + 1]; vi2 = a.faces[3 * f + 2];
+                        fv[lane * 3 + 0] = make_float2(vn[3 * vi0], vn[3 * vi0 + 1]);
+                        fv[lane * 3 + 1] = make_float2(vn[3 * vi1], vn[3 * vi1 + 1]);
+                        fv[lane * 3 + 2] = make_float2(vn[3 * vi2], vn[3 * vi2 + 1]);
                     }
                     for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
                     __syncthreads();
-                    struct GRec { uint32_t z, mt; float rx, ry, t; };
+                    struct GRec { uint32_t z, mt; float rx, ry; };
                     auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
-                            r[u].z = ld_stream(sz, idx); r[u].mt = ld_stream(smeta, idx);
-                            r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx); r[u].t = ld_stream(st, idx);
+                            r[u].z = any_trunc ? ld_stream(sz, idx) : 0u;  // (threshold = +inf bits everywhere otherwise)
+                            r[u].mt = ld_stream(smeta, idx); r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx);
                         }
                     };
                     auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {
@@ -1152,9 +1158,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             int fid = 0;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
                             if (valid & (r[u].z == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[pos];
                             const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & (fid <= cut)));
-                            const float t = r[u].t;
                             const int edge = (int)(mt >> 23);
                             const int va = edge == 2 ? 1 : 0, vb = edge == 0 ? 1 : 2;  // end points of the closest edge
+                            // clamped projection of the pixel on that edge, as eval_pair computed it (0 for a degenerate edge)
+                            const float2 pa = fv[(pos % GCHUNK) * 3 + va], pb = fv[(pos % GCHUNK) * 3 + vb], pc = lds.pixt[mt & 63u];
+                            const float exx = pb.x - pa.x, eyy = pb.y - pa.y;
+                            const float l2 = exx * exx + eyy * eyy;
+                            const float t = __builtin_amdgcn_fmed3f((exx * (pc.x - pa.x) + eyy * (pc.y - pa.y)) * (l2 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l2)), 0.f, 1.f);
                             const float ex = 2.0f * r[u].rx * gd, ey = 2.0f * r[u].ry * gd;
                             const float bx = t * ex, by = t * ey;
 #ifdef RASTER_EXPERIMENT
@@ -1243,8 +1253,8 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (five record + three compact) words
-#define N_STREAMS 8
+// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (four record + three compact) words
+#define N_STREAMS 7
 static inline size_t scratch_bytes(int grid, int F) {
     return (size_t)grid * (2 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
@@ -1306,7 +1316,6 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.smeta = (uint32_t *)ws; ws += stream;
         a.srx = (float *)ws; ws += stream;
         a.sry = (float *)ws; ws += stream;
-        a.st = (float *)ws; ws += stream;
         a.ckey = (uint32_t *)ws; ws += stream;
         a.cmeta = (uint32_t *)ws; ws += stream;
         a.clf = (float *)ws;

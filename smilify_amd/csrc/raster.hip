@@ -21,9 +21,9 @@
 //              the boxes end to end, and the wave sweeps that pair list 64 at a time (a start-bit map gives each pair its
 //              face with two v_mbcnt and one ds_bpermute; face record and pixel coordinates are gathered from LDS).
 //              Accepted pairs are ballot-compacted into the workgroup's record streams - depth, {pixel | list position |
-//              inside | edge}, rx, ry: four words, structure of arrays - in global memory (reused for every tile).  The
+//              inside | edge}, signed squared distance: three words, structure of arrays - in global memory (reused for every tile).  The
 //              first radix digit of every depth is histogrammed on the way (the tile's depth range is known from the list).
-//      blend   one sweep over the records (their 16 bytes; 12 where no pixel is truncated).  A record of a pixel with <= K candidates, or whose first
+//      blend   one sweep over the records (their 12 bytes; 8 where no pixel is truncated).  A record of a pixel with <= K candidates, or whose first
 //              digit lies below the digit that holds the pixel's K-th depth, is kept for certain: log2 of its factor is
 //              added to the pixel's sum (fp64 LDS atomics).  A record inside that digit goes on to a compact stream {key,
 //              meta, log} and has its second digit counted; one above it is dropped.
@@ -139,7 +139,7 @@ struct RasterArgs {
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
     uint32_t *sz;            // depth bits
     uint32_t *smeta;         // pixel | list position << 6 | inside << 22 | closest edge << 23
-    float *srx, *sry;        // closest point minus pixel (the clamped edge parameter is recomputed by pass 3)
+    float *ssd;              // signed squared distance to the closest edge (pass 3 recomputes the closest point itself)
     // records that survive the first selection digit: key (depth bits - tile minimum), meta, log2 of the blend factor
     uint32_t *ckey, *cmeta;
     float *clf;
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     uint32_t *const sz = a.sz + rec0, *const smeta = a.smeta + rec0;
-    float *const srx = a.srx + rec0, *const sry = a.sry + rec0;
+    float *const ssd = a.ssd + rec0;
     uint32_t *const ckey = a.ckey + rec0, *const cmeta = a.cmeta + rec0;
     float *const clf = a.clf + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
@@ -897,8 +897,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     if (cand) {
                         st_stream(sz, slot, zb);
                         st_stream(smeta, slot, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23));
-                        st_stream(srx, slot, e.rx);
-                        st_stream(sry, slot, e.ry);
+                        st_stream(ssd, slot, e.sd);
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
@@ -952,13 +951,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             int n_cmp = 0;
             float rmax2 = 0.f;  // largest |closest point - pixel|^2 over the records: bounds the gradient sums of pass 3
             if (vbase > 0) {
-                struct Rec { uint32_t z, mt; float rx, ry; };
+                struct Rec { uint32_t z, mt; float sd; };
                 auto load_recs = [&](Rec (&r)[DGROUP], int g0) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
                         const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
                         r[u].z = any_trunc ? ld_stream(sz, idx) : 0u;  // (wave-uniform: depths only matter where a pixel is truncated)
-                        r[u].mt = ld_stream(smeta, idx); r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx);
+                        r[u].mt = ld_stream(smeta, idx); r[u].sd = ld_stream(ssd, idx);
                     }
                 };
                 auto blend_recs = [&](const Rec (&r)[DGROUP], int g0) {
@@ -971,9 +970,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         const uint32_t key = r[u].z - kmin, d1 = key >> nbits;
                         const bool sure = valid & ((ps[u].y == 0u) | (d1 < ps[u].x));
                         const bool maybe = valid & (ps[u].y > 0u) & (d1 == ps[u].x);
-                        const float dist = sq2(r[u].rx, r[u].ry);
-                        rmax2 = fmaxf(rmax2, dist);  // (the clamped tail repeats a record: harmless)
-                        const float lf = __log2f(1.0f - face_prob(((r[u].mt >> 22) & 1u) ? -dist : dist, a.inv_sigma));
+                        rmax2 = fmaxf(rmax2, fabsf(r[u].sd));  // (the clamped tail repeats a record: harmless)
+                        const float lf = __log2f(1.0f - face_prob(r[u].sd, a.inv_sigma));
                         if (sure & (lf != 0.f)) atomicAdd(&lds.plog[r[u].mt & 63u], (double)lf);
                         if (any_trunc) {  // wave-uniform
                             const unsigned long long km = __ballot(maybe);
@@ -1131,13 +1129,13 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     }
                     for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
                     __syncthreads();
-                    struct GRec { uint32_t z, mt; float rx, ry; };
+                    struct GRec { uint32_t z, mt; float sd; };
                     auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
                             r[u].z = any_trunc ? ld_stream(sz, idx) : 0u;  // (threshold = +inf bits everywhere otherwise)
-                            r[u].mt = ld_stream(smeta, idx); r[u].rx = ld_stream(srx, idx); r[u].ry = ld_stream(sry, idx);
+                            r[u].mt = ld_stream(smeta, idx); r[u].sd = ld_stream(ssd, idx);
                         }
                     };
                     auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {
@@ -1151,8 +1149,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             const int pos = (int)((mt >> 6) & 0xFFFFu);
                             const uint32_t zt_ = __float_as_uint(pg[u].y);
                             const bool inside = ((mt >> 22) & 1u) != 0u;
-                            const float dist = sq2(r[u].rx, r[u].ry);
-                            float gd = pg[u].x * face_prob(inside ? -dist : dist, a.inv_sigma);  // scale * d L / d (signed dist)
+                            float gd = pg[u].x * face_prob(r[u].sd, a.inv_sigma);                 // scale * d L / d (signed dist)
                             gd = inside ? -gd : gd;                                               // ... / d (unsigned squared distance)
                             const int cut = __float_as_int(pg[u].z);
                             int fid = 0;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
@@ -1160,12 +1157,14 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & (fid <= cut)));
                             const int edge = (int)(mt >> 23);
                             const int va = edge == 2 ? 1 : 0, vb = edge == 0 ? 1 : 2;  // end points of the closest edge
-                            // clamped projection of the pixel on that edge, as eval_pair computed it (0 for a degenerate edge)
+                            // closest point of that edge: clamped projection of the pixel, as eval_pair computed it (t = 0 for a
+                            // degenerate edge); r = closest point - pixel
                             const float2 pa = fv[(pos % GCHUNK) * 3 + va], pb = fv[(pos % GCHUNK) * 3 + vb], pc = lds.pixt[mt & 63u];
                             const float exx = pb.x - pa.x, eyy = pb.y - pa.y;
                             const float l2 = exx * exx + eyy * eyy;
                             const float t = __builtin_amdgcn_fmed3f((exx * (pc.x - pa.x) + eyy * (pc.y - pa.y)) * (l2 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l2)), 0.f, 1.f);
-                            const float ex = 2.0f * r[u].rx * gd, ey = 2.0f * r[u].ry * gd;
+                            const float rx = fmaf(t, exx, pa.x - pc.x), ry = fmaf(t, eyy, pa.y - pc.y);
+                            const float ex = 2.0f * rx * gd, ey = 2.0f * ry * gd;
                             const float bx = t * ex, by = t * ey;
 #ifdef RASTER_EXPERIMENT
                             if (a.stop_after == 4) { if (keep && ex + ey + t == 123.456f) lds.gacc[0][0] = 1ull; continue; }  // no LDS atomics
@@ -1253,8 +1252,8 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (four record + three compact) words
-#define N_STREAMS 7
+// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (three record + three compact) words
+#define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
     return (size_t)grid * (2 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
@@ -1314,8 +1313,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(uint32_t);
         a.sz = (uint32_t *)ws; ws += stream;
         a.smeta = (uint32_t *)ws; ws += stream;
-        a.srx = (float *)ws; ws += stream;
-        a.sry = (float *)ws; ws += stream;
+        a.ssd = (float *)ws; ws += stream;
         a.ckey = (uint32_t *)ws; ws += stream;
         a.cmeta = (uint32_t *)ws; ws += stream;
         a.clf = (float *)ws;

@@ -177,7 +177,7 @@ typedef struct {
 } SmilRasterSettings;
 
 /* Caller-owned scratch for N images of side S: per-face tile boxes / depth ranges, the tile work list, and the pair-record
- * streams of the resident workgroups (about 2.1 MB each, 14 per CU: 7.5 GB once N * tiles exceeds that many - size the
+ * streams of the resident workgroups (about 1.6 MB each, 16 per CU: 6.6 GB once N * tiles exceeds that many - size the
  * buffer once and reuse it).  Meshes with more than 65536 faces are rejected (SMIL_E_INVALID). */
 size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
 

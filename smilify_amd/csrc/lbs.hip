@@ -437,7 +437,10 @@ __device__ __forceinline__ void vertex_upstream(const float *__restrict__ d_vert
 
 // d_A[b][j] = sum_{v in bone j} w (dv (x) [v_posed;1]).  One block per frame, one wave per bone
 // (strided); deterministic (no atomics).
-__global__ void __launch_bounds__(1024) k_skin_bwd_transforms(
+#ifndef SKIN_BWD_THREADS
+#define SKIN_BWD_THREADS 512
+#endif
+__global__ void __launch_bounds__(SKIN_BWD_THREADS) k_skin_bwd_transforms(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ v_posed,
     const int *__restrict__ bone_ptr, const int *__restrict__ bone_vid, const float *__restrict__ bone_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
@@ -621,10 +624,14 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
 }
 
 #define BETA_CHUNK 8
+#define SHAPE_TERMS (BETA_CHUNK + 3)
+#ifndef SHAPE_BWD_THREADS
+#define SHAPE_BWD_THREADS 256
+#endif
 
 // Per frame: d v_posed = T_R^T dv (+ regressor^T d J_rest), reduced against shapedirs -> d_beta[b],
 // and d_trans[b] = sum_v dv.  One block per frame, deterministic.
-__global__ void __launch_bounds__(1024) k_shape_bwd(
+__global__ void __launch_bounds__(SHAPE_BWD_THREADS) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
@@ -634,7 +641,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     float *sA = smem;            // (J,12)
     float *sDJ = sA + J * 12;    // (J,3) upstream on posed joints
     float *sDR = sDJ + J * 3;    // (J,3) gradient on rest joints
-    float *red = sDR + J * 3;    // 16
+    float *red = sDR + J * 3;    // (waves, SHAPE_TERMS)
     const int b = blockIdx.x;
     const bool reg_j = regress && d_joints;
     const bool reg_r = regress && d_Jrest;
@@ -692,22 +699,33 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
                 }
             }
         }
-        for (int k = 0; k < BETA_CHUNK; ++k) {
-            if (k0 + k < nB_used) {
-                const float r = block_sum(bsum[k], red);
-                if (threadIdx.x == 0 && d_beta_frame) d_beta_frame[(size_t)b * nB_used + k0 + k] = r;
-                if (threadIdx.x == 0 && d_beta_shared && r != 0.f) atomicAdd(&d_beta_shared[k0 + k], r);  // sum over frames
+        // one batched reduction of the chunk's sums (BETA_CHUNK shape terms + 3 translation terms): wave sums into
+        // red[wave][term], one barrier, then one thread per term adds the waves in a fixed order
+        const bool with_trans = k0 == 0 && d_trans;
+        if (with_trans && trans_after && d_joints)
+            for (int j = threadIdx.x; j < J; j += blockDim.x) {
+                const float *dj = d_joints + ((size_t)b * J + j) * 3;
+                tsum[0] += dj[0]; tsum[1] += dj[1]; tsum[2] += dj[2];
             }
+        const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE, nw = (blockDim.x + WAVE - 1) / WAVE;
+        __syncthreads();  // `red` may still be read by the previous chunk
+#pragma unroll
+        for (int k = 0; k < BETA_CHUNK + 3; ++k) {
+            const float r = wave_sum(k < BETA_CHUNK ? bsum[k] : tsum[k - BETA_CHUNK]);
+            if (lane == 0) red[wid * SHAPE_TERMS + k] = r;
         }
-        if (k0 == 0 && d_trans) {
-            if (trans_after && d_joints)
-                for (int j = threadIdx.x; j < J; j += blockDim.x) {
-                    const float *dj = d_joints + ((size_t)b * J + j) * 3;
-                    tsum[0] += dj[0]; tsum[1] += dj[1]; tsum[2] += dj[2];
+        __syncthreads();
+        if (threadIdx.x < SHAPE_TERMS) {
+            const int k = threadIdx.x;
+            float r = 0.f;
+            for (int w = 0; w < nw; ++w) r += red[w * SHAPE_TERMS + k];
+            if (k < BETA_CHUNK) {
+                if (k0 + k < nB_used) {
+                    if (d_beta_frame) d_beta_frame[(size_t)b * nB_used + k0 + k] = r;
+                    if (d_beta_shared && r != 0.f) atomicAdd(&d_beta_shared[k0 + k], r);  // sum over frames
                 }
-            for (int c = 0; c < 3; ++c) {
-                const float r = block_sum(tsum[c], red);
-                if (threadIdx.x == 0) d_trans[3 * b + c] = r;
+            } else if (with_trans) {
+                d_trans[3 * b + k - BETA_CHUNK] = r;
             }
         }
     }
@@ -747,7 +765,7 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     const float *v_skin = m->posedirs ? sv->v_posed : sv->v_shaped;
     const int nS_skin = m->posedirs ? B : nS;
     SMIL_REQUIRE(!m->posedirs || (sv->v_posed && g->d_vposed), "smil_lbs_backward: pose blend shapes need v_posed and d_vposed");
-    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(1024), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
+    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(SKIN_BWD_THREADS), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
                        g->d_joints, v_skin, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
                        m->jreg_cval, g->d_A, V, J, nS_skin, regress);
     SMIL_LAUNCH_CHECK();
@@ -810,8 +828,8 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
                 dbeta_frame = g->d_beta;
             }
         }
-        const size_t lds = ((size_t)J * 18 + 16) * sizeof(float);
-        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(1024), lds, stream, g->d_verts, g->d_joints,
+        const size_t lds = ((size_t)J * 18 + (SHAPE_BWD_THREADS / WAVE) * SHAPE_TERMS) * sizeof(float);
+        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(SHAPE_BWD_THREADS), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
                            m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, dbeta_shared, g->d_trans, g->d_del_v, V, J, nBu, regress,
                            in->trans_after_joints ? 1 : 0);

@@ -157,7 +157,10 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // ---------------------------------------------------------------------------------------------
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
+#ifndef SETUP_THREADS
+#define SETUP_THREADS 1024
+#endif
+__global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
                                                       uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
@@ -214,7 +217,11 @@ __global__ void __launch_bounds__(1024) k_raster_setup(const float *__restrict__
                             if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it
                                 const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
                                 const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
+#ifdef SETUP_NO_COUNT  // timing experiment only: how much of the setup kernel is the LDS atomics
+                                if (f == 0) atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
+#else
                                 atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
+#endif
                             } else {
                                 atomicOr(&tcnt[t >> 5], 1u << (t & 31));
                             }
@@ -878,7 +885,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const uint32_t pk = (uint32_t)__shfl((int)pk_rank.x, max(r, 0), WAVE), pk2 = (uint32_t)__shfl((int)pk_rank.y, max(r, 0), WAVE);
                     const int fs = (int)((pk >> 13) & (DCHUNK - 1));
                     const uint32_t rr = (uint32_t)(q0 + lane) - (pk & 0x1FFFu);
-                    const uint32_t dy = __umul24(rr, pk2 & 0x1FFFFu) >> 16;
+                    // rr < 64 and the reciprocal has 17 bits: a 24-bit multiply (full rate) is exact.  Spelled in assembly because
+                    // hipcc widens __umul24 here to the quarter-rate v_mul_lo_u32 (it cannot see the range of rr)
+                    uint32_t rr_inv;
+                    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rr_inv) : "v"(rr), "v"(pk2 & 0x1FFFFu));
+                    const uint32_t dy = rr_inv >> 16;
                     const int p = (int)((__umul24(dy, (pk2 >> 17) & 7u) + rr + (pk2 >> 20)) & 63u);
                     const float2 pc = lds.pixt[p];
                     const float4 pt = make_float4(pc.x, pc.y, pc.x - cx, pc.y - cy);
@@ -1296,7 +1307,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
     const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(1024), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
+    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
                        fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst);
     SMIL_LAUNCH_CHECK();
     {

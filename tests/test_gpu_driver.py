@@ -147,6 +147,45 @@ def test_bench_launches_its_own_ranks_and_shards_like_one_rank():
     assert abs(two["final_loss"] - one["final_loss"]) <= 2e-4 * abs(one["final_loss"]), (two["final_loss"], one["final_loss"])
 
 
+_RCCL_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(sys.argv[1]), rank=0, world_size=1, device_id=dev)
+from smilify_amd import optimize
+shared = {"betas": torch.arange(5.0, device=dev), "fov": torch.full((1,), 3.0, device=dev)}
+objs = torch.arange(10.0, device=dev)
+want = {k: v.clone() for k, v in shared.items()}
+optimize.allreduce_shared(shared, objs)                  # device tensors through RCCL, as bench.py --gpus N does
+assert all(torch.equal(shared[k], want[k]) for k in shared) and torch.equal(objs, torch.arange(10.0, device=dev))
+mine = torch.stack([torch.ones(168, device=dev), 2 * torch.ones(168, device=dev)])
+got = [torch.empty_like(mine)]
+dist.all_gather(got, mine)                               # the halo exchange's collective
+assert torch.equal(got[0], mine)
+t = torch.tensor([1.5], device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # the bench's max-over-ranks clock
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_collectives_of_the_sharded_path_run_on_device_tensors():
+    """The box has one GPU, so RCCL is exercised with a one-rank group: backend "nccl" initialises, and the fused
+    all-reduce, the halo all-gather, the MAX reduce and the barrier of the multi-GPU path accept this build's device
+    tensors (the N > 1 arithmetic is covered by the gloo tests)."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    out = subprocess.run([sys.executable, "-c", _RCCL_PROBE, "29631"], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_two_stage_schedule_follows_the_reference_trajectory(use_graph, tables):
     """optimize.optimize (one hipGraph per stage, or eager) against the reference's loop restated on the oracle

@@ -29,7 +29,7 @@ out_path = os.path.join(REPO, "profiles", f"{rnd}_traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 entry = {"source": f"rocprofv3 --pmc, separate passes (tools/pmc_traffic.sh {tag}); kernel k_raster_dense<2>, mean over {len(acc.get('FETCH_SIZE', []))} dispatches",
          "images_per_launch": n_img, "FETCH_SIZE_KB": mean.get("FETCH_SIZE"), "WRITE_SIZE_KB": mean.get("WRITE_SIZE"), "fetch_correction": 2.0,
-         "fetch_correction_note": "assumed (documented for 16 B/lane streams; these sweeps load 4 B/lane)",
+         "fetch_correction_note": "calibrated for 4 B/lane coalesced reads: profiles/r2_fetch_calib.txt (tools/dbg/fetch_calib.hip)",
          "sq": {k: v for k, v in mean.items() if k.startswith("SQ_")}, "vgpr": mean.get("_vgpr"), "lds_bytes": mean.get("_lds"), "grid": mean.get("_grid")}
 data[tag] = entry
 os.makedirs(os.path.dirname(out_path), exist_ok=True)

@@ -229,8 +229,12 @@ def main():
         ms = 1000.0 * dt / args.steps
         per_view, per_frame = algorithmic_bytes(tables.V, tables.J, S, views)
         n_img = frames * views
+        # batches above 16 384 images are rendered in several launches per iteration (engine.MAX_IMAGES_PER_LAUNCH): the roofline
+        # figures are per launch, i.e. per slice of images
+        launches_per_step = max(1, round(kern_n / max(args.steps, 1)))
         kern_avg_ms = kern_ms / max(kern_n, 1)
-        achieved = (n_img * per_view) / (kern_avg_ms * 1e-3) / 1e9 if kern_n else 0.0
+        img_per_launch = n_img / launches_per_step
+        achieved = (img_per_launch * per_view) / (kern_avg_ms * 1e-3) / 1e9 if kern_n else 0.0
         iter_bytes = frames * (per_frame + views * per_view)
         # HBM bytes of one tile-kernel launch from the PMC passes committed under profiles/ (offline data of this round:
         # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 passes, so they cannot be read inside this run); used only
@@ -242,7 +246,7 @@ def main():
             if tj and tj["images_per_launch"] == n_img:
                 traffic = (tj["FETCH_SIZE_KB"] * tj["fetch_correction"] + tj["WRITE_SIZE_KB"]) * 1024.0
                 traffic_src = f"offline PMC passes (FETCH_SIZE x{tj['fetch_correction']:g} + WRITE_SIZE per launch), profiles/{TRAFFIC_FILE}"
-        alg_launch = n_img * per_view
+        alg_launch = img_per_launch * per_view
         out = {
             "metric": "SMIL fit frame-iters/sec (LBS+render+loss), whole job",
             "value": world * frames / (dt / args.steps),
@@ -269,6 +273,7 @@ def main():
                          "traffic_achieved": (traffic / (kern_avg_ms * 1e-3) / 1e9) if (traffic and kern_n) else None,
                          "traffic_frac": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_n) else None,
                          "algorithmic_bytes_per_launch": alg_launch, "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
+                         "launches_per_step": launches_per_step, "images_per_launch": img_per_launch,
                          "algorithmic_bytes_per_image": per_view,
                          "iteration_frac": (iter_bytes / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
                          "note": "achieved = algorithmic bytes (SURVEY.md 8(d): 36V + 20S^2 + 28J + 56 per image) / tile-kernel time from HIP "

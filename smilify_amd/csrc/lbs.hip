@@ -68,10 +68,10 @@ __global__ void k_shape_blend(const float *__restrict__ vt, const float *__restr
                               const float *__restrict__ beta, const float *__restrict__ del_v,
                               float *__restrict__ v_shaped, int V3, int nB_used, int beta_stride) {
     __shared__ float sbeta[SMIL_MAX_BETAS];
-    const int s = blockIdx.y;
+    const int s = blockIdx.x;
     if (threadIdx.x < nB_used) sbeta[threadIdx.x] = beta[(size_t)s * beta_stride + threadIdx.x];
     __syncthreads();
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;
     if (e >= V3) return;
     float acc = 0.f;
     for (int k = 0; k < nB_used; ++k) acc += sbeta[k] * sd[(size_t)k * V3 + e];
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) k_pose_blend_fwd(const float *__restrict_
                                                         int J, int V3, int nS) {
     extern __shared__ float sfeat[];  // (PB_FRAMES, 9(J-1))
     const int K9 = 9 * (J - 1);
-    const int b0 = blockIdx.y * PB_FRAMES;
+    const int b0 = blockIdx.x * PB_FRAMES;
     for (int i = threadIdx.x; i < PB_FRAMES * K9; i += blockDim.x) {
         const int fb = i / K9, k = i - fb * K9;
         const int b = b0 + fb;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_pose_blend_fwd(const float *__restrict_
         sfeat[i] = v;
     }
     __syncthreads();
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;
     if (e >= V3) return;
     float acc[PB_FRAMES];
 #pragma unroll
@@ -237,11 +237,11 @@ __global__ void __launch_bounds__(256) k_pose_blend_fwd(const float *__restrict_
     }
 }
 
-// d_feat[b][k] = sum_e posedirs[k][e] d_vposed[b][e]; grid (ceil(K9/8), B)
+// d_feat[b][k] = sum_e posedirs[k][e] d_vposed[b][e]; grid (B, ceil(K9/8))
 __global__ void __launch_bounds__(256) k_pose_blend_bwd(const float *__restrict__ pd, const float *__restrict__ d_vposed,
                                                         float *__restrict__ d_feat, int K9, int V3) {
     __shared__ float red[16];
-    const int b = blockIdx.y, k0 = blockIdx.x * 8;
+    const int b = blockIdx.x, k0 = blockIdx.y * 8;
     float acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
@@ -267,12 +267,12 @@ __global__ void __launch_bounds__(256) k_vposed_bwd(const float *__restrict__ d_
                                                     float *__restrict__ d_vposed, int V, int J, int regress) {
     extern __shared__ float smem[];
     float *sA = smem, *sDJ = smem + J * 12;
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;
     const bool reg = regress && d_joints;
     for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = A[(size_t)b * J * 12 + i];
     for (int i = threadIdx.x; i < J * 3; i += blockDim.x) sDJ[i] = reg ? d_joints[(size_t)b * J * 3 + i] : 0.f;
     __syncthreads();
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y * blockDim.x + threadIdx.x;
     if (v >= V) return;
     float dv[3];
     vertex_upstream(d_verts ? d_verts + (size_t)b * V * 3 : nullptr, sDJ, colptr, row, cval, v, reg, dv);
@@ -292,18 +292,18 @@ __global__ void __launch_bounds__(256) k_vposed_bwd(const float *__restrict__ d_
 
 // ---------------------------------------------------------------------------------------------
 // skinning: verts = (sum_k w_k A_k) [v;1] + trans                               (smal_torch.py:320-340)
-// grid (ceil(V/256), B); the frame's J transforms are staged in LDS.
+// grid (B, ceil(V/256)); the frame's J transforms are staged in LDS.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_skin_fwd(const float *__restrict__ A, const float *__restrict__ v_posed,
                                                   const uint32_t *__restrict__ skin_idx,
                                                   const float4 *__restrict__ skin_w, const float *__restrict__ trans,
                                                   float *__restrict__ verts, int V, int J, int nS) {
     extern __shared__ float sA[];
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;
     const float *Ab = A + (size_t)b * J * 12;
     for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = Ab[i];
     __syncthreads();
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y * blockDim.x + threadIdx.x;
     if (v >= V) return;
     const uint32_t ids = skin_idx[v];
     const float4 w4 = skin_w[v];
@@ -366,7 +366,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
     const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
     const float *vt = in->v_template ? in->v_template : m->v_template;
     {
-        dim3 grid(ceil_div(3 * V, 256), nS);
+        dim3 grid(nS, ceil_div(3 * V, 256));  // batch on x: gridDim.y stops at 65 535
         hipLaunchKernelGGL(k_shape_blend, grid, dim3(256), 0, stream, vt, m->shapedirs, in->beta, in->del_v,
                            out->v_shaped, 3 * V, in->nB_used, in->shared_beta ? 0 : in->nB_used);
         SMIL_LAUNCH_CHECK();
@@ -395,7 +395,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
     int nS_skin = nS;
     if (m->posedirs) {
         SMIL_REQUIRE(out->v_posed && out->Rs, "smil_lbs_forward: this model has pose blend shapes: v_posed and Rs outputs required");
-        dim3 grid(ceil_div(3 * V, 256), ceil_div(B, PB_FRAMES));
+        dim3 grid(ceil_div(B, PB_FRAMES), ceil_div(3 * V, 256));
         hipLaunchKernelGGL(k_pose_blend_fwd, grid, dim3(256), (size_t)PB_FRAMES * 9 * (J - 1) * sizeof(float), stream, out->Rs,
                            m->posedirs, out->v_shaped, out->v_posed, B, J, 3 * V, nS);
         SMIL_LAUNCH_CHECK();
@@ -403,7 +403,7 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
         nS_skin = B;
     }
     {
-        dim3 grid(ceil_div(V, 256), B);
+        dim3 grid(B, ceil_div(V, 256));
         hipLaunchKernelGGL(k_skin_fwd, grid, dim3(256), (size_t)J * 12 * sizeof(float), stream, out->A, v_skin,
                            m->skin_idx, m->skin_w, in->trans, out->verts, V, J, nS_skin);
         SMIL_LAUNCH_CHECK();
@@ -774,12 +774,12 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         // gradient through v_posed -> vec(Rs[1:] - I): d_vposed, then the transposed product with posedirs;
         // the (B,9(J-1)) result lives in the d_Rs scratch behind the per-frame scale / translation gradients
         const int K9 = 9 * (J - 1);
-        dim3 gridv(ceil_div(V, 256), B);
+        dim3 gridv(B, ceil_div(V, 256));
         hipLaunchKernelGGL(k_vposed_bwd, gridv, dim3(256), (size_t)J * 15 * sizeof(float), stream, g->d_verts, g->d_joints, sv->A,
                            m->skin_idx, m->skin_w, m->jreg_colptr, m->jreg_row, m->jreg_cval, g->d_vposed, V, J, regress);
         SMIL_LAUNCH_CHECK();
         SMIL_REQUIRE(g->d_posefeat, "smil_lbs_backward: pose blend shapes need the d_posefeat scratch");
-        dim3 gridf(ceil_div(K9, 8), B);
+        dim3 gridf(B, ceil_div(K9, 8));
         hipLaunchKernelGGL(k_pose_blend_bwd, gridf, dim3(256), 0, stream, m->posedirs, g->d_vposed, g->d_posefeat, K9, 3 * V);
         SMIL_LAUNCH_CHECK();
         d_posefeat = g->d_posefeat;

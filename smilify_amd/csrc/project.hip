@@ -57,14 +57,14 @@ __device__ __forceinline__ void project_point(const SmilCameras &c, const CamPar
     }
 }
 
-// grid (blocks of set 0 + blocks of set 1, N)
+// grid (N, blocks of set 0 + blocks of set 1)
 __global__ void __launch_bounds__(256) k_project(SmilCameras c, ProjectSet s0, ProjectSet s1) {
-    const int n = blockIdx.y;
+    const int n = blockIdx.x;  // image on x: gridDim.y stops at 65 535
     const int b = n / c.views;
     const CamParams cp = load_camera(c, n);
-    const bool second = (int)blockIdx.x >= s0.blocks;
+    const bool second = (int)blockIdx.y >= s0.blocks;
     const ProjectSet &s = second ? s1 : s0;
-    const int p = ((int)blockIdx.x - (second ? s0.blocks : 0)) * blockDim.x + threadIdx.x;
+    const int p = ((int)blockIdx.y - (second ? s0.blocks : 0)) * blockDim.x + threadIdx.x;
     if (p < s.P) project_point(c, cp, s, b, n, p);
 }
 
@@ -81,7 +81,7 @@ extern "C" int smil_project(const SmilCameras *cam, const float *pts, int32_t P,
     if (int rc = check_cameras(cam, "smil_project")) return rc;
     SMIL_REQUIRE(pts && P > 0, "smil_project: bad points argument (P=%d)", P);
     const ProjectSet s0 = {pts, ndc, yx, P, ceil_div(P, 256)}, none = {nullptr, nullptr, nullptr, 0, 0};
-    hipLaunchKernelGGL(k_project, dim3(s0.blocks, cam->N), dim3(256), 0, (hipStream_t)stream, *cam, s0, none);
+    hipLaunchKernelGGL(k_project, dim3(cam->N, s0.blocks), dim3(256), 0, (hipStream_t)stream, *cam, s0, none);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -91,7 +91,7 @@ extern "C" int smil_project2(const SmilCameras *cam, const float *pts_a, int32_t
     if (int rc = check_cameras(cam, "smil_project2")) return rc;
     SMIL_REQUIRE(pts_a && Pa > 0 && pts_b && Pb > 0, "smil_project2: bad points arguments (Pa=%d Pb=%d)", Pa, Pb);
     const ProjectSet s0 = {pts_a, ndc_a, yx_a, Pa, ceil_div(Pa, 256)}, s1 = {pts_b, ndc_b, yx_b, Pb, ceil_div(Pb, 256)};
-    hipLaunchKernelGGL(k_project, dim3(s0.blocks + s1.blocks, cam->N), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1);
+    hipLaunchKernelGGL(k_project, dim3(cam->N, s0.blocks + s1.blocks), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -102,15 +102,15 @@ struct ProjectBwdSet {
     int P, blocks, accumulate;
 };
 
-// grid (blocks of set 0 + blocks of set 1, frames): each thread owns one world point and walks the views of its frame, so
+// grid (frames, blocks of set 0 + blocks of set 1): each thread owns one world point and walks the views of its frame, so
 // d_pts needs no atomics; the per-image fov term is block-reduced and added once per block.
 __global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, ProjectBwdSet s0, ProjectBwdSet s1, float *__restrict__ d_fov_img) {
     __shared__ float red[16];
-    const int b = blockIdx.y;
-    const bool second = (int)blockIdx.x >= s0.blocks;
+    const int b = blockIdx.x;
+    const bool second = (int)blockIdx.y >= s0.blocks;
     const ProjectBwdSet &s = second ? s1 : s0;
     const int P = s.P;
-    const int p = ((int)blockIdx.x - (second ? s0.blocks : 0)) * blockDim.x + threadIdx.x;
+    const int p = ((int)blockIdx.y - (second ? s0.blocks : 0)) * blockDim.x + threadIdx.x;
     const bool live = p < P;
     float x = 0.f, y = 0.f, z = 0.f;
     if (live) {
@@ -161,7 +161,7 @@ extern "C" int smil_project_backward(const SmilCameras *cam, const float *pts, i
     SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && P > 0, "smil_project_backward: bad sizes");
     SMIL_REQUIRE(d_ndc || d_yx, "smil_project_backward: no upstream gradient");
     const ProjectBwdSet s0 = {pts, d_ndc, d_yx, d_pts, P, ceil_div(P, 256), accumulate}, none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    hipLaunchKernelGGL(k_project_bwd, dim3(s0.blocks, cam->N / cam->views), dim3(256), 0, (hipStream_t)stream, *cam, s0, none, d_fov_img);
+    hipLaunchKernelGGL(k_project_bwd, dim3(cam->N / cam->views, s0.blocks), dim3(256), 0, (hipStream_t)stream, *cam, s0, none, d_fov_img);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -173,7 +173,7 @@ extern "C" int smil_project_backward2(const SmilCameras *cam, const float *pts_a
     SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && Pa > 0 && Pb > 0, "smil_project_backward2: bad sizes");
     SMIL_REQUIRE((d_ndc_a || d_yx_a) && (d_ndc_b || d_yx_b), "smil_project_backward2: no upstream gradient");
     const ProjectBwdSet s0 = {pts_a, d_ndc_a, d_yx_a, d_pts_a, Pa, ceil_div(Pa, 256), 0}, s1 = {pts_b, d_ndc_b, d_yx_b, d_pts_b, Pb, ceil_div(Pb, 256), 0};
-    hipLaunchKernelGGL(k_project_bwd, dim3(s0.blocks + s1.blocks, cam->N / cam->views), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1, d_fov_img);
+    hipLaunchKernelGGL(k_project_bwd, dim3(cam->N / cam->views, s0.blocks + s1.blocks), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1, d_fov_img);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }

@@ -146,6 +146,7 @@ struct RasterArgs {
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
     int stop_after;          // RASTER_EXPERIMENT builds: ablation (0 list, 1 + staging, 2 + pair sweep, 3 + blend / select; else all)
+    int force_split;         // RASTER_EXPERIMENT builds: >= 0 overrides the pieces a tile is dealt out in (log2)
 };
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
@@ -523,19 +524,18 @@ __device__ __forceinline__ void sort_list_near_to_far(const float2 *__restrict__
 // forms (rows 1-3 of the record) and the pixel ROWS the face's blurred box covers inside the open part of the tile; the
 // HIGH lane the bounding box (row 0), the edge data (rows 4-7) and the pixel COLUMNS; the columns then cross over (one
 // ds_bpermute each) and the low lane leaves with the face's pair count `cf` and the word pairs decode their pixel from.
-// Both lanes load the same nine vertex floats (one transaction).  Pixel index i (flipped axis) has centre -1 + (2i+1)/S:
+// Both lanes load the same nine vertex floats (one transaction); the face's vertex indices (i0, i1, i2) come from the
+// caller, which fetched them while the previous chunk was being evaluated.  Pixel index i (flipped axis) has centre -1 + (2i+1)/S:
 // centres inside [lo, hi] are ceil(v_lo) .. floor(v_hi) with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding
 // (a superset; eval_pair applies the exact test).
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
-__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const uint32_t *list, int c0, int m,
+__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
                                             int oy0, int oy1, int &cf, int &packed2) {
     const int slot = lane & (DCHUNK - 1);
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
     if (slot < m) {
-        const int f = (int)list[c0 + slot];
-        const int i0 = a.faces[3 * f], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
         const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
         const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
         const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
@@ -731,7 +731,12 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         for (int c = 0; c < N_CLASSES; ++c) n_items_all += a.ctr->n_class[q][c];
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
     // the launch finishes in a fraction of one tile's serial time.
-    const unsigned int split_log = n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u));
+#ifdef RASTER_EXPERIMENT
+    const unsigned int split_log = a.force_split >= 0 ? (unsigned int)a.force_split :
+#else
+    const unsigned int split_log =
+#endif
+        n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u));
     // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
     // near to far).
     const unsigned int split0_log = SPLIT0_LOG;
@@ -817,6 +822,14 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             unsigned long long open_px = __ballot(in_img && mine);
             int ox0 = sx0, ox1 = sx1, oy0 = sy0, oy1 = sy1;  // bounding box of the open pixels
             int chunks_done = 0;
+            // The staging loads form a chain list entry -> vertex indices -> vertex coordinates.  The first two links are
+            // fetched ahead: while chunk k is evaluated the indices of chunk k + 1 and the list entries of chunk k + 2 are in
+            // flight (four registers), so a chunk starts with one memory round trip instead of three.
+            const int slot_ = lane & (DCHUNK - 1);
+            auto list_at = [&](int c) { return (int)lst[min(c + slot_, list_total - 1)]; };
+            int f_nx = list_at(DCHUNK);
+            int ia, ib, ic;
+            { const int f_ = list_at(0); ia = a.faces[3 * f_]; ib = a.faces[3 * f_ + 1]; ic = a.faces[3 * f_ + 2]; }
             for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
                 if (may_truncate) {
                     // digit of this chunk's first face = number of buckets that start at or before it, minus one
@@ -841,7 +854,10 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 }
                 const int m = min(DCHUNK, list_total - c0);
                 int cf, packed2, packed = 0;
-                stage_faces(a, vn, lst, c0, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, cf, packed2);
+                const int i0 = ia, i1 = ib, i2 = ic;
+                ia = a.faces[3 * f_nx]; ib = a.faces[3 * f_nx + 1]; ic = a.faces[3 * f_nx + 2];  // chunk c0 + DCHUNK
+                f_nx = list_at(c0 + 2 * DCHUNK);
+                stage_faces(a, vn, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, cf, packed2);
                 if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
@@ -1216,7 +1232,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             if (qy != 0) atomicAdd(&dn[2 * vi[k] + 1], (float)qy * fx_inv);
                         }
                     }
-                    __syncthreads();
+                    lds_fence();  // the accumulators are read before the next group clears them; unlike __syncthreads() this does
+                                  // not wait for the flush's global atomics to be acknowledged (a microsecond per group)
                 }
             }
             __syncthreads();
@@ -1334,8 +1351,10 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;
     a.stop_after = 99;
+    a.force_split = -1;
 #ifdef RASTER_EXPERIMENT
     if (const char *e = getenv("SMIL_STOP")) a.stop_after = atoi(e);
+    if (const char *e = getenv("SMIL_SPLIT")) a.force_split = atoi(e);
     {
         uint32_t mask = 0xFFFFFFFFu;
         if (const char *e = getenv("SMIL_WRAP")) mask = (uint32_t)strtoul(e, nullptr, 0);

@@ -190,3 +190,32 @@ def test_renderer_topology_cache_is_keyed_by_content(tables):
     assert rend._device_model(other.clone().to(torch.int32), t.V) is dm_other and len(rend._topologies) == 1
     sil_b, _ = rend(verts, joints, other)
     assert (sil_a - sil_b).abs().max() > 1e-3
+
+
+def test_batches_beyond_65535_frames_and_images(tables):
+    """gridDim.y stops at 65 535; BASELINE config 5 holds 147 456 images per GPU and the whole 65 536-frame sequence may sit
+    on one GPU.  Projection and LBS with 70 000 rows: first and last rows equal the same rows computed in a small batch."""
+    from smilify_amd import engine as eng
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    B = 70000
+    g = torch.Generator().manual_seed(3)
+    theta = (0.2 * torch.randn(B, t.J, 3, generator=g)).to(DEV)
+    trans = (0.05 * torch.randn(B, 3, generator=g)).to(DEV)
+    beta = torch.zeros(t.nB, device=DEV)
+    big = eng.lbs_forward(dm, beta, theta, trans=trans, shared_beta=True, trans_after_joints=True)
+    sel = torch.tensor([0, 1, 65535, 65536, B - 1], device=DEV)
+    small = eng.lbs_forward(dm, beta, theta[sel].contiguous(), trans=trans[sel].contiguous(), shared_beta=True, trans_after_joints=True)
+    assert torch.equal(big["verts"][sel], small["verts"]) and torch.equal(big["joints"][sel], small["joints"])
+    R = torch.eye(3, device=DEV)[None].contiguous()
+    R[0, 0, 0] = R[0, 2, 2] = -1.0
+    T = torch.tensor([[0.0, 0.0, 2.7]], device=DEV)
+    cams = eng.CameraSet(R, T, torch.full((1,), 60.0, device=DEV), None, 1, 64)
+    ndc, yx = eng.project(cams, big["joints"])
+    ndc_s, yx_s = eng.project(cams, small["joints"])
+    assert torch.equal(ndc[sel], ndc_s) and torch.equal(yx[sel], yx_s)
+    w = torch.ones_like(yx)
+    d_pts, d_fov_img = eng.project_backward(cams, big["joints"], d_yx=w)
+    d_pts_s, _ = eng.project_backward(cams, small["joints"], d_yx=torch.ones_like(yx_s))
+    assert torch.equal(d_pts[sel], d_pts_s) and d_fov_img.shape[0] == B

@@ -76,7 +76,7 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #ifdef DBG_TIMERS
 #define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0;
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
-#define STAT(k, v) { if (a.dbg && lane == 0) atomicAdd(&a.dbg[k], (unsigned long long)(v)); }
+#define STAT(k, v) { const unsigned long long v_ = (unsigned long long)(v); /* (all lanes: v may hold a ballot) */ if (a.dbg && lane == 0) atomicAdd(&a.dbg[k], v_); }
 #define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
         atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); \
         atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); }
@@ -913,6 +913,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     PairEval e;
                     eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
                     const bool cand = valid && e.cand && ((open_px >> p) & 1ull);
+                    STAT(31, __popcll(__ballot(valid && !((open_px >> p) & 1ull))))  // pairs on closed pixels (slot 31: printed as 'closed')
                     const unsigned long long cm = __ballot(cand);
                     if (cm == 0ull) continue;
                     // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
@@ -1375,6 +1376,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
                 (double)h[16], (double)h[17], (double)h[18], (double)h[19]);
         fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e; chunks walked %.4e of %.4e, pixels still open at the end %.4e\n",
                 (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25], (double)h[28], (double)h[29], (double)h[30]);
+        fprintf(stderr, "[dbg stats] evaluated pairs whose pixel was already closed %.4e\n", (double)h[31]);
         (void)hipMemset(dbg_dev, 0, 256);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;

@@ -113,6 +113,8 @@ struct RasterCounters {
     struct { unsigned int next, pad[15]; } deal[N_PARTS];  // one cache line per partition's cursor
 };
 
+struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
+
 struct RasterArgs {
     const float *verts_ndc;  // (N,V,3)
     const int *faces;        // (F,3)
@@ -137,12 +139,12 @@ struct RasterArgs {
     uint32_t *slist2;        // ... and the same ids ordered near to far by the first radix digit of their nearest vertex depth
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
-    uint32_t *sz;            // depth bits
-    uint32_t *smeta;         // pixel | list position << 6 | inside << 22 | closest edge << 23
-    float *ssd;              // signed squared distance to the closest edge (pass 3 recomputes the closest point itself)
-    // records that survive the first selection digit: key (depth bits - tile minimum), meta, log2 of the blend factor
-    uint32_t *ckey, *cmeta;
-    float *clf;
+    // pair records, 12 bytes each in ONE stream per workgroup (an append or a sweep step then touches one contiguous run of
+    // memory instead of three): {depth bits, pixel | list position << 6 | inside << 22 | closest edge << 23, signed squared
+    // distance to the closest edge (pass 3 recomputes the closest point itself)}
+    Rec3 *srec;
+    // records that survive the first selection digit: {key = depth bits - tile minimum, meta, log2 of the blend factor}
+    Rec3 *crec;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
     int stop_after;          // RASTER_EXPERIMENT builds: ablation (0 list, 1 + staging, 2 + pair sweep, 3 + blend / select; else all)
@@ -531,7 +533,7 @@ __device__ __forceinline__ void sort_list_near_to_far(const float2 *__restrict__
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
-                                            int oy0, int oy1, int &cf, int &packed2) {
+                                            int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2) {
     const int slot = lane & (DCHUNK - 1);
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
@@ -570,9 +572,27 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             b1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
         }
     }
-    const int bx0 = __shfl(b0, slot + DCHUNK, WAVE), bx1 = __shfl(b1, slot + DCHUNK, WAVE);  // (all lanes: no divergent ds_bpermute)
+    int bx0 = __shfl(b0, slot + DCHUNK, WAVE), bx1 = __shfl(b1, slot + DCHUNK, WAVE);  // (all lanes: no divergent ds_bpermute)
     cf = 0;
     packed2 = 0;
+    if (!hi && slot < m && bx0 <= bx1 && b0 <= b1) {
+        // shrink the box to the open pixels inside it (bit 8 * row + column of `open_px`): between two closing steps the
+        // open pixels of a tile are often scattered, and their common bounding box (ox0 .. oy1) is then the whole tile
+        const uint32_t colb = ((2u << bx1) - (1u << bx0)) * 0x01010101u;                  // columns bx0 .. bx1 of every row
+        const unsigned long long rows = (b1 >= 7 ? ~0ull : ((1ull << (8 * (b1 + 1))) - 1ull)) & ~((1ull << (8 * b0)) - 1ull);
+        const unsigned long long mbox = open_px & rows & (((unsigned long long)colb << 32) | colb);
+        if (mbox == 0ull) {
+            b1 = b0 - 1;
+        } else {
+            b0 = (int)(__builtin_ctzll(mbox) >> 3);
+            b1 = (int)((63 - __builtin_clzll(mbox)) >> 3);
+            uint32_t c8 = (uint32_t)mbox | (uint32_t)(mbox >> 32);
+            c8 |= c8 >> 16;
+            c8 = (c8 | (c8 >> 8)) & 0xFFu;
+            bx0 = (int)__builtin_ctz(c8);
+            bx1 = 31 - (int)__builtin_clz(c8);
+        }
+    }
     if (!hi && slot < m && bx0 <= bx1 && b0 <= b1) {
         const int bw = bx1 - bx0 + 1;
         cf = bw * (b1 - b0 + 1);
@@ -613,7 +633,7 @@ __device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b,
 // One radix-select sweep over `n_rec` (key, meta) pairs: among the keys of pixel p whose bits above `nbits` equal
 // psel[p].x, histogram the next `b` bits (psel[p].y == 0: pixel not taking part; key 0xFFFFFFFF: record not taking part).
 template <typename KeyFn>
-__device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__restrict__ meta, int n_rec, int nbits, int b,
+__device__ __forceinline__ void select_sweep(DenseLds &lds, const Rec3 *__restrict__ crec, int n_rec, int nbits, int b,
                                              int lane, uint32_t pre, int need, KeyFn key_of) {
     const int shift = nbits - b;
     lds.psel[lane] = make_uint2(pre, (uint32_t)need);
@@ -623,7 +643,7 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
 #pragma unroll
         for (int u = 0; u < KGROUP; ++u) {
             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_rec - 1);  // unsigned 32-bit: SGPR base + VGPR offset addressing
-            mt[u] = at(meta, idx);
+            mt[u] = at(crec, idx).b;
             kk[u] = key_of(idx, mt[u]);
         }
     };
@@ -661,7 +681,7 @@ __device__ __forceinline__ void select_sweep(DenseLds &lds, const uint32_t *__re
 //   above     -> dropped.
 // Returns the number of records left.  Every later sweep thus reads only the records that are still undecided (a tenth per
 // digit) instead of the whole compact stream, and the final pass only sees the last bucket.
-__device__ __forceinline__ int refine_sweep(DenseLds &lds, uint32_t *ckey, uint32_t *cmeta, float *clf, int n_rec, int nbits, int b,
+__device__ __forceinline__ int refine_sweep(DenseLds &lds, Rec3 *crec, int n_rec, int nbits, int b,
                                             int lane, uint32_t pre, int need) {
     const int shift = nbits - b;
     lds.psel[lane] = make_uint2(pre, (uint32_t)need);
@@ -673,7 +693,8 @@ __device__ __forceinline__ int refine_sweep(DenseLds &lds, uint32_t *ckey, uint3
 #pragma unroll
         for (int u = 0; u < KGROUP; ++u) {
             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_rec - 1);
-            r[u].kk = at(ckey, idx); r[u].mt = at(cmeta, idx); r[u].lf = at(clf, idx);
+            const Rec3 q = at(crec, idx);
+            r[u].kk = q.a; r[u].mt = q.b; r[u].lf = __uint_as_float(q.c);
         }
     };
     auto sift_recs = [&](const CRec (&r)[KGROUP], int g0) {
@@ -690,7 +711,7 @@ __device__ __forceinline__ int refine_sweep(DenseLds &lds, uint32_t *ckey, uint3
             const unsigned long long sm = __ballot(stay);
             const uint32_t slot = (uint32_t)n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
             if (stay) {
-                at(ckey, slot) = r[u].kk; at(cmeta, slot) = r[u].mt; at(clf, slot) = r[u].lf;
+                at(crec, slot) = Rec3{r[u].kk, r[u].mt, __float_as_uint(r[u].lf)};
                 const uint32_t bucket = (r[u].kk >> shift) & ((1u << b) - 1u);
                 atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
             }
@@ -719,10 +740,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
-    uint32_t *const sz = a.sz + rec0, *const smeta = a.smeta + rec0;
-    float *const ssd = a.ssd + rec0;
-    uint32_t *const ckey = a.ckey + rec0, *const cmeta = a.cmeta + rec0;
-    float *const clf = a.clf + rec0;
+    Rec3 *const srec = a.srec + rec0, *const crec = a.crec + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
@@ -857,7 +875,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 const int i0 = ia, i1 = ib, i2 = ic;
                 ia = a.faces[3 * f_nx]; ib = a.faces[3 * f_nx + 1]; ic = a.faces[3 * f_nx + 2];  // chunk c0 + DCHUNK
                 f_nx = list_at(c0 + 2 * DCHUNK);
-                stage_faces(a, vn, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, cf, packed2);
+                stage_faces(a, vn, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2);
                 if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
@@ -923,9 +941,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const uint32_t zb = __float_as_uint(z);
                     const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (cand) {
-                        st_stream(sz, slot, zb);
-                        st_stream(smeta, slot, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23));
-                        st_stream(ssd, slot, e.sd);
+                        st_stream(srec, slot, Rec3{zb, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23),
+                                                   __float_as_uint(e.sd)});
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
@@ -984,8 +1001,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
                         const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
-                        r[u].z = any_trunc ? ld_stream(sz, idx) : 0u;  // (wave-uniform: depths only matter where a pixel is truncated)
-                        r[u].mt = ld_stream(smeta, idx); r[u].sd = ld_stream(ssd, idx);
+                        const Rec3 q = ld_stream(srec, idx);
+                        r[u].z = q.a; r[u].mt = q.b; r[u].sd = __uint_as_float(q.c);
                     }
                 };
                 auto blend_recs = [&](const Rec (&r)[DGROUP], int g0) {
@@ -1005,9 +1022,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             const unsigned long long km = __ballot(maybe);
                             const uint32_t slot = (uint32_t)n_cmp + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
                             if (maybe) {
-                                at(ckey, slot) = key;
-                                at(cmeta, slot) = r[u].mt;
-                                at(clf, slot) = lf;
+                                at(crec, slot) = Rec3{key, r[u].mt, __float_as_uint(lf)};
                                 const uint32_t bucket = (key >> shift2) & ((1u << b2) - 1u);
                                 atomicAdd(&lds.hist[(bucket >> 1) * WAVE + (r[u].mt & 63u)], (bucket & 1u) ? 0x10000u : 1u);
                             }
@@ -1033,7 +1048,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 }
                 while (nbits > 0 && __ballot(need > 0) != 0ull) {
                     const int b = min(SEL_BITS, nbits);
-                    n_cmp = refine_sweep(lds, ckey, cmeta, clf, n_cmp, nbits, b, lane, pre, need);
+                    n_cmp = refine_sweep(lds, crec, n_cmp, nbits, b, lane, pre, need);
                     pick_digit(lds.hist, lane, b, pre, need, n_eq);
                     nbits -= b;
                     __syncthreads();
@@ -1050,11 +1065,11 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     int pneed = split ? need : 0, peq = 0;
                     auto pos_key = [&](uint32_t idx, uint32_t mt) {
                         // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
-                        return at(ckey, idx) == __float_as_uint(lds.pgrad[mt & 63u].y) ? lst[(mt >> 6) & 0xFFFFu] : 0xFFFFFFFFu;
+                        return at(crec, idx).a == __float_as_uint(lds.pgrad[mt & 63u].y) ? lst[(mt >> 6) & 0xFFFFu] : 0xFFFFFFFFu;
                     };
                     while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
                         const int b = min(SEL_BITS, pbits);
-                        select_sweep(lds, cmeta, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
+                        select_sweep(lds, crec, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
                         pick_digit(lds.hist, lane, b, ppre, pneed, peq);
                         pbits -= b;
                         __syncthreads();
@@ -1071,7 +1086,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
                         const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_cmp - 1);
-                        kk[u] = at(ckey, idx); mt[u] = at(cmeta, idx); lf[u] = at(clf, idx);
+                        const Rec3 q = at(crec, idx);
+                        kk[u] = q.a; mt[u] = q.b; lf[u] = __uint_as_float(q.c);
                     }
 #pragma unroll
                     for (int u = 0; u < DGROUP; ++u) {
@@ -1162,8 +1178,8 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
-                            r[u].z = any_trunc ? ld_stream(sz, idx) : 0u;  // (threshold = +inf bits everywhere otherwise)
-                            r[u].mt = ld_stream(smeta, idx); r[u].sd = ld_stream(ssd, idx);
+                            const Rec3 q = ld_stream(srec, idx);
+                            r[u].z = q.a; r[u].mt = q.b; r[u].sd = __uint_as_float(q.c);
                         }
                     };
                     auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {
@@ -1281,7 +1297,7 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (three record + three compact) words
+// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
 #define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
     return (size_t)grid * (2 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
@@ -1339,13 +1355,9 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
         ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
-        const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(uint32_t);
-        a.sz = (uint32_t *)ws; ws += stream;
-        a.smeta = (uint32_t *)ws; ws += stream;
-        a.ssd = (float *)ws; ws += stream;
-        a.ckey = (uint32_t *)ws; ws += stream;
-        a.cmeta = (uint32_t *)ws; ws += stream;
-        a.clf = (float *)ws;
+        const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3);
+        a.srec = (Rec3 *)ws; ws += stream;
+        a.crec = (Rec3 *)ws;
     }
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;

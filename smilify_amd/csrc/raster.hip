@@ -370,8 +370,13 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
 // ---------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------
-#define GCHUNK 64            // faces whose gradient accumulators are live in pass 3 (a multiple of DCHUNK)
-#define GCOPIES 2            // private copies of those accumulators (measured: 1 -> 2 copies -3 %, 4 copies lose it again to zeroing and flushing)
+#ifndef GCHUNK
+#define GCHUNK 64            // faces whose gradient accumulators are live in pass 3 (a multiple of WAVE)
+#endif
+#ifndef GCOPIES
+#define GCOPIES 2
+#endif
+//      GCOPIES              // private copies of those accumulators (measured: 1 -> 2 copies -3 %, 4 copies lose it again to zeroing and flushing)
 struct alignas(16) DenseLds {
     union {
         float rec[DCHUNK * FSTR];    // pass 1: staged face records
@@ -1159,17 +1164,23 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[min(ch + GR, chunks_done)];
                     if (i_beg == i_end) continue;
                     // vertex ids of this chunk's faces: requested now, used by the flush
-                    const int fch = ch * DCHUNK + lane;
-                    int vi0 = 0, vi1 = 0, vi2 = 0;
+                    // vertex ids of this group's faces (lane = face, GCHUNK / WAVE faces per lane): requested now, used by the flush
+                    constexpr int FPL = GCHUNK / WAVE;
+                    int vi[FPL][3];
                     // ... and their projected vertices, from which a record's edge parameter t is recomputed (4 bytes less
                     // written and read per record than storing it); the table lives where the selection histograms were
                     float2 *const fv = reinterpret_cast<float2 *>(lds.hist);  // [GCHUNK][3]
-                    if (fch < list_total) {
-                        const int f = (int)lst[fch];
-                        vi0 = a.faces[3 * f]; vi1 = a.faces[3 * f + 1]; vi2 = a.faces[3 * f + 2];
-                        fv[lane * 3 + 0] = make_float2(vn[3 * vi0], vn[3 * vi0 + 1]);
-                        fv[lane * 3 + 1] = make_float2(vn[3 * vi1], vn[3 * vi1 + 1]);
-                        fv[lane * 3 + 2] = make_float2(vn[3 * vi2], vn[3 * vi2 + 1]);
+                    static_assert(GCHUNK * 3 * sizeof(float2) <= sizeof(lds.hist), "the vertex table of a group lives in the histogram area");
+#pragma unroll
+                    for (int h = 0; h < FPL; ++h) {
+                        const int fch = ch * DCHUNK + h * WAVE + lane;
+                        vi[h][0] = vi[h][1] = vi[h][2] = 0;
+                        if (fch < list_total) {
+                            const int f = (int)lst[fch];
+                            vi[h][0] = a.faces[3 * f]; vi[h][1] = a.faces[3 * f + 1]; vi[h][2] = a.faces[3 * f + 2];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) fv[(h * WAVE + lane) * 3 + k] = make_float2(vn[3 * vi[h][k]], vn[3 * vi[h][k] + 1]);
+                        }
                     }
                     for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
                     __syncthreads();
@@ -1236,17 +1247,18 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         }
                     }
                     __syncthreads();
-                    if (fch < list_total) {  // flush: sum the copies, unpack, one global atomic per touched vertex component
-                        const int vi[3] = {vi0, vi1, vi2};
+#pragma unroll
+                    for (int h = 0; h < FPL; ++h) {  // flush: sum the copies, unpack, one global atomic per touched vertex component
+                        if (ch * DCHUNK + h * WAVE + lane >= list_total) continue;
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             unsigned long long tot = 0ull;
 #pragma unroll
-                            for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][lane * 3 + k];
+                            for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][(h * WAVE + lane) * 3 + k];
                             const int qy = (int)(uint32_t)tot;
                             const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
-                            if (qx != 0) atomicAdd(&dn[2 * vi[k]], (float)qx * fx_inv);
-                            if (qy != 0) atomicAdd(&dn[2 * vi[k] + 1], (float)qy * fx_inv);
+                            if (qx != 0) atomicAdd(&dn[2 * vi[h][k]], (float)qx * fx_inv);
+                            if (qy != 0) atomicAdd(&dn[2 * vi[h][k] + 1], (float)qy * fx_inv);
                         }
                     }
                     lds_fence();  // the accumulators are read before the next group clears them; unlike __syncthreads() this does

@@ -147,7 +147,8 @@ struct RasterArgs {
     Rec3 *crec;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
-    int stop_after;          // RASTER_EXPERIMENT builds: ablation (0 list, 1 + staging, 2 + pair sweep, 3 + blend / select; else all)
+    int stop_after;          // RASTER_EXPERIMENT builds: ablation (0 list, 1 + staging, 2 + pair sweep, 3 + blend / select, 4 no LDS
+                             // gradient atomics, 5 no global gradient atomics; else all)
     int force_split;         // RASTER_EXPERIMENT builds: >= 0 overrides the pieces a tile is dealt out in (log2)
 };
 
@@ -1257,6 +1258,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][(h * WAVE + lane) * 3 + k];
                             const int qy = (int)(uint32_t)tot;
                             const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
+#ifdef RASTER_EXPERIMENT
+                            if (a.stop_after == 5 && (qx | qy) != 0x12345678) continue;  // ablation: no global gradient atomics
+#endif
                             if (qx != 0) atomicAdd(&dn[2 * vi[h][k]], (float)qx * fx_inv);
                             if (qy != 0) atomicAdd(&dn[2 * vi[h][k] + 1], (float)qy * fx_inv);
                         }

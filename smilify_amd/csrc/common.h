@@ -42,6 +42,7 @@ void smil_set_error(const char *fmt, ...);
 struct SmilModel {
     int V = 0, F = 0, J = 0, nB = 0;
     int max_depth = 0;
+    int max_valence = 0;          // most faces sharing one vertex (bounds the gradient a vertex can receive, raster.hip)
     bool static_joints = false;
     int jreg_nnz = 0;
     int bone_nnz = 0;

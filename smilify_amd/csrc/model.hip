@@ -53,6 +53,11 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
     }
     for (int i = 0; i < 3 * F; ++i)
         SMIL_REQUIRE(d->faces[i] >= 0 && d->faces[i] < V, "smil_model_create: face index %d out of range", d->faces[i]);
+    int max_valence = 0;
+    {
+        std::vector<int> valence(V, 0);
+        for (int i = 0; i < 3 * F; ++i) max_valence = std::max(max_valence, ++valence[d->faces[i]]);
+    }
     const int nnz = d->jreg_rowptr[J];
     SMIL_REQUIRE(nnz >= 0 && (nnz == 0 || (d->jreg_col && d->jreg_val)), "smil_model_create: regressor CSR malformed");
     for (int e = 0; e < nnz; ++e)
@@ -108,6 +113,7 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
     SmilModel *m = new SmilModel();
     m->V = V; m->F = F; m->J = J; m->nB = d->nB;
     m->max_depth = max_depth;
+    m->max_valence = max_valence;
     m->static_joints = d->static_joints != 0;
     m->jreg_nnz = nnz;
     m->bone_nnz = bone_nnz;

@@ -93,6 +93,9 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 // Per partition two arrays of ceil(N / N_PARTS) * tiles entries hold two classes each (one filled from the front, one
 // from the back).
 #define N_CLASSES 4
+#ifndef PACKED_MIN_IMAGES
+#define PACKED_MIN_IMAGES 64  // from this many images per launch the fused entry point packs its gradient atomics (see image_fx_scale)
+#endif
 #ifndef CLASS_T0
 #define CLASS_T0 65536        // class 0 can be dealt out in pieces (SPLIT0_LOG)
 #endif
@@ -132,6 +135,8 @@ struct RasterArgs {
     const float *target;     // FUSED (fp32 targets) ...
     const uint8_t *target_u8; // ... or binary {0,1} targets stored as bytes
     const float *pix_scale;  // FUSED (N,)
+    const float *img_bound;  // (N,) setup kernel: 0.4 x valence x largest face box (pixels), the geometric part of the bound on a vertex's gradient
+    int packed;              // FUSED: d_ndc is accumulated as (x, y) fixed point packed in 64 bits (one memory-side atomic per vertex, not two)
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
     // scratch per resident workgroup
@@ -169,7 +174,10 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
                                                       float z_clip, float *__restrict__ d_ndc_zero, const float *__restrict__ loss_src,
-                                                      float *__restrict__ loss_dst) {
+                                                      float *__restrict__ loss_dst, float *__restrict__ img_bound, int max_valence) {
+    __shared__ uint32_t s_maxpx;  // largest blurred pixel box of a face
+    if (threadIdx.x == 0) s_maxpx = 0u;
+    uint32_t my_px = 0u;
     extern __shared__ uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
     // the fused entry point's per-image initialisation rides along (saves a 100 MB memset and a copy launch per iteration):
@@ -210,6 +218,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
                 xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
                 xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
                 if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
+                    my_px = max(my_px, (uint32_t)((xi_hi - xi_lo + 1) * (yi_hi - yi_lo + 1)));
                     // output column xo = S-1-xi
                     const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
                     const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
@@ -245,7 +254,13 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
         if ((threadIdx.x & (WAVE - 1)) == 0 && grp < n_groups)
             gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
+    // Bound on what one vertex component of this image can receive from pass 3, up to the factor |upstream gradient| /
+    // sqrt(sigma): a kept record of probability p = sigmoid(-+r^2 / sigma) adds at most 2 r p alpha |g| / sigma to an end point,
+    // alpha <= 1 - p, and r p (1 - p) <= 0.197 sqrt(sigma) for every r (maximum of sqrt(u) s(u) (1 - s(u)), u = r^2 / sigma);
+    // a face has at most its blurred pixel box of records; a vertex has at most max_valence faces.
+    if (my_px) atomicMax(&s_maxpx, my_px);
     __syncthreads();
+    if (threadIdx.x == 0 && img_bound) img_bound[n] = 1.02f * 0.4f * (float)max_valence * (float)s_maxpx;
     // touched tiles -> the work list of their cost class
     __shared__ uint32_t s_cnt[N_CLASSES], s_base[N_CLASSES];
     if (threadIdx.x < N_CLASSES) s_cnt[threadIdx.x] = 0u;
@@ -366,6 +381,30 @@ __device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e)
 __device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
     // sigmoid(-dist / sigma) = 1 / (1 + e^{dist/sigma}); v_exp_f32 + v_rcp_f32 (1 ulp each)
     return __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));
+}
+
+// Packed gradient accumulation (fused entry point, large launches).  The flush of pass 3 goes to memory-side atomics (the
+// per-XCD L2s forward every atomic), whose cost is proportional to their number: (x, y) of a vertex travel as two 32-bit
+// fixed-point numbers in ONE 64-bit integer atomic instead of two float atomics.  The scale is a power of two per image,
+// chosen so that no vertex component can overflow: |sum| <= img_bound * |pix_scale| / sqrt(sigma) (see k_raster_setup) maps into
+// [2^29, 2^30].  Integer sums are order independent: the gradient becomes reproducible bit for bit.  k_unpack_dndc turns the
+// buffer into the (N,V,2) floats the interface promises, in place.
+__device__ __forceinline__ float image_fx_scale(float img_bound, float pix_scale, float inv_sigma) {
+    const float bound = img_bound * fabsf(pix_scale) * sqrtf(inv_sigma);
+    return (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_unpack_dndc(float *__restrict__ d_ndc, const float *__restrict__ img_bound,
+                                                     const float *__restrict__ pix_scale, float inv_sigma, int V) {
+    const int n = blockIdx.x, v = blockIdx.y * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float sc = image_fx_scale(img_bound[n], pix_scale[n], inv_sigma);
+    const float inv = sc > 0.f ? 1.0f / sc : 0.f;
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(d_ndc) + (size_t)n * V + v;
+    const unsigned long long tot = *p;
+    const int qy = (int)(uint32_t)tot;
+    const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
+    *reinterpret_cast<float2 *>(p) = make_float2((float)qx * inv, (float)qy * inv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1157,6 +1196,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 const float bound = 2.0f * sqrtf(wave_max(rmax2)) * csum;
                 const float fx_scale = (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
                 const float fx_inv = fx_scale > 0.f ? 1.0f / fx_scale : 0.f;
+                const float img_scale = (MODE == MODE_FUSED && a.packed) ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma) : 0.f;
                 lds.pgrad[lane] = make_float4(active ? coef * fx_scale : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
                 __syncthreads();
                 constexpr int GR = GCHUNK / DCHUNK;
@@ -1261,7 +1301,17 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
 #ifdef RASTER_EXPERIMENT
                             if (a.stop_after == 5 && (qx | qy) != 0x12345678) continue;  // ablation: no global gradient atomics
 #endif
+                            if (MODE == MODE_FUSED && a.packed) {  // wave-uniform
+                                const int ix = __float2int_rn((float)qx * fx_inv * img_scale), iy = __float2int_rn((float)qy * fx_inv * img_scale);
+                                if ((ix | iy) != 0)
+                                    atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[h][k],
+                                              ((unsigned long long)(uint32_t)(ix + (iy >> 31)) << 32) | (unsigned long long)(uint32_t)iy);
+                                continue;
+                            }
                             if (qx != 0) atomicAdd(&dn[2 * vi[h][k]], (float)qx * fx_inv);
+#ifdef RASTER_EXPERIMENT
+                            if (a.stop_after == 6) continue;  // ablation: half of the global gradient atomics
+#endif
                             if (qy != 0) atomicAdd(&dn[2 * vi[h][k] + 1], (float)qy * fx_inv);
                         }
                     }
@@ -1326,7 +1376,8 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
     // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), per-workgroup scratch
     return align256((size_t)N * m->F * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
            align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint32_t)) +
-           align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) + 256 +
+           align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) +
+           align256((size_t)N * sizeof(float)) + 256 +
            scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
 
@@ -1353,12 +1404,14 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += align256((size_t)N * m->F * sizeof(float2));
     uint32_t *gbox = (uint32_t *)ws;
     ws += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
+    float *img_bound = (float *)ws;
+    ws += align256((size_t)N * sizeof(float));
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
     const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
-                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst);
+                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst, img_bound, m->max_valence);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
@@ -1375,7 +1428,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.srec = (Rec3 *)ws; ws += stream;
         a.crec = (Rec3 *)ws;
     }
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr;
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
     a.dbg = nullptr;
@@ -1508,9 +1561,16 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
     if (target_is_u8) a.target_u8 = (const uint8_t *)target; else a.target = (const float *)target;
     a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
+    // large launches accumulate the vertex gradients as packed fixed point (half the memory-side atomics) and decode them in
+    // place afterwards; small ones keep float atomics and save the extra launch
+    a.packed = N >= PACKED_MIN_IMAGES ? 1 : 0;
     PROF_BEGIN(stream);
     launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
+    if (a.packed) {
+        hipLaunchKernelGGL(k_unpack_dndc, dim3(N, ceil_div(m->V, 256)), dim3(256), 0, stream, d_ndc, a.img_bound, pix_scale, a.inv_sigma, m->V);
+        SMIL_LAUNCH_CHECK();
+    }
     return SMIL_OK;
 }

@@ -192,7 +192,10 @@ int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t
  * fitter.py:332-333): loss_img[n] = sum_px |sil - target|, d_ndc (N,V,2) = d(sum_n pix_scale[n] *
  * loss_img[n]) / d ndc.  target_sum[n] = sum_px target (constant, computed once by the caller) lets
  * untouched tiles skip their target read.  target is (N,S,S) fp32, or uint8 holding binary {0,1} masks when
- * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL. */
+ * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL.
+ * From 64 images per call on, d_ndc is accumulated as 64-bit packed fixed point in the same buffer and decoded in place
+ * before the call's work ends on the stream: the caller always sees floats; the sums are then independent of the order in
+ * which tiles finish (bit-reproducible), with an absolute resolution of about 2e-6 of an image's largest component. */
 int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
                              const SmilRasterSettings *rs, const void *target, int32_t target_is_u8,
                              const float *target_sum, const float *pix_scale, float *loss_img, float *d_ndc,

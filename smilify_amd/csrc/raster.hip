@@ -140,8 +140,9 @@ struct RasterArgs {
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
     // scratch per resident workgroup
-    uint32_t *slist;         // F face ids of the current tile (ascending id) ...
-    uint32_t *slist2;        // ... and the same ids ordered near to far by the first radix digit of their nearest vertex depth
+    uint2 *slist;            // the current tile's faces in ascending id: {face id, bits of its nearest vertex depth} ...
+    uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may
+                             // truncate (the sort reads the depths it needs from slist instead of gathering them per face)
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
     // pair records, 12 bytes each in ONE stream per workgroup (an append or a sweep step then touches one contiguous run of
@@ -491,7 +492,7 @@ __device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
     return (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
 }
 
-__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, uint32_t *list, int lane, uint32_t &kmin,
+__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, uint2 *list, int lane, uint32_t &kmin,
                                           uint32_t &kmax) {
     const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.F;
     const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.F;
@@ -521,7 +522,7 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
                 const bool hit = fidx[u] < a.F && box_has(tb[u], tx, ty);
                 const unsigned long long mask = __ballot(hit);
                 if (hit) {
-                    list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)fidx[u];
+                    list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)fidx[u], __float_as_uint(zz[u].x));
                     zlo = fminf(zlo, zz[u].x);
                     zhi = fmaxf(zhi, zz[u].y);
                 }
@@ -546,12 +547,12 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
 // nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
 // Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
 // recovers through `out`.  bstart[d] = first position of bucket d, bstart[2^b1] = n.
-__device__ __forceinline__ void sort_list_near_to_far(const float2 *__restrict__ fzr_n, const uint32_t *list, uint32_t *out, int n,
-                                                      uint32_t kmin, int shift1, int b1, DenseLds &lds, int lane) {
+__device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
+                                                      DenseLds &lds, int lane) {
     const int n_buckets = 1 << b1;
     lds.start[lane] = 0;
     __syncthreads();
-    auto digit_of = [&](uint32_t f) { return (int)(((__float_as_uint(fzr_n[f].x) - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
+    auto digit_of = [&](uint2 e) { return (int)(((e.y - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
     for (int i = lane; i < n; i += WAVE) atomicAdd(&lds.start[digit_of(list[i])], 1);
     __syncthreads();
     const int c = lane < n_buckets ? lds.start[lane] : 0;
@@ -561,8 +562,8 @@ __device__ __forceinline__ void sort_list_near_to_far(const float2 *__restrict__
     lds.start[lane] = incl - c;  // running cursor of every bucket
     __syncthreads();
     for (int i = lane; i < n; i += WAVE) {
-        const uint32_t f = list[i];
-        out[atomicAdd(&lds.start[digit_of(f)], 1)] = f;
+        const uint2 e = list[i];
+        out[atomicAdd(&lds.start[digit_of(e)], 1)] = e.x;
     }
     __syncthreads();
 }
@@ -781,7 +782,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
     const int lane = threadIdx.x;
-    uint32_t *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
+    uint2 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
@@ -851,10 +852,12 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         const int b1 = min(SEL_BITS, nbits0), shift1 = nbits0 - b1;
         __syncthreads();  // the list stores are visible to the loads below
         // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
-        const uint32_t *lst = slist;
+        const uint32_t *const lst = slist2;
         if (may_truncate) {
-            sort_list_near_to_far(a.fzr + (size_t)n * a.F, slist, slist2, list_total, kmin, shift1, b1, lds, lane);
-            lst = slist2;
+            sort_list_near_to_far(slist, slist2, list_total, kmin, shift1, b1, lds, lane);
+        } else {  // at most K faces: the id order is kept
+            for (int i = lane; i < list_total; i += WAVE) slist2[i] = slist[i].x;
+            __syncthreads();
         }
         TMARK(0)
 #ifdef RASTER_EXPERIMENT
@@ -1363,10 +1366,10 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: 2 x F face ids (id order, near-to-far order), F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
+// per resident workgroup: F x {face id, nearest depth} in id order, F face ids in walking order, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
 #define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
-    return (size_t)grid * (2 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+    return (size_t)grid * (3 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
 
@@ -1418,8 +1421,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.list_stride = (int)(align256((size_t)m->F * sizeof(uint32_t)) / sizeof(uint32_t));
         a.n_cf = (int)(align256((size_t)(m->F / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
         ws += 256;
-        a.slist = (uint32_t *)ws;
-        ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
+        a.slist = (uint2 *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(uint2);
         a.slist2 = (uint32_t *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;

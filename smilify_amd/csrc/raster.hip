@@ -128,7 +128,7 @@ struct RasterArgs {
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
-    float blur, sqrt_blur, inv_sigma;
+    float blur, sqrt_blur, inv_sigma, inv_sigma_log2e;
     // outputs / inputs per mode
     float *sil;              // (N,S,S) FWD (or optional in FUSED)
     const float *grad_sil;   // BWD
@@ -379,9 +379,10 @@ __device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e)
     return single ? zv : pz;
 }
 
-__device__ __forceinline__ float face_prob(float sd, float inv_sigma) {
-    // sigmoid(-dist / sigma) = 1 / (1 + e^{dist/sigma}); v_exp_f32 + v_rcp_f32 (1 ulp each)
-    return __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));
+__device__ __forceinline__ float face_prob(float sd, float inv_sigma_log2e) {
+    // sigmoid(-dist / sigma) = 1 / (1 + 2^{dist log2(e) / sigma}); v_exp_f32 + v_rcp_f32 (1 ulp each), the two constant factors
+    // of the exponent folded into one on the host
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sd * inv_sigma_log2e));
 }
 
 // Packed gradient accumulation (fused entry point, large launches).  The flush of pass 3 goes to memory-side atomics (the
@@ -449,15 +450,26 @@ __constant__ uint32_t g_wrap_mask = 0xFFFFFFFFu;
 #else
 #define WRAP_IDX(i) (i)
 #endif
+// (12-byte elements: the index is below 2^24, so the full-rate 24-bit multiply is exact; left to itself hipcc emits the
+// quarter-rate v_mul_lo_u32, also for the shift-and-add spelling)
+template <typename T>
+__device__ __forceinline__ uint32_t byte_offset(uint32_t i) {
+    if (sizeof(T) == 12) {
+        uint32_t r;
+        asm("v_mul_u32_u24 %0, %1, 12" : "=v"(r) : "v"(i));
+        return r;
+    }
+    return i * (uint32_t)sizeof(T);
+}
 template <typename T>
 __device__ __forceinline__ T &at(T *base, uint32_t i) {
     i = WRAP_IDX(i);
-    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset<T>(i));
 }
 template <typename T>
 __device__ __forceinline__ const T &at(const T *base, uint32_t i) {
     i = WRAP_IDX(i);
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset<T>(i));
 }
 
 // Record-stream accesses: written once, read once or twice, never shared between workgroups.
@@ -1064,7 +1076,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                         const bool sure = valid & ((ps[u].y == 0u) | (d1 < ps[u].x));
                         const bool maybe = valid & (ps[u].y > 0u) & (d1 == ps[u].x);
                         rmax2 = fmaxf(rmax2, fabsf(r[u].sd));  // (the clamped tail repeats a record: harmless)
-                        const float lf = __log2f(1.0f - face_prob(r[u].sd, a.inv_sigma));
+                        const float lf = __log2f(1.0f - face_prob(r[u].sd, a.inv_sigma_log2e));
                         if (sure & (lf != 0.f)) atomicAdd(&lds.plog[r[u].mt & 63u], (double)lf);
                         if (any_trunc) {  // wave-uniform
                             const unsigned long long km = __ballot(maybe);
@@ -1248,7 +1260,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                             const int pos = (int)((mt >> 6) & 0xFFFFu);
                             const uint32_t zt_ = __float_as_uint(pg[u].y);
                             const bool inside = ((mt >> 22) & 1u) != 0u;
-                            float gd = pg[u].x * face_prob(r[u].sd, a.inv_sigma);                 // scale * d L / d (signed dist)
+                            float gd = pg[u].x * face_prob(r[u].sd, a.inv_sigma_log2e);                 // scale * d L / d (signed dist)
                             gd = inside ? -gd : gd;                                               // ... / d (unsigned squared distance)
                             const int cut = __float_as_int(pg[u].z);
                             int fid = 0;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
@@ -1433,7 +1445,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     }
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
-    a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma;
+    a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
     a.dbg = nullptr;
     a.stop_after = 99;
     a.force_split = -1;

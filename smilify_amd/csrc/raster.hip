@@ -50,6 +50,9 @@
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
 #define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
+#define SEL1_BITS 6         // width of the FIRST digit, the one pass 1 counts and the closing rule works with: 64 buckets in the same
+                            // 16 words per pixel as four 8-bit counts that stop at SAT8 (a count only ever matters up to K <= 128)
+#define SAT8 160u           // a byte takes no further increment from here on; at most 63 more arrive with the instruction that crosses it
 #ifndef DGROUP
 #define DGROUP 4            // 64-record rows per buffer in the dense walks (two buffers)
 #endif
@@ -438,7 +441,7 @@ struct alignas(16) DenseLds {
     float2 pixt[WAVE];               // pass 1: pixel centre (px, py) in NDC
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run (list phase: bucket counters)
-    int bstart[(1 << SEL_BITS) + 1]; // first list position of every depth bucket of the near-to-far list
+    uint16_t bstart[1 << SEL1_BITS]; // first list position of every depth bucket of the near-to-far list (clamped to 65535)
 };
 static_assert(sizeof(DenseLds) * RESIDENT_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
 
@@ -558,7 +561,7 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
 // pass 1 uses that to stop collecting records for pixels that already hold K nearer ones (the reference keeps the K = 100
 // nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
 // Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
-// recovers through `out`.  bstart[d] = first position of bucket d, bstart[2^b1] = n.
+// recovers through `out`.  bstart[d] = first position of bucket d.
 __device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
                                                       DenseLds &lds, int lane) {
     const int n_buckets = 1 << b1;
@@ -570,7 +573,7 @@ __device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_
     const int c = lane < n_buckets ? lds.start[lane] : 0;
     const int incl = wave_scan_add(c);
     __syncthreads();
-    if (lane <= n_buckets) lds.bstart[lane] = lane < n_buckets ? incl - c : n;
+    if (lane < n_buckets) lds.bstart[lane] = (uint16_t)min(incl - c, 65535);
     lds.start[lane] = incl - c;  // running cursor of every bucket
     __syncthreads();
     for (int i = lane; i < n; i += WAVE) {
@@ -683,6 +686,34 @@ __device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b,
         n_eq = cnt_sel;
     } else {
         need = 0;  // fewer keys than the rank asked for: this pixel keeps everything
+        n_eq = 0;
+    }
+    return all;
+}
+
+// The same for the first digit, whose histogram holds four 8-bit counts per word ([bucket / 4][pixel]) that stop growing at
+// SAT8 > K: the cumulative counts below the chosen digit are exact (they are below `need` <= K), a count that reached SAT8
+// only ever compares as "more than K".
+__device__ __forceinline__ int pick_digit8(const uint32_t *hist, int lane, int b, uint32_t &pre, int &need, int &n_eq) {
+    int cum = 0, sel = 0, cnt_sel = 0, all = 0;
+    bool found = false;
+#pragma unroll
+    for (int w_ = 0; w_ < (1 << SEL1_BITS) / 4; ++w_) {
+        const uint32_t hw = hist[w_ * WAVE + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = (int)((hw >> (8 * q)) & 0xFFu);
+            all += h;
+            if (!found && cum + h >= need) { sel = 4 * w_ + q; cnt_sel = h; found = true; }
+            cum += found ? 0 : h;
+        }
+    }
+    if (need > 0 && found) {
+        pre = (pre << b) | (uint32_t)sel;
+        need -= cum;
+        n_eq = cnt_sel;
+    } else {
+        need = 0;
         n_eq = 0;
     }
     return all;
@@ -861,7 +892,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
         // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
         const uint32_t krange = kmax - kmin;
         const int nbits0 = krange ? 32 - __clz(krange) : 0;
-        const int b1 = min(SEL_BITS, nbits0), shift1 = nbits0 - b1;
+        const int b1 = min(SEL1_BITS, nbits0), shift1 = nbits0 - b1;
         __syncthreads();  // the list stores are visible to the loads below
         // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
         const uint32_t *const lst = slist2;
@@ -911,12 +942,10 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
                 if (may_truncate) {
                     // digit of this chunk's first face = number of buckets that start at or before it, minus one
-                    const int d0 = __popcll(__ballot(lane < (1 << b1) && lds.bstart[lane] <= c0)) - 1;
+                    const int d0 = __popcll(__ballot(lane < (1 << b1) && (int)lds.bstart[lane] <= c0)) - 1;
                     if (d0 > final_digits) {  // wave-uniform: digits [final_digits, d0) have just become final
-                        for (int d = final_digits; d < d0; ++d) {
-                            const uint32_t hw = lds.hist[(d >> 1) * WAVE + lane];
-                            final_cnt += (int)((d & 1) ? hw >> 16 : hw & 0xFFFFu);
-                        }
+                        for (int d = final_digits; d < d0; ++d)
+                            final_cnt += (int)((lds.hist[(d >> 2) * WAVE + lane] >> (8 * (d & 3))) & 0xFFu);
                         final_digits = d0;
                         open_px &= ~__ballot(final_cnt >= K);
                         if (open_px == 0ull) break;  // every pixel of the (sub-)tile is closed: the remaining faces are all farther
@@ -1005,7 +1034,9 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                                                    __float_as_uint(e.sd)});
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
-                            atomicAdd(&lds.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
+                            uint32_t *const hw = &lds.hist[(bucket >> 2) * WAVE + p];
+                            const uint32_t sh = 8u * (bucket & 3u);
+                            if (((*hw >> sh) & 0xFFu) < SAT8) atomicAdd(hw, 1u << sh);
                         }
                     }
                     vbase += __popcll(cm);
@@ -1039,7 +1070,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
             bool trunc = false;
             if (may_truncate && vbase > 0) {
                 need = K;
-                const int tot = pick_digit(lds.hist, lane, b1, pre, need, n_eq);
+                const int tot = pick_digit8(lds.hist, lane, b1, pre, need, n_eq);
                 trunc = tot > K;
                 if (!trunc) need = 0;
             }

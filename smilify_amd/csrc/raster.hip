@@ -982,6 +982,7 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                 // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
                 // (start bits at or below its lane) - 1, two v_mbcnt and one ds_bpermute away.
                 const unsigned long long nonempty = __ballot(cf > 0);
+                STAT(31, __popcll(nonempty))  // staged faces that have any open pixel in their box
                 lds.start[lane] = 0;
                 lds_fence();
                 if (cf > 0) {
@@ -1020,7 +1021,6 @@ __global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
                     PairEval e;
                     eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
                     const bool cand = valid && e.cand && ((open_px >> p) & 1ull);
-                    STAT(31, __popcll(__ballot(valid && !((open_px >> p) & 1ull))))  // pairs on closed pixels (slot 31: printed as 'closed')
                     const unsigned long long cm = __ballot(cand);
                     if (cm == 0ull) continue;
                     // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
@@ -1503,7 +1503,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
                 (double)h[16], (double)h[17], (double)h[18], (double)h[19]);
         fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e; chunks walked %.4e of %.4e, pixels still open at the end %.4e\n",
                 (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25], (double)h[28], (double)h[29], (double)h[30]);
-        fprintf(stderr, "[dbg stats] evaluated pairs whose pixel was already closed %.4e\n", (double)h[31]);
+        fprintf(stderr, "[dbg stats] staged faces with a non-empty pixel box %.4e\n", (double)h[31]);
         (void)hipMemset(dbg_dev, 0, 256);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;

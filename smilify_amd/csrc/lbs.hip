@@ -440,7 +440,7 @@ __device__ __forceinline__ void vertex_upstream(const float *__restrict__ d_vert
 #ifndef SKIN_BWD_THREADS
 #define SKIN_BWD_THREADS 512
 #endif
-__global__ void __launch_bounds__(SKIN_BWD_THREADS) k_skin_bwd_transforms(
+__global__ void __launch_bounds__(1024) k_skin_bwd_transforms(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ v_posed,
     const int *__restrict__ bone_ptr, const int *__restrict__ bone_vid, const float *__restrict__ bone_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
 
 // Per frame: d v_posed = T_R^T dv (+ regressor^T d J_rest), reduced against shapedirs -> d_beta[b],
 // and d_trans[b] = sum_v dv.  One block per frame, deterministic.
-__global__ void __launch_bounds__(SHAPE_BWD_THREADS) k_shape_bwd(
+__global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
@@ -765,7 +765,10 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     const float *v_skin = m->posedirs ? sv->v_posed : sv->v_shaped;
     const int nS_skin = m->posedirs ? B : nS;
     SMIL_REQUIRE(!m->posedirs || (sv->v_posed && g->d_vposed), "smil_lbs_backward: pose blend shapes need v_posed and d_vposed");
-    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(SKIN_BWD_THREADS), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
+    // one block per frame: many frames -> smaller blocks (more of them resident, phases decoupled); a handful of frames -> the
+    // widest block (the launch is one block's latency)
+    const int few_frames = B < 64;
+    hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(few_frames ? 1024 : SKIN_BWD_THREADS), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
                        g->d_joints, v_skin, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
                        m->jreg_cval, g->d_A, V, J, nS_skin, regress);
     SMIL_LAUNCH_CHECK();
@@ -828,8 +831,9 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
                 dbeta_frame = g->d_beta;
             }
         }
-        const size_t lds = ((size_t)J * 18 + (SHAPE_BWD_THREADS / WAVE) * SHAPE_TERMS) * sizeof(float);
-        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(SHAPE_BWD_THREADS), lds, stream, g->d_verts, g->d_joints,
+        const int shape_threads = few_frames ? 1024 : SHAPE_BWD_THREADS;
+        const size_t lds = ((size_t)J * 18 + (shape_threads / WAVE) * SHAPE_TERMS) * sizeof(float);
+        hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(shape_threads), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
                            m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, dbeta_shared, g->d_trans, g->d_del_v, V, J, nBu, regress,
                            in->trans_after_joints ? 1 : 0);

@@ -568,7 +568,16 @@ __device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_
     lds.start[lane] = 0;
     __syncthreads();
     auto digit_of = [&](uint2 e) { return (int)(((e.y - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
-    for (int i = lane; i < n; i += WAVE) atomicAdd(&lds.start[digit_of(list[i])], 1);
+    // (four rows per step: the loads of a step are in flight together - at small launches a tile's time is its chain of
+    // memory round trips)
+    for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = list[min(i0 + u * WAVE + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * WAVE + lane < n) atomicAdd(&lds.start[digit_of(e[u])], 1);
+    }
     __syncthreads();
     const int c = lane < n_buckets ? lds.start[lane] : 0;
     const int incl = wave_scan_add(c);
@@ -576,9 +585,13 @@ __device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_
     if (lane < n_buckets) lds.bstart[lane] = (uint16_t)min(incl - c, 65535);
     lds.start[lane] = incl - c;  // running cursor of every bucket
     __syncthreads();
-    for (int i = lane; i < n; i += WAVE) {
-        const uint2 e = list[i];
-        out[atomicAdd(&lds.start[digit_of(e)], 1)] = e.x;
+    for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = list[min(i0 + u * WAVE + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * WAVE + lane < n) out[atomicAdd(&lds.start[digit_of(e[u])], 1)] = e[u].x;
     }
     __syncthreads();
 }

@@ -507,6 +507,9 @@ __device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
     return (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
 }
 
+#ifndef LGROUP
+#define LGROUP 8  // 64-face groups whose tile boxes / depth ranges are requested together by the list build
+#endif
 __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, uint2 *list, int lane, uint32_t &kmin,
                                           uint32_t &kmax) {
     const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.F;
@@ -519,12 +522,12 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
         // lane = group of 64 consecutive faces: does its box union reach this tile?
         const int g = g0 + lane;
         unsigned long long gm = __ballot(g < n_groups && box_has(gbox_n[min(g, n_groups - 1)], tx, ty));
-        while (gm) {  // wave-uniform: the groups that do, in ascending order, four at a time (independent loads in flight)
-            int fidx[4];
-            uint32_t tb[4];
-            float2 zz[4];
+        while (gm) {  // wave-uniform: the groups that do, in ascending order, LGROUP at a time (independent loads in flight)
+            int fidx[LGROUP];
+            uint32_t tb[LGROUP];
+            float2 zz[LGROUP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LGROUP; ++u) {
                 const int gi = gm ? g0 + (int)__builtin_ctzll(gm) : -1;
                 gm &= gm - 1ull;  // 0 stays 0
                 fidx[u] = gi >= 0 ? gi * WAVE + lane : a.F;
@@ -533,7 +536,7 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
                 zz[u] = fzr_n[fc];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LGROUP; ++u) {
                 const bool hit = fidx[u] < a.F && box_has(tb[u], tx, ty);
                 const unsigned long long mask = __ballot(hit);
                 if (hit) {

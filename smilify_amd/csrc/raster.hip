@@ -17,23 +17,32 @@
 //    (lane = record) over the records that pass produced.  An earlier design (lane = pixel, each face broadcast to the 64
 //    pixels of the tile, three re-evaluating passes, K smallest depths in a sorted register array) spent ~75 % of its
 //    lanes on pairs that do not exist and 100 v_med3 per face on the selection; it is gone.
-//      pass 1  lane = pair.  Per DCHUNK-face chunk: lane = face computes its pixel box inside the tile, a prefix sum lays
-//              the boxes end to end, and the wave sweeps that pair list 64 at a time (a start-bit map gives each pair its
-//              face with two v_mbcnt and one ds_bpermute; face record and pixel coordinates are gathered from LDS).
-//              Accepted pairs are ballot-compacted into the workgroup's record streams - depth, {pixel | list position |
-//              inside | edge}, signed squared distance: three words, structure of arrays - in global memory (reused for every tile).  The
-//              first radix digit of every depth is histogrammed on the way (the tile's depth range is known from the list).
-//      blend   one sweep over the records (their 12 bytes; 8 where no pixel is truncated).  A record of a pixel with <= K candidates, or whose first
-//              digit lies below the digit that holds the pixel's K-th depth, is kept for certain: log2 of its factor is
-//              added to the pixel's sum (fp64 LDS atomics).  A record inside that digit goes on to a compact stream {key,
-//              meta, log} and has its second digit counted; one above it is dropped.
+//      list    faces whose tile box contains the tile (via the 64-face group boxes), with their nearest vertex depth; tiles
+//              that may truncate (list > K) order it NEAR TO FAR by the first radix digit of that depth (counting sort).
+//      pass 1  lane = pair.  Per DCHUNK-face chunk: two lanes per face stage its record and its pixel box inside the tile
+//              (shrunk to the pixels that are still open), a prefix sum lays the boxes end to end, and the wave sweeps that
+//              pair list 64 at a time (a start-bit map gives each pair its face with two v_mbcnt and two ds_bpermute; face
+//              record and pixel coordinates are gathered from LDS).  Accepted pairs are ballot-compacted into the
+//              workgroup's record stream in global memory (reused for every tile): 12 bytes {depth, pixel | list position
+//              | inside | edge, signed squared distance}, one array of structures.  The first radix digit of every depth
+//              (64 buckets, saturating 8-bit counts) is histogrammed per pixel on the way.  CLOSING: a record's depth is
+//              at least its face's nearest vertex depth, so once the walk reaches digit d the per-pixel counts of digits
+//              < d are final; a pixel holding >= K records there takes no further record, and when no pixel is open the
+//              rest of the list is skipped.
+//      blend   one sweep over the records.  A record of a pixel with <= K candidates, or whose first digit lies below the
+//              digit that holds the pixel's K-th depth, is kept for certain: log2 of its factor is added to the pixel's
+//              sum (fp64 LDS atomics).  A record inside that digit goes on to a compact stream {key, meta, log} and has
+//              its second digit counted; one above it is dropped.
 //      select  (only where a pixel has more than K candidates) the remaining digits by radix select over the compact
-//              stream, SEL_BITS per sweep, per-pixel histograms in LDS.  Exact, including the number of faces tied at the
-//              threshold; when a tie group straddles K, further sweeps select on the list position (= face id).  A last
-//              sweep over the compact stream adds the logs of the records that made it; alpha = exp2(sum) (the fp32
-//              product and the fp64-accumulated log-sum are both ~1e-6 relative from the exact product).
-//      pass 3  gradient of every kept record into per-face LDS accumulators, flushed per 64 faces.
-//    LDS accumulators are fp64: ds_add_f64 runs at full rate on gfx950 while ds_add_f32 costs ~3 cycles per active lane.
+//              stream, SEL_BITS per sweep, per-pixel histograms in LDS; the stream shrinks in place with every sweep.
+//              Exact, including the number of faces tied at the threshold; when a tie group straddles K, further sweeps
+//              select on the face id (fetched through the list only for records at the threshold).  A last sweep adds the
+//              logs of the records that made it; alpha = exp2(sum) (the fp32 product and the fp64-accumulated log-sum are
+//              both ~1e-6 relative from the exact product).
+//      pass 3  gradient of every kept record into per-face LDS accumulators ((x, y) packed as two 32-bit fixed-point numbers
+//              in one 64-bit word), per 64 faces; the closest point on the record's edge is recomputed from a table of the
+//              group's vertices.  Flush: one global atomic per touched vertex - two floats, or, from 64 images per launch
+//              on, one packed 64-bit integer decoded afterwards (k_unpack_dndc); these atomics execute memory-side.
 //  * A tile whose records would not fit the stream (REC_CAP) is processed in sub-tiles: power-of-two runs of its 64 pixels,
 //    halved until pass 1 fits.  A single pixel always fits because F <= REC_CAP is required on the host.
 //  * Deviation from the reference kept on purpose: the K faces a truncated pixel keeps are the K smallest by (depth, face

@@ -320,3 +320,29 @@ def test_more_tiles_than_the_setup_kernel_counts(tables):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
     gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
     assert np.linalg.norm(gotg - want) / np.linalg.norm(want) < 2e-3
+
+
+def test_sixty_thousand_faces_in_a_handful_of_tiles():
+    """A mesh near the rasteriser's face limit (65 536): a tube of 3 000 slivers per ring, 60 000 faces, drawn small - every
+    touched tile lists tens of thousands of faces (list positions and bucket starts near their 16-bit range, records far
+    beyond the stream, depth buckets with thousands of entries that saturate the 8-bit first-digit counts)."""
+    from smilify_amd import model_io
+
+    eng = _eng()
+    t = model_io.synthetic_model(V_side=3000, J=9, nB=2, seed=5)
+    assert 59000 < t.F <= 65536
+    dm = eng.DeviceModel(t, DEV)
+    S = 40
+    ndc = _scene(t, 1, S, 3.0, 3)
+    with render_ref.select_mode(1):
+        ref, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    assert ncand.max() > 4000
+    got = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
+    d = np.abs(got - ref)
+    assert d.mean() < 2e-4 and np.mean(d > 1e-2) < 0.005, (d.mean(), d.max())
+    gs = torch.ones(1, S, S)
+    with render_ref.select_mode(1):
+        want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
+    gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
+    cos = (gotg * want).sum() / (np.linalg.norm(gotg) * np.linalg.norm(want) + 1e-30)
+    assert cos > 0.995, cos

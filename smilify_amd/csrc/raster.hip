@@ -1634,7 +1634,7 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
     // large launches accumulate the vertex gradients as packed fixed point (half the memory-side atomics) and decode them in
     // place afterwards; small ones keep float atomics and save the extra launch
-    a.packed = N >= PACKED_MIN_IMAGES ? 1 : 0;
+    a.packed = (N >= PACKED_MIN_IMAGES && (reinterpret_cast<uintptr_t>(d_ndc) & 7u) == 0u) ? 1 : 0;  // (64-bit atomics need 8-byte alignment)
     PROF_BEGIN(stream);
     launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);

@@ -63,6 +63,9 @@ class _LbsFunction(torch.autograd.Function):
         return None, None, g["d_beta"], d_theta, g["d_trans"], d_ls, d_bt, d_delv, d_vt
 
 
+_HARDCODED_BODY_VERTS = (1863, 26, 2124, 150, 3055, 1097)  # end of nose, chin, right / left ear tip, left / right eye
+
+
 class SMAL(nn.Module):
     def __init__(self, device, shape_family_id=-1, dtype=torch.float, model_path: Optional[str] = None,
                  tables: Optional[model_io.SmilModelTables] = None, config: Optional[_config.FitterConfig] = None):
@@ -162,6 +165,12 @@ class SMAL(nn.Module):
         verts, joints, Rs, v_shaped, new_J = _LbsFunction.apply(self._dm, flags, beta, theta, trans, betas_logscale, betas_trans,
                                                                 del_v, v_template)
         self.J_transformed = new_J
+        if J == 35 and not self.config.ignore_hardcoded_body:
+            # legacy SMAL / WLDO body: six vertices (nose, chin, ear tips, eyes) ride along as extra joints
+            # (reference smal_torch.py:353-365; never taken by SMIL models, whose config sets ignore_hardcoded_body)
+            if V <= max(_HARDCODED_BODY_VERTS):
+                raise ValueError(f"the hard-coded body vertices need a mesh with more than {max(_HARDCODED_BODY_VERTS)} vertices, this one has {V}")
+            joints = torch.cat([joints, verts[:, list(_HARDCODED_BODY_VERTS)]], dim=1)
         if get_skin:
             return verts, joints, Rs, v_shaped
         return joints

@@ -279,3 +279,26 @@ def test_graph_replay_with_packed_gradients(tables):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=1e-6)
     for n in ("joint_rotations", "trans", "betas"):
         np.testing.assert_allclose(getattr(fg, n).detach().cpu().numpy(), getattr(fe, n).detach().cpu().numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_hardcoded_body_joints_of_35_joint_models():
+    """reference smal_torch.py:353-365: a 35-joint model with ignore_hardcoded_body off returns six mesh vertices behind its
+    joints (gradients flow to them like to any vertex)."""
+    from smilify_amd import config as cfgmod
+    from smilify_amd import model_io
+    from smilify_amd.smal_torch import SMAL, _HARDCODED_BODY_VERTS
+
+    t = model_io.synthetic_model(V_side=100, J=35, nB=2, seed=2)   # 3602 vertices > 3055
+    assert t.J == 35 and t.V > max(_HARDCODED_BODY_VERTS)
+    cfg = cfgmod.FitterConfig.from_tables(t, ignore_hardcoded_body=False)
+    smal = SMAL(DEV, tables=t, config=cfg)
+    beta = torch.zeros(2, t.nB, device=DEV)
+    theta = (0.1 * torch.randn(2, t.J, 3, generator=torch.Generator().manual_seed(0))).to(DEV).requires_grad_()
+    verts, joints, _, _ = smal(beta, theta)
+    assert joints.shape == (2, 41, 3)
+    assert torch.equal(joints[:, 35:], verts[:, list(_HARDCODED_BODY_VERTS)])
+    assert smal(beta, theta, get_skin=False).shape == (2, 41, 3)
+    joints[:, 35:].sum().backward()
+    assert theta.grad is not None and float(theta.grad.abs().max()) > 0
+    plain = SMAL(DEV, tables=t, config=cfgmod.FitterConfig.from_tables(t))
+    assert plain(beta, theta.detach())[1].shape == (2, 35, 3)

@@ -387,6 +387,10 @@ class SMALFitter(nn.Module):
     # ------------------------------------------------------------------------------------------
     # reference API
     # ------------------------------------------------------------------------------------------
+    def print_grads(self, grad_output):
+        """Debug hook of the reference (fitter.py:233-234): prints a gradient it is registered on."""
+        print(grad_output)
+
     def forward(self, batch_range, weights, stage_id):
         """Reference fitter.py:236-335: ``(sum of the weighted terms, dict of the terms)`` for one window."""
         total, objs = _FitWindow.apply(self, list(batch_range), [float(w) for w in weights], 0.0, self.betas, self.log_beta_scales,

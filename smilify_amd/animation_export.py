@@ -1,16 +1,17 @@
 """AMASS-style animation export of fitted / predicted SMIL parameters.
 
-``AnimationRecorder`` keeps the constructor, ``record`` / ``set_cameras`` / ``num_frames`` / ``write`` contract and the
-on-disk schema (``.npz`` payload keys + ``.json`` side-car, schema 1.1) of the reference's
-``smal_fitter/neuralSMIL/animation_export.py:41-218`` so that files written here load in the reference's Blender /
-video tooling and vice versa.  ``record_fitter`` feeds it from a ``SMALFitter`` (one frame per fitted frame).
+``AnimationRecorder`` answers to the constructor / ``record`` / ``set_cameras`` / ``num_frames`` / ``write`` calls of the
+reference's recorder (``smal_fitter/neuralSMIL/animation_export.py:41-218``) and writes its on-disk schema (``.npz`` payload
+keys + ``.json`` side-car, schema 1.1), so files written here load in the reference's Blender / video tooling and vice
+versa.  Inside it is a table-driven column store with a bulk path: ``record_fitter`` copies a ``SMALFitter``'s parameter
+buffers into a clip with one copy per track.
 Host-side format code only: nothing here runs on the hot path.
 """
 from __future__ import annotations
 
 import json
 from pathlib import Path
-from typing import Any, Dict, List, Optional, Union
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -43,115 +44,172 @@ def rotation_6d_to_axis_angle(d6: torch.Tensor) -> torch.Tensor:
     return aa.to(d6.dtype)
 
 
-def _to_numpy(t: Any) -> np.ndarray:
-    if isinstance(t, torch.Tensor):
-        return t.detach().cpu().float().numpy()
-    return np.asarray(t, dtype=np.float32)
+# ---------------------------------------------------------------------------------------------------------------------
+# The clip file format is the contract (``.npz`` payload + ``.json`` side-car, schema 1.1, as the reference's Blender /
+# video tooling reads it: neuralSMIL/animation_export.py:160-210).  Everything below is organised around ONE table of the
+# per-frame tracks a clip can hold; tracks live in preallocated float32 column stores that bulk producers (a fitter's
+# parameter buffers) fill with one copy per track.
+# ---------------------------------------------------------------------------------------------------------------------
+class _Track:
+    """Growable ``(frames, *cell)`` float32 store (capacity doubles; ``rows()`` is a contiguous view of what is filled)."""
+
+    def __init__(self, cell: Tuple[int, ...]) -> None:
+        self.cell = tuple(int(c) for c in cell)
+        self._buf = np.empty((0,) + self.cell, np.float32)
+        self.filled = 0
+
+    def append_block(self, block: np.ndarray) -> None:
+        block = np.asarray(block, np.float32).reshape((-1,) + self.cell)
+        need = self.filled + block.shape[0]
+        if need > self._buf.shape[0]:
+            grown = np.empty((max(need, 2 * self._buf.shape[0], 16),) + self.cell, np.float32)
+            grown[:self.filled] = self._buf[:self.filled]
+            self._buf = grown
+        self._buf[self.filled:need] = block
+        self.filled = need
+
+    def rows(self) -> np.ndarray:
+        return self._buf[:self.filled]
+
+
+def _host_f32(x: Any) -> np.ndarray:
+    return x.detach().to("cpu", torch.float32).numpy() if isinstance(x, torch.Tensor) else np.asarray(x, np.float32)
+
+
+# track name -> (cell shape from (n_joints, n_betas), mandatory in every frame?, payload key or None when side-car only)
+_TRACKS = {
+    "poses": (lambda J, nB: (J, 3), True, "poses"),
+    "trans": (lambda J, nB: (3,), True, "trans"),
+    "betas": (lambda J, nB: (nB,), True, "betas_per_frame"),
+    "log_beta_scales": (lambda J, nB: (J, 3), False, "log_beta_scales"),
+    "betas_trans": (lambda J, nB: (J, 3), False, "betas_trans"),
+    "mesh_scale": (lambda J, nB: (), False, "mesh_scale"),
+    "cam_rot": (lambda J, nB: (3, 3), False, None),
+    "cam_trans": (lambda J, nB: (3,), False, None),
+    "fov": (lambda J, nB: (), False, None),
+}
+# side-car layout: (key, attribute of the recorder or a callable of it), in file order
+_SIDECAR = (
+    ("schema_version", lambda r: SCHEMA_VERSION), ("model_id", "model_id"), ("source_checkpoint", "source_checkpoint"),
+    ("source_input", "source_input"), ("n_frames", lambda r: r.num_frames()), ("n_joints", "n_joints"), ("n_betas", "n_betas"),
+    ("joint_names", "joint_names"), ("parents", "parents"), ("rotation_representation", lambda r: "axis_angle"),
+    ("root_joint_index", lambda r: 0), ("static_joint_locs", "static_joint_locs"), ("ignore_hardcoded_body", "ignore_hardcoded_body"),
+    ("fps", "fps"), ("cameras", lambda r: r._camera_block()),
+)
+_ROTATION_DECODERS = {"axis_angle": lambda t: t, "6d": rotation_6d_to_axis_angle}
 
 
 class AnimationRecorder:
-    """Accumulates per-frame ``predicted_params`` dicts (batch dimension 1) and writes ``<output_path>.npz`` +
-    ``<output_path>.json``.  Rotations are stored as axis-angle whatever the inbound representation."""
+    """Collects frames of SMIL parameters and writes ``<output_path>.npz`` + ``<output_path>.json``.
+
+    ``record(params)`` takes one frame the way the reference's inference loop hands it over (tensors with a leading batch
+    dimension of 1, rotations in ``rotation_representation``); ``record_block(**tracks)`` takes whole ``(F, ...)`` arrays at
+    once.  Rotations always reach the file as axis-angle."""
 
     def __init__(self, output_path: Union[str, Path], rotation_representation: str, n_joints: int, n_betas: int,
                  joint_names: List[str], parents: List[int], fps: float, static_joint_locs: bool, ignore_hardcoded_body: bool,
                  source_checkpoint: Optional[str] = None, source_input: Optional[str] = None, model_id: Optional[str] = None) -> None:
-        if rotation_representation not in ("axis_angle", "6d"):
-            raise ValueError(f"rotation_representation must be 'axis_angle' or '6d', got {rotation_representation!r}")
-        self.output_path = Path(output_path)
+        try:
+            self._decode_rotation = _ROTATION_DECODERS[rotation_representation]
+        except KeyError:
+            raise ValueError(f"rotation_representation must be one of {sorted(_ROTATION_DECODERS)}, "
+                             f"got {rotation_representation!r}") from None
         self.rotation_representation = rotation_representation
-        self.n_joints, self.n_betas = int(n_joints), int(n_betas)
-        self.joint_names = [str(n) for n in joint_names]
-        self.parents = [int(p) for p in parents]
-        self.fps = float(fps)
+        self.output_path = Path(output_path)
+        self.n_joints, self.n_betas, self.fps = int(n_joints), int(n_betas), float(fps)
+        self.joint_names, self.parents = list(map(str, joint_names)), list(map(int, parents))
         self.static_joint_locs, self.ignore_hardcoded_body = bool(static_joint_locs), bool(ignore_hardcoded_body)
         self.source_checkpoint, self.source_input, self.model_id = source_checkpoint, source_input, model_id
-        self._rows: Dict[str, List[np.ndarray]] = {k: [] for k in ("poses", "trans", "betas", "log_beta_scales", "betas_trans", "mesh_scale",
-                                                                  "cam_rot", "cam_trans", "fov")}
-        self._cameras_sidecar: List[Dict[str, Any]] = []
+        self._tracks = {name: _Track(cell(self.n_joints, self.n_betas)) for name, (cell, _, _) in _TRACKS.items()}
+        self._static_cameras: List[Dict[str, Any]] = []
 
-    def _axis_angle(self, rot):
-        if isinstance(rot, torch.Tensor):
-            rot = rot.detach().cpu()
-        else:
-            rot = torch.as_tensor(np.asarray(rot, dtype=np.float32))
-        return rotation_6d_to_axis_angle(rot) if self.rotation_representation == "6d" else rot
+    # ---- producers --------------------------------------------------------------------------------------------------
+    def record_block(self, **tracks: Any) -> None:
+        """Append ``F`` frames at once: every given track is an ``(F, *cell)`` array (axis-angle ``poses`` incl. the root);
+        one copy per track.  Mandatory tracks must be present; an optional track must come with every block or none."""
+        given = {k: _host_f32(v) for k, v in tracks.items() if v is not None}
+        unknown = set(given) - set(_TRACKS)
+        if unknown:
+            raise KeyError(f"unknown animation tracks {sorted(unknown)}")
+        for name, (_, mandatory, _) in _TRACKS.items():
+            if mandatory and name not in given:
+                raise KeyError(f"animation frame without {name!r}")
+        for name, block in given.items():
+            self._tracks[name].append_block(block)
 
     def record(self, predicted_params: Dict[str, Any]) -> None:
-        g, j = self._axis_angle(predicted_params["global_rot"]), self._axis_angle(predicted_params["joint_rot"])
-        if g.dim() == 2:  # (B,3) -> (B,1,3)
-            g = g.unsqueeze(1)
-        self._rows["poses"].append(_to_numpy(torch.cat([g, j], dim=1)[0]))
-        self._rows["trans"].append(_to_numpy(predicted_params["trans"][0]))
-        self._rows["betas"].append(_to_numpy(predicted_params["betas"][0]))
-        for key in ("log_beta_scales", "betas_trans", "cam_rot", "cam_trans", "fov"):
-            if predicted_params.get(key, None) is not None:
-                self._rows[key].append(_to_numpy(predicted_params[key][0]))
-        if predicted_params.get("mesh_scale", None) is not None:
-            self._rows["mesh_scale"].append(_to_numpy(predicted_params["mesh_scale"][0]).reshape(-1))
+        """One frame from a ``predicted_params`` dict (``global_rot``, ``joint_rot``, ``trans``, ``betas`` and the optional
+        tracks); only batch element 0 is taken."""
+        def first(key):
+            v = predicted_params.get(key)
+            return None if v is None else (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, np.float32)))[0]
+
+        root = self._decode_rotation(first("global_rot")).reshape(1, 3)
+        limbs = self._decode_rotation(first("joint_rot")).reshape(-1, 3)
+        frame = {"poses": torch.cat((root, limbs))[None], "trans": first("trans")[None], "betas": first("betas")[None]}
+        for name in ("log_beta_scales", "betas_trans", "mesh_scale", "cam_rot", "cam_trans", "fov"):
+            v = first(name)
+            if v is not None:
+                frame[name] = v.reshape((1,) + self._tracks[name].cell)
+        self.record_block(**frame)
 
     def set_cameras(self, cameras: List[Dict[str, Any]]) -> None:
-        """Cameras block of the side-car for multi-view clips: ``{"view_name", "R" 3x3, "t" 3, "fov"}`` per view."""
-        self._cameras_sidecar = list(cameras)
+        """Static cameras of a multi-view clip for the side-car: ``{"view_name", "R" 3x3, "t" 3, "fov"}`` per view."""
+        self._static_cameras = [dict(c) for c in cameras]
 
     def num_frames(self) -> int:
-        return len(self._rows["poses"])
+        return self._tracks["poses"].filled
 
-    def _averaged_camera(self) -> List[Dict[str, Any]]:
-        r = self._rows
-        if not r["cam_rot"]:
+    # ---- file ---------------------------------------------------------------------------------------------------------
+    def _camera_block(self) -> List[Dict[str, Any]]:
+        if self._static_cameras:
+            return self._static_cameras
+        rot, pos, fov = (self._tracks[k].rows() for k in ("cam_rot", "cam_trans", "fov"))
+        if not len(rot):  # no per-frame camera was ever recorded
             return []
-        t = np.stack(r["cam_trans"]).mean(axis=0) if r["cam_trans"] else np.zeros(3, np.float32)
-        return [{"view_name": "view_0", "R": np.stack(r["cam_rot"]).mean(axis=0).tolist(), "t": t.flatten().tolist(),
-                 "fov": float(np.mean(r["fov"])) if r["fov"] else 0.0}]
+        # a single-view clip carries its (predicted, per-frame) camera as one time-averaged entry
+        return [{"view_name": "view_0", "R": rot.mean(axis=0).tolist(),
+                 "t": (pos.mean(axis=0) if len(pos) else np.zeros(3, np.float32)).tolist(),
+                 "fov": float(fov.mean()) if len(fov) else 0.0}]
 
     def write(self) -> Dict[str, Path]:
-        r = self._rows
-        if not r["poses"]:
+        frames = self.num_frames()
+        if frames == 0:
             raise RuntimeError("AnimationRecorder has no frames to write.")
+        payload: Dict[str, Any] = {}
+        for name, (_, mandatory, key) in _TRACKS.items():
+            rows = self._tracks[name].rows()
+            if key is None or not len(rows):
+                continue
+            if len(rows) != frames:
+                raise RuntimeError(f"track {name!r} holds {len(rows)} frames, the clip {frames}")
+            payload[key] = rows.copy()
+        payload["betas"] = payload["betas_per_frame"].mean(axis=0).astype(np.float32)  # the clip's single shape vector
+        payload["fps"] = np.float32(self.fps)
+        paths = {"npz": self.output_path.with_suffix(".npz"), "json": self.output_path.with_suffix(".json")}
         self.output_path.parent.mkdir(parents=True, exist_ok=True)
-        npz_path, json_path = self.output_path.with_suffix(".npz"), self.output_path.with_suffix(".json")
-        poses = np.stack(r["poses"]).astype(np.float32)
-        betas_per_frame = np.stack(r["betas"]).astype(np.float32)
-        payload: Dict[str, Any] = {"poses": poses, "trans": np.stack(r["trans"]).astype(np.float32),
-                                   "betas": betas_per_frame.mean(axis=0).astype(np.float32), "betas_per_frame": betas_per_frame,
-                                   "fps": np.float32(self.fps)}
-        for key in ("log_beta_scales", "betas_trans"):
-            if r[key]:
-                payload[key] = np.stack(r[key]).astype(np.float32)
-        if r["mesh_scale"]:  # (F,): isotropic scale about the root joint
-            payload["mesh_scale"] = np.stack(r["mesh_scale"]).astype(np.float32).reshape(-1)
-        np.savez(npz_path, **payload)
-        sidecar = {"schema_version": SCHEMA_VERSION, "model_id": self.model_id, "source_checkpoint": self.source_checkpoint,
-                   "source_input": self.source_input, "n_frames": int(poses.shape[0]), "n_joints": self.n_joints, "n_betas": self.n_betas,
-                   "joint_names": self.joint_names, "parents": self.parents, "rotation_representation": "axis_angle",
-                   "root_joint_index": 0, "static_joint_locs": self.static_joint_locs, "ignore_hardcoded_body": self.ignore_hardcoded_body,
-                   "fps": self.fps, "cameras": self._cameras_sidecar or self._averaged_camera()}
-        with open(json_path, "w") as f:
-            json.dump(sidecar, f, indent=2)
-        return {"npz": npz_path, "json": json_path}
+        np.savez(paths["npz"], **payload)
+        sidecar = {key: (src(self) if callable(src) else getattr(self, src)) for key, src in _SIDECAR}
+        paths["json"].write_text(json.dumps(sidecar, indent=2))
+        return paths
 
 
 def record_fitter(fitter, output_path: Union[str, Path], fps: float = 30.0, view_names: Optional[List[str]] = None,
                   model_id: Optional[str] = None) -> Dict[str, Path]:
-    """Write the current parameters of a ``SMALFitter`` (every frame of this rank) as one clip; cameras go to the
-    side-car as one static entry per view."""
+    """Write the current parameters of a ``SMALFitter`` (every frame of this rank) as one clip: each track is copied from
+    the fitter's parameter buffer in one piece; cameras go to the side-car as one static entry per view."""
     t = fitter.smal_model.tables
     rec = AnimationRecorder(output_path, "axis_angle", t.J, t.nB, list(t.joint_names), [int(p) for p in t.parents], fps,
                             bool(t.static_joints), bool(fitter.config.ignore_hardcoded_body), model_id=model_id or t.name)
     N = fitter.num_images
-    gr = (fitter.global_rotation.detach() * fitter.global_mask).cpu()
-    jr = (fitter.joint_rotations.detach() * fitter.rotation_mask).cpu()
-    tr, betas = fitter.trans.detach().cpu(), fitter.betas.detach().cpu()
-    ls, bt = fitter.log_beta_scales.detach().cpu(), fitter.betas_trans.detach().cpu()
-    for i in range(N):
-        rec.record(dict(global_rot=gr[i:i + 1], joint_rot=jr[i:i + 1], trans=tr[i:i + 1], betas=betas[None],
-                        log_beta_scales=ls[min(i, ls.shape[0] - 1)][None], betas_trans=bt[min(i, bt.shape[0] - 1)][None]))
+    with torch.no_grad():
+        poses = torch.cat(((fitter.global_rotation * fitter.global_mask)[:, None], fitter.joint_rotations * fitter.rotation_mask), dim=1)
+        per_frame = lambda p: p.expand(N, *p.shape[1:]) if p.shape[0] != N else p  # noqa: E731  (tables shared by all frames)
+        rec.record_block(poses=poses, trans=fitter.trans, betas=fitter.betas[None].expand(N, -1),
+                         log_beta_scales=per_frame(fitter.log_beta_scales), betas_trans=per_frame(fitter.betas_trans))
     cam = fitter.renderer.cameras
     fov = fitter.fov.detach().reshape(-1).cpu()
-    cams = []
-    for v in range(fitter.views):
-        cams.append({"view_name": view_names[v] if view_names else f"view_{v}", "R": cam.R[min(v, cam.R.shape[0] - 1)].cpu().tolist(),
-                     "t": cam.T[min(v, cam.T.shape[0] - 1)].cpu().tolist(), "fov": float(fov[min(v, fov.numel() - 1)])})
-    rec.set_cameras(cams)
+    pick = lambda a, v: a[min(v, a.shape[0] - 1)]  # noqa: E731  (one shared camera or one per view)
+    rec.set_cameras([{"view_name": view_names[v] if view_names else f"view_{v}", "R": pick(cam.R, v).cpu().tolist(),
+                      "t": pick(cam.T, v).cpu().tolist(), "fov": float(pick(fov, v))} for v in range(fitter.views)])
     return rec.write()

@@ -58,8 +58,14 @@
                             // pass 1 gathers 3-5 different faces per instruction; 144 bytes keeps 8 consecutive faces apart
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
-#define SEL_BITS 5          // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
-#define SEL1_BITS 6         // width of the FIRST digit, the one pass 1 counts and the closing rule works with: 64 buckets in the same
+#ifndef SEL_BITS
+#define SEL_BITS 5
+#endif
+//      SEL_BITS            // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
+#ifndef SEL1_BITS
+#define SEL1_BITS 6
+#endif
+//      SEL1_BITS           // width of the FIRST digit, the one pass 1 counts and the closing rule works with: 64 buckets in the same
                             // 16 words per pixel as four 8-bit counts that stop at SAT8 (a count only ever matters up to K <= 128)
 #define SAT8 160u           // a byte takes no further increment from here on; at most 63 more arrive with the instruction that crosses it
 #ifndef DGROUP
@@ -72,9 +78,15 @@
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
 #endif
 #define REC_PAD 64          // slack so that a clamped read stays inside the allocation
-#define RESIDENT_PER_CU 16  // single-wave workgroups per CU: what 128 VGPRs and 9.9 KB of LDS per workgroup allow (measured 10 ... 14: every
+#ifndef RESIDENT_PER_CU
+#define RESIDENT_PER_CU 16
+#endif
+//      RESIDENT_PER_CU     // single-wave workgroups per CU: what 128 VGPRs and 9.9 KB of LDS per workgroup allow (measured 10 ... 14: every
                             // further workgroup still shortens the launch)
 
+#ifndef WAVES_PER_SIMD
+#define WAVES_PER_SIMD 4     // what the tile kernel's register budget is set for: RESIDENT_PER_CU / 4
+#endif
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
 // -DDBG_TIMERS: per-phase cycle sums and work counters of the tile kernel (printed by the next launch); off in normal
@@ -847,7 +859,7 @@ __device__ __forceinline__ int refine_sweep(DenseLds &lds, Rec3 *crec, int n_rec
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(64, 4) k_raster_dense(RasterArgs a) {
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
     const int lane = threadIdx.x;
     uint2 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;

@@ -128,3 +128,45 @@ def test_reference_checkpoint_fixture_layout():
         assert p["global_rotation"].shape == (3,) and p["joint_rotations"].shape == (J - 1, 3) and p["trans"].shape == (3,)
         assert p["log_betascale"].shape == (J, 3) and p["betas_trans"].shape == (J, 3) and p["fov"].shape == ()
         np.testing.assert_array_equal(p["global_rotation"], exp["global_rotation"][frame])  # what the reference loader restored
+
+
+def test_record_fitter_copies_whole_parameter_buffers(tmp_path):
+    """``record_fitter`` on a fitter-shaped object: every track arrives in one block, masks applied, shared tables expanded,
+    one static camera per view in the side-car; the same clip comes out of the frame-by-frame path."""
+    from types import SimpleNamespace
+
+    from smilify_amd.animation_export import record_fitter
+
+    N, J, nB, views = 7, 5, 3, 2
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    gmask, rmask = torch.tensor([1.0, 0.0, 1.0]), torch.ones(J - 1, 3)
+    rmask[2] = 0.0
+    fitter = SimpleNamespace(
+        smal_model=SimpleNamespace(tables=SimpleNamespace(J=J, nB=nB, joint_names=[f"j{i}" for i in range(J)], parents=[-1, 0, 1, 1, 3],
+                                                           static_joints=False, name="toy")),
+        config=SimpleNamespace(ignore_hardcoded_body=True), num_images=N, views=views,
+        global_rotation=rnd(N, 3), joint_rotations=rnd(N, J - 1, 3), global_mask=gmask, rotation_mask=rmask, trans=rnd(N, 3),
+        betas=rnd(nB), log_beta_scales=rnd(1, J, 3), betas_trans=rnd(N, J, 3), fov=torch.tensor([50.0, 70.0]),
+        renderer=SimpleNamespace(cameras=SimpleNamespace(R=rnd(views, 3, 3), T=rnd(views, 3))))
+    out = record_fitter(fitter, tmp_path / "fit", fps=12.0, view_names=["left", "right"])
+    d, side = np.load(out["npz"]), json.load(open(out["json"]))
+    assert d["poses"].shape == (N, J, 3) and d["betas_per_frame"].shape == (N, nB) and d["log_beta_scales"].shape == (N, J, 3)
+    np.testing.assert_array_equal(d["poses"][:, 0], (fitter.global_rotation * gmask).numpy())
+    np.testing.assert_array_equal(d["poses"][:, 1:], (fitter.joint_rotations * rmask).numpy())
+    np.testing.assert_array_equal(d["log_beta_scales"], fitter.log_beta_scales.expand(N, J, 3).numpy())
+    np.testing.assert_array_equal(d["betas"], d["betas_per_frame"].mean(axis=0))
+    assert side["n_frames"] == N and side["model_id"] == "toy" and [c["view_name"] for c in side["cameras"]] == ["left", "right"]
+    assert side["cameras"][1]["fov"] == 70.0 and "mesh_scale" not in d.files
+    # frame by frame through record(): the identical payload
+    rec = AnimationRecorder(tmp_path / "fit2", "axis_angle", J, nB, side["joint_names"], side["parents"], 12.0, False, True)
+    for i in range(N):
+        rec.record({"global_rot": (fitter.global_rotation * gmask)[i:i + 1], "joint_rot": (fitter.joint_rotations * rmask)[i:i + 1],
+                    "trans": fitter.trans[i:i + 1], "betas": fitter.betas[None], "log_beta_scales": fitter.log_beta_scales,
+                    "betas_trans": fitter.betas_trans[i:i + 1]})
+    d2 = np.load(rec.write()["npz"])
+    assert sorted(d2.files) == sorted(d.files)
+    for k in d.files:
+        np.testing.assert_array_equal(d2[k], d[k], err_msg=k)
+    with pytest.raises(KeyError):
+        rec.record_block(poses=np.zeros((1, J, 3)), trans=np.zeros((1, 3)))  # no betas

@@ -212,11 +212,17 @@ class SMALFitter(nn.Module):
         super().__setattr__(name, value)
 
     def _mask_table(self) -> torch.Tensor:
-        """(J,3) = [global_mask ; rotation_mask], rebuilt only when a mask tensor was replaced or edited in place."""
+        """(J,3) = [global_mask ; rotation_mask] in ONE persistent device buffer, refreshed in place when a mask tensor was
+        replaced or edited in place (the reference documents ``fitter.rotation_mask[25:32] = 0.0``): a captured iteration
+        reads this buffer, so it sees the current masks at every replay."""
         key = (self.global_mask.data_ptr(), self.global_mask._version, self.rotation_mask.data_ptr(), self.rotation_mask._version)
         cached = self.__dict__.get("_mask_cache")
         if cached is None or cached[0] != key:
-            cached = (key, torch.cat([self.global_mask.reshape(1, 3), self.rotation_mask.reshape(-1, 3)], 0).float().contiguous())
+            table = torch.cat([self.global_mask.reshape(1, 3), self.rotation_mask.reshape(-1, 3)], 0).float().contiguous()
+            if cached is not None and cached[1].shape == table.shape and cached[1].device == table.device:
+                cached[1].copy_(table)
+                table = cached[1]
+            cached = (key, table)
             self.__dict__["_mask_cache"] = cached
         return cached[1]
 
@@ -500,7 +506,7 @@ class SMALFitter(nn.Module):
         cam = self.renderer.cameras
         ptr = lambda t: None if t is None else (t.data_ptr(), tuple(t.shape))  # noqa: E731
         ws = self.device_model._ws
-        addresses = (ptr(cam.R), ptr(cam.T), ptr(cam.aspect_ratio), ptr(self.fov.data), ptr(self.global_mask), ptr(self.rotation_mask),
+        addresses = (ptr(cam.R), ptr(cam.T), ptr(cam.aspect_ratio), ptr(self.fov.data), ptr(self._mask_table()),
                      ptr(self.log_beta_scales.data), ptr(self.betas_trans.data), ptr(self.betas.data), None if ws is None else ws.data_ptr())
         return (tuple(float(w) for w in weights), float(w_temp), window, flags, self._target_signature, addresses)
 
@@ -511,6 +517,7 @@ class SMALFitter(nn.Module):
         window = self.config.WINDOW_SIZE if window is None else window
         if self._targets_dirty or self._signature() != self._target_signature:
             self._refresh_targets()
+        self._mask_table()  # in-place mask edits since the capture reach the buffer the graph reads (outside the graph)
         key = self._graph_key(weights, w_temp, window)
         g = getattr(self, "_graph", None)
         if g is None or g["key"] != key:

@@ -137,6 +137,13 @@ def test_graph_replay_is_invalidated_by_camera_mask_and_workspace_changes(tables
     third = fg._graph["graph"]
     both()
     assert fg._graph["graph"] is third          # nothing changed: replayed
+    for f in (fe, fg):                          # the reference's idiom: a mask edited IN PLACE (same tensor, same address)
+        f.rotation_mask[0] = 0.0
+        f.global_mask[0, 1] = 0.0
+    both()                                      # the graph reads the refreshed mask table ...
+    both()
+    assert fg._graph["graph"] is third          # ... without a re-capture
+    np.testing.assert_allclose(fg._pose.cpu().numpy(), fe._pose.cpu().numpy(), rtol=2e-4, atol=2e-6)
     fg.device_model._ws = None                  # as a larger Renderer call on the same model would do: workspace replaced
     both()
     assert fg._graph["graph"] is not third

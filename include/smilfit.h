@@ -176,26 +176,16 @@ typedef struct {
                                  nearer than this are culled (clip_faces); straddling faces are not split */
 } SmilRasterSettings;
 
-/* Caller-owned scratch for N images of side S: per-face tile boxes / depth ranges, the tile work lists, the scratch arena of the
- * resident workgroups (about 1.6 MB each, 16 per CU: 6.6 GB once N * tiles exceeds that many) and, from 64 images per call on,
- * the record pool of the split tile kernels: ~960 bytes per face and image at 256^2 (scaled with the image area), capped at
- * 24 GB.  Images whose records do not fit the pool are rendered by the fused kernel on the arena (slower, same results), so
- * the pool never limits what can be rendered; smil_raster_split_images says how many images per call it covers.  Size the
- * buffer once and reuse it.  Meshes with more than 65536 faces are rejected (SMIL_E_INVALID). */
+/* Caller-owned scratch for N images of side S: per-face tile boxes / depth ranges, the tile work list, and the pair-record
+ * streams of the resident workgroups (about 1.6 MB each, 16 per CU: 6.6 GB once N * tiles exceeds that many - size the
+ * buffer once and reuse it).  Meshes with more than 65536 faces are rejected (SMIL_E_INVALID). */
 size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
-int32_t smil_raster_split_images(const SmilModel *m, int32_t S);
-/* Process-wide routing knobs, for tests and experiments: calls of at least split_min_images images use the split kernels
- * (<= 0: the default, 64); pool_max_bytes caps the record pool (< 0: the default, 24 GB; 0: fused kernel only).  Changes the
- * workspace size: re-query smil_raster_workspace_bytes afterwards. */
-int smil_raster_configure(int32_t split_min_images, int64_t pool_max_bytes);
 
-/* Counters of the most recent rasteriser call that used `workspace` with the same (N, S), copied to out8[8] (synchronises the
- * stream): [0] pool units (64 B) handed out, [1] images rendered by the fused kernel because the pool was full, [2] tiles
- * through the fused kernel, [3] tiles through the split kernels, [4] guard trips (a tile found more pairs than its region
- * was sized for; never expected, 0 in every test), [5] faces straddling z_clip (one or two vertices nearer than znear / 2):
- * pytorch3d's clip_faces would cut them at the plane (p3d_renderer.py:36-47 leaves that default on), this library renders
- * them unclipped - a non-zero count says the silhouette of that call deviates. */
-int smil_raster_stats(const SmilModel *m, int32_t N, int32_t S, const void *workspace, void *stream, uint32_t *out8);
+/* Counters of the most recent rasteriser call that used `workspace` with the same N, copied to out4[4] (synchronises the
+ * stream): [0] faces straddling z_clip (one or two vertices nearer than znear / 2).  pytorch3d's clip_faces would cut such a
+ * face at the plane (p3d_renderer.py:36-47 leaves that default on); this library renders it whole, so a non-zero count says
+ * the silhouettes of that call deviate from the reference's.  [1] touched 8x8 tiles.  [2], [3] reserved. */
+int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream, uint32_t *out4);
 
 /* verts_ndc (N,V,3) -> sil (N,S,S) */
 int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

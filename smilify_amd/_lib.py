@@ -17,7 +17,7 @@ EXPORTS = [
     "smil_model_create", "smil_model_destroy", "smil_model_dims", "smil_last_error", "smil_version",
     "smil_lbs_forward", "smil_lbs_backward", "smil_project", "smil_project2", "smil_project_backward", "smil_project_backward2",
     "smil_fov_reduce", "smil_fit_epilogue",
-    "smil_raster_workspace_bytes", "smil_raster_split_images", "smil_raster_stats", "smil_raster_configure", "smil_silhouette_forward", "smil_silhouette_backward",
+    "smil_raster_workspace_bytes", "smil_raster_stats", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
     "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_adam_step_multi", "smil_adam_step_dev", "smil_profile_enable",
     "smil_profile_read",
@@ -113,10 +113,7 @@ def load():
                                                                                  c_void_p, c_void_p, c_void_p]
     lib.smil_raster_workspace_bytes.argtypes = [c_void_p, c_int32, c_int32]
     lib.smil_raster_workspace_bytes.restype = c_size_t
-    lib.smil_raster_split_images.argtypes = [c_void_p, c_int32]
-    lib.smil_raster_split_images.restype = c_int32
-    lib.smil_raster_configure.argtypes = [c_int32, c_int64]
-    lib.smil_raster_stats.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.smil_raster_stats.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
     lib.smil_silhouette_forward.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,
                                             c_void_p, c_void_p]
     lib.smil_silhouette_backward.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,

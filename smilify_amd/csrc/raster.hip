@@ -88,35 +88,6 @@
 #define WAVES_PER_SIMD 4     // what the tile kernel's register budget is set for: RESIDENT_PER_CU / 4
 #endif
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
-// The tile kernel exists in three forms (template parameter PHASE):
-//   PHASE_A    list + pass 1 of a tile; the records, the walking list and the per-pixel selection state go to the tile's REGION in
-//              the record pool (global memory), sized by the setup kernel from the tile's exact pair count.  VALU-bound.
-//   PHASE_B    blend / select / epilogue / pass 3 of a tile from its region.  Memory-latency-bound, few registers, small LDS:
-//              compiled for WAVES_B waves per SIMD.
-//   PHASE_ALL  both in one go on per-workgroup scratch (the only form up to round 2).  Kept for what the pool cannot take: images
-//              beyond its capacity, tiles with more than REC_CAP pairs (processed in sub-tiles), launches of a few images (tiles dealt
-//              out in pieces), images with more tiles than the setup kernel counts.  The setup kernel routes every tile to one
-//              of the two work lists.
-enum { PHASE_ALL = 0, PHASE_A = 1, PHASE_B = 2 };
-#ifndef WAVES_B
-#define WAVES_B 5           // waves per SIMD the phase-B kernel is compiled for (registers) ...
-#endif
-#ifndef RESIDENT_B
-#define RESIDENT_B 20       // ... and its single-wave workgroups per CU (LDS: 160 KB / RESIDENT_B each)
-#endif
-#ifndef SEL_BITS_B
-#define SEL_BITS_B 4        // radix-select digit width of the phase-B kernel (half the histogram of SEL_BITS = 5)
-#endif
-#ifndef SPLIT_MIN_IMAGES
-#define SPLIT_MIN_IMAGES 64 // launches below this stay on the fused kernel (their tiles are dealt out in pieces)
-#endif
-#define POOL_UNIT 64        // bytes: granularity of region addresses (32-bit unit index: 256 GB of pool)
-#ifndef POOL_MAX_BYTES
-#define POOL_MAX_BYTES (24ull << 30)
-#endif
-#ifndef POOL_PAIRS_PER_FACE
-#define POOL_PAIRS_PER_FACE 80  // budget of (face, pixel) pairs per face and image at 256^2 (scaled by (S / 256)^2): STICK needs ~71, the mouse ~60
-#endif
 
 // -DDBG_TIMERS: per-phase cycle sums and work counters of the tile kernel (printed by the next launch); off in normal
 // builds (tools/dbg builds libsmilfit_dbg.so with it).  The marks only read the cycle counter into registers; the one
@@ -157,8 +128,7 @@ enum { PHASE_ALL = 0, PHASE_A = 1, PHASE_B = 2 };
 #ifndef SPLIT0_LOG
 #define SPLIT0_LOG 0          // log2 of the pieces every class-0 tile is dealt out in (0: whole; with near-to-far lists and closing the
 #endif                        // tiles with the longest lists finish early, and pieces only repeat their list walk: measured 2 -> 0: mouse -9 %)
-#define COUNT_TILES_MAX 4096  // per-tile pair and entry counts live in LDS (8 bytes per tile); larger images (S > 512) queue everything in the
-                              // last class of the fused lists
+#define COUNT_TILES_MAX 8192  // per-tile face counts live in LDS (4 bytes each); larger images queue everything in the last class
 // XCD-aware dealing.  Each of the 8 XCDs of an MI355X has its own 4 MB L2, and the tiles of one image read the same
 // per-image tables (projected vertices, face tile boxes, depth ranges: ~180 KB on STICK).  Images are therefore dealt to
 // N_PARTS work-list partitions (image % N_PARTS); a workgroup drains the partition of the XCD it runs on first
@@ -167,35 +137,9 @@ enum { PHASE_ALL = 0, PHASE_A = 1, PHASE_B = 2 };
 #define N_PARTS 8
 struct RasterCounters {
     unsigned int n_class[N_PARTS][N_CLASSES];
-    struct { unsigned int next, pad[15]; } deal[N_PARTS];    // one cache line per partition's cursor
-    struct { unsigned int next, pad[15]; } deal_b[N_PARTS];  // the same for the phase-B kernel, which walks the same lists
+    struct { unsigned int next, pad[15]; } deal[N_PARTS];  // one cache line per partition's cursor
+    unsigned int straddling;  // faces with zmin < z_clip <= zmax in this launch: rendered unclipped (smil_raster_stats)
 };
-// per launch: what the caller can ask for afterwards (smil_raster_stats)
-struct RasterStats {
-    unsigned int pool_next;       // region units handed out (setup kernel)
-    unsigned int images_fused;    // images whose regions did not fit the pool any more: processed by the fused kernel
-    unsigned int tiles_fused;     // tiles routed to the fused kernel (incl. those of images_fused)
-    unsigned int tiles_split;
-    unsigned int guard_trips;     // phase A found more pairs than the setup kernel counted (never expected: both use pixel_range())
-    unsigned int straddling;      // faces with zmin < z_clip <= zmax: rendered unclipped (see smil_raster_stats)
-    unsigned int pad[2];
-};
-// head of a tile's region (PHASE_A -> PHASE_B).  Layout of a region: header | pixel selection state uint2[64] | scfirst[list / DCHUNK + 2]
-// | walking list[list] | (64-byte aligned) records[pairs]
-struct TileHeader {
-    uint32_t n_rec, list_total, chunks_done, kmin;
-    int32_t nbits0, b1;
-    uint32_t flags;               // bit 0: may_truncate
-    uint32_t pad[9];
-};
-static_assert(sizeof(TileHeader) == 64, "TileHeader is one pool unit");
-__host__ __device__ __forceinline__ uint32_t region_meta_bytes(uint32_t ents) {
-    return (uint32_t)(sizeof(TileHeader) + WAVE * sizeof(uint2)) + 4u * (ents / DCHUNK + 2u) + 4u * ents;
-}
-__host__ __device__ __forceinline__ uint32_t region_rec_offset(uint32_t ents) { return (region_meta_bytes(ents) + 63u) & ~63u; }
-__host__ __device__ __forceinline__ uint32_t region_units(uint32_t ents, uint32_t pairs) {
-    return (region_rec_offset(ents) + 12u * pairs + (POOL_UNIT - 1)) / POOL_UNIT;
-}
 
 struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
 
@@ -206,15 +150,8 @@ struct RasterArgs {
     const uint32_t *gbox;    // (N, ceil(F/64)) union of the tile boxes of 64 consecutive faces
     const uint32_t *items;   // work lists, per partition q at 2 q cap: [0, cap) classes 0 (front) / 1 (back), [cap, 2 cap) classes 2 / 3
     uint32_t item_cap;       // entries of one array of ONE partition: ceil(N / N_PARTS) * tiles
-    const uint32_t *ibase;   // split lists only, parallel to items: the tile's region in the pool (POOL_UNIT units) ...
-    const uint32_t *icap;    // ... and the records it has room for (= the tile's pair count)
-    char *pool;
-    RasterStats *stats;
-    Rec3 *crec_b;            // PHASE_B: compact streams of its workgroups (REC_CAP + REC_PAD each, in the scratch arena)
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
-    RasterCounters *ctr;     // counters of the SPLIT lists (items); PHASE_ALL walks the FUSED lists:
-    const uint32_t *items_f;
-    RasterCounters *ctr_f;
+    RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
     float blur, sqrt_blur, inv_sigma, inv_sigma_log2e;
     // outputs / inputs per mode
@@ -252,77 +189,44 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
 
-// inclusive wave64 prefix sum in DPP (row_shr within 16-lane rows, then row_bcast across rows)
-__device__ __forceinline__ int wave_scan_add(int x) {
-#define SCAN_STEP(ctrl, rows) { x += __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); }
-    SCAN_STEP(0x111, 0xF) SCAN_STEP(0x112, 0xF) SCAN_STEP(0x114, 0xF) SCAN_STEP(0x118, 0xF)
-    SCAN_STEP(0x142, 0xA) SCAN_STEP(0x143, 0xC)
-#undef SCAN_STEP
-    return x;
-}
-
 // ---------------------------------------------------------------------------------------------
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
-// Pixel indices (flipped axis) whose centres -1 + (2i+1)/S lie inside [lo, hi]: ceil(v_lo) .. floor(v_hi) with v = ((x+1) S - 1)/2;
-// 0.01 px of slack covers the float rounding of both sides (a superset; eval_pair applies the exact test).  ONE function for
-// the setup kernel (which sizes a tile's record region by its pair count) and for the staging of pass 1 (which enumerates
-// those pairs), with contraction off so that both round identically whatever the surrounding code.
-__device__ __forceinline__ void pixel_range(float lo, float hi, float fS, int &i_lo, int &i_hi) {
-#pragma clang fp contract(off)
-    const float vlo = ((lo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f, vhi = ((hi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f;
-    i_lo = (int)ceilf(vlo);
-    i_hi = (int)floorf(vhi);
-}
-// blurred bounding box of a face, the same way for both users
-__device__ __forceinline__ void blurred_box(float a, float b, float c, float sqrt_blur, float &lo, float &hi) {
-#pragma clang fp contract(off)
-    lo = fminf(fminf(a, b), c) - sqrt_blur;
-    hi = fmaxf(fmaxf(a, b), c) + sqrt_blur;
-}
-
 #ifndef SETUP_THREADS
 #define SETUP_THREADS 1024
 #endif
-struct SetupArgs {
-    const float *verts_ndc; const int *faces;
-    uint32_t *tbox, *gbox; float2 *fzr;
-    uint32_t *items, *items_f, *ibase, *icap; uint32_t item_cap;
-    RasterCounters *ctr, *ctr_f; RasterStats *stats;
-    int V, F, S, tiles_x; float sqrt_blur, z_clip;
-    float *d_ndc_zero; const float *loss_src; float *loss_dst; float *img_bound; int max_valence;
-    uint32_t pool_units;     // 0: no split path in this launch (everything goes to the fused lists)
-};
-__global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
+__global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
+                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
+                                                      uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
+                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
+                                                      float z_clip, float *__restrict__ d_ndc_zero, const float *__restrict__ loss_src,
+                                                      float *__restrict__ loss_dst, float *__restrict__ img_bound, int max_valence) {
     __shared__ uint32_t s_maxpx;  // largest blurred pixel box of a face
     __shared__ uint32_t s_straddle;
     if (threadIdx.x == 0) { s_maxpx = 0u; s_straddle = 0u; }
     uint32_t my_px = 0u, my_straddle = 0u;
-    // per tile: (face, pixel) pairs and list entries (counted), or a touched-tile bitmap when the image has too many tiles
-    extern __shared__ uint32_t tcnt[];
+    extern __shared__ uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
-    const int V = q.V, F = q.F, S = q.S, tiles_x = q.tiles_x;
     // the fused entry point's per-image initialisation rides along (saves a 100 MB memset and a copy launch per iteration):
     // the vertex gradient of this image starts at zero, its loss at sum |0 - target|
-    if (q.d_ndc_zero) {
-        float2 *z = reinterpret_cast<float2 *>(q.d_ndc_zero) + (size_t)n * V;
+    if (d_ndc_zero) {
+        float2 *z = reinterpret_cast<float2 *>(d_ndc_zero) + (size_t)n * V;
         for (int i = threadIdx.x; i < V; i += blockDim.x) z[i] = make_float2(0.f, 0.f);
     }
-    if (q.loss_dst && threadIdx.x == 0) q.loss_dst[n] = q.loss_src[n];
+    if (loss_dst && threadIdx.x == 0) loss_dst[n] = loss_src[n];
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
-    uint32_t *const tpairs = tcnt, *const tents = tcnt + n_tiles;  // (counted only)
-    const int n_words = counted ? 2 * n_tiles : (n_tiles + 31) >> 5;
+    const int n_words = counted ? n_tiles : (n_tiles + 31) >> 5;
     for (int i = threadIdx.x; i < n_words; i += blockDim.x) tcnt[i] = 0u;
     __syncthreads();
-    const float *vn = q.verts_ndc + (size_t)n * V * 3;
+    const float *vn = verts_ndc + (size_t)n * V * 3;
     const float fS = (float)S;
     const int n_groups = (F + WAVE - 1) / WAVE;
     for (int f0 = 0; f0 < F; f0 += blockDim.x) {  // every wave handles 64 consecutive faces per round
         const int f = f0 + threadIdx.x;
         uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
         if (f < F) {
-            const int i0 = q.faces[3 * f], i1 = q.faces[3 * f + 1], i2 = q.faces[3 * f + 2];
+            const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
             const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
             const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
             const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
@@ -330,16 +234,15 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
             const float area = edge_fn(x0, y0, x1, y1, x2, y2);
             const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
             // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
-            // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split;
-            // they are counted (smil_raster_stats).
-            if (finite && !(zmin < K_EPS) && !(zmax < q.z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
-                if (zmin < q.z_clip) ++my_straddle;
-                float xlo, xhi, ylo, yhi;
-                blurred_box(x0, x1, x2, q.sqrt_blur, xlo, xhi);
-                blurred_box(y0, y1, y2, q.sqrt_blur, ylo, yhi);
-                int xi_lo, xi_hi, yi_lo, yi_hi;
-                pixel_range(xlo, xhi, fS, xi_lo, xi_hi);
-                pixel_range(ylo, yhi, fS, yi_lo, yi_hi);
+            // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split.
+            if (finite && !(zmin < K_EPS) && !(zmax < z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
+                if (zmin < z_clip) ++my_straddle;  // clip_faces() would cut this face at z_clip; it is rendered whole (counted)
+                const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
+                const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
+                // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
+                // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides
+                int xi_lo = (int)ceilf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
+                int yi_lo = (int)ceilf(((ylo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((yhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
                 xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
                 xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
                 if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
@@ -352,19 +255,22 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
                     for (int ty = ty0; ty <= ty1; ++ty)
                         for (int tx = tx0; tx <= tx1; ++tx) {
                             const int t = ty * tiles_x + tx;
-                            if (counted) {  // this face in this tile: its (face, pixel) pairs, and one list entry
+                            if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it
                                 const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
                                 const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
-                                atomicAdd(&tpairs[t], (uint32_t)(wx * wy));
-                                atomicAdd(&tents[t], 1u);
+#ifdef SETUP_NO_COUNT  // timing experiment only: how much of the setup kernel is the LDS atomics
+                                if (f == 0) atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
+#else
+                                atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
+#endif
                             } else {
                                 atomicOr(&tcnt[t >> 5], 1u << (t & 31));
                             }
                         }
                 }
             }
-            q.tbox[(size_t)n * F + f] = box;
-            q.fzr[(size_t)n * F + f] = make_float2(zmin, zmax);
+            tbox[(size_t)n * F + f] = box;
+            fzr[(size_t)n * F + f] = make_float2(zmin, zmax);
         }
         // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test
         int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
@@ -374,7 +280,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
         }
         const int grp = (f0 + (int)threadIdx.x) / WAVE;
         if ((threadIdx.x & (WAVE - 1)) == 0 && grp < n_groups)
-            q.gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
+            gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
     // Bound on what one vertex component of this image can receive from pass 3, up to the factor |upstream gradient| /
     // sqrt(sigma): a kept record of probability p = sigmoid(-+r^2 / sigma) adds at most 2 r p alpha |g| / sigma to an end point,
@@ -383,88 +289,42 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
     if (my_px) atomicMax(&s_maxpx, my_px);
     if (my_straddle) atomicAdd(&s_straddle, my_straddle);
     __syncthreads();
-    if (threadIdx.x == 0 && q.img_bound) q.img_bound[n] = 1.02f * 0.4f * (float)q.max_valence * (float)s_maxpx;
-    if (threadIdx.x == 0 && s_straddle) atomicAdd(&q.stats->straddling, s_straddle);
-    // Touched tiles -> a work list.  cost = pairs + 8 per face (its staging): the cost class.  A tile goes to the SPLIT lists
-    // (phase A / phase B kernels) when the launch has a record pool, its pairs fit one record stream and the regions of this
-    // image's tiles still fit the pool; to the FUSED lists otherwise.
-    __shared__ uint32_t s_cnt[2][N_CLASSES], s_base[2][N_CLASSES], s_units[SETUP_THREADS / WAVE], s_img_base, s_split;
-    if (threadIdx.x < 2 * N_CLASSES) s_cnt[threadIdx.x / N_CLASSES][threadIdx.x % N_CLASSES] = 0u;
+    if (threadIdx.x == 0 && img_bound) img_bound[n] = 1.02f * 0.4f * (float)max_valence * (float)s_maxpx;
+    if (threadIdx.x == 0 && s_straddle) atomicAdd(&ctr->straddling, s_straddle);
+    // touched tiles -> the work list of their cost class
+    __shared__ uint32_t s_cnt[N_CLASSES], s_base[N_CLASSES];
+    if (threadIdx.x < N_CLASSES) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
     auto tile_class = [&](int t) -> int {  // -1: untouched
         if (!counted) return ((tcnt[t >> 5] >> (t & 31)) & 1u) ? N_CLASSES - 1 : -1;
-        const uint32_t e = tents[t];
-        const uint32_t c = tpairs[t] + 8u * e;
-        return e == 0u ? -1 : (c >= CLASS_T0 ? 0 : (c >= CLASS_T1 ? 1 : (c >= CLASS_T2 ? 2 : 3)));
+        const uint32_t c = tcnt[t];
+        return c == 0u ? -1 : (c >= CLASS_T0 ? 0 : (c >= CLASS_T1 ? 1 : (c >= CLASS_T2 ? 2 : 3)));
     };
-    auto splittable = [&](int t) -> bool { return counted && q.pool_units != 0u && tpairs[t] <= (uint32_t)REC_CAP; };
-    // region units of this thread's splittable tiles -> exclusive prefix over the block (thread order) -> image base from the pool
-    uint32_t my_units = 0u;
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x)
-        if (tile_class(t) >= 0 && splittable(t)) my_units += region_units(tents[t], tpairs[t]);
-    const uint32_t incl = (uint32_t)wave_scan_add((int)my_units);
-    if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) s_units[threadIdx.x / WAVE] = incl;
-    __syncthreads();
-    uint32_t unit_off = incl - my_units;
-    for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) unit_off += s_units[w];
-    if (threadIdx.x == blockDim.x - 1) {
-        const uint32_t total = unit_off + my_units;
-        uint32_t base = 0u, ok = 0u;
-        if (total != 0u) {
-            base = atomicAdd(&q.stats->pool_next, total);
-            ok = (base <= q.pool_units && total <= q.pool_units - base) ? 1u : 0u;  // (a wrapped cursor fails the first test for good)
-            if (!ok) atomicAdd(&q.stats->images_fused, 1u);
-        }
-        s_img_base = base;
-        s_split = ok;
-    }
-    __syncthreads();
-    const bool img_split = s_split != 0u;
-    uint32_t mine[2][N_CLASSES] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    uint32_t mine[N_CLASSES] = {0u, 0u, 0u, 0u};
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int c = tile_class(t);
-        const int which = (c >= 0 && img_split && splittable(t)) ? 0 : 1;
 #pragma unroll
-        for (int k = 0; k < N_CLASSES; ++k) mine[which][k] += (c == k) ? 1u : 0u;
+        for (int k = 0; k < N_CLASSES; ++k) mine[k] += (c == k) ? 1u : 0u;
     }
-    uint32_t off[2][N_CLASSES];
+    uint32_t off[N_CLASSES];
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
-#pragma unroll
-        for (int k = 0; k < N_CLASSES; ++k) off[w][k] = mine[w][k] ? atomicAdd(&s_cnt[w][k], mine[w][k]) : 0u;
+    for (int k = 0; k < N_CLASSES; ++k) off[k] = mine[k] ? atomicAdd(&s_cnt[k], mine[k]) : 0u;
     __syncthreads();
     const int part = n % N_PARTS;
-    if (threadIdx.x < 2 * N_CLASSES) {
-        const int w = threadIdx.x / N_CLASSES, k = threadIdx.x % N_CLASSES;
-        RasterCounters *c = w == 0 ? q.ctr : q.ctr_f;
-        s_base[w][k] = s_cnt[w][k] ? atomicAdd(&c->n_class[part][k], s_cnt[w][k]) : 0u;
-        if (s_cnt[w][k]) atomicAdd(w == 0 ? &q.stats->tiles_split : &q.stats->tiles_fused, s_cnt[w][k]);
-    }
+    if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr->n_class[part][threadIdx.x], s_cnt[threadIdx.x]) : 0u;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
-#pragma unroll
-        for (int k = 0; k < N_CLASSES; ++k) off[w][k] += s_base[w][k];
-    uint32_t run = s_img_base + unit_off;  // this thread's tiles in the same order as above
+    for (int k = 0; k < N_CLASSES; ++k) off[k] += s_base[k];
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int c = tile_class(t);
         if (c < 0) continue;
-        const bool sp = splittable(t);
-        const int which = (img_split && sp) ? 0 : 1;
         uint32_t slot = 0u;
 #pragma unroll
         for (int k = 0; k < N_CLASSES; ++k)
-            if (c == k) slot = off[which][k]++;
+            if (c == k) slot = off[k]++;
         // classes 0 and 2 grow from the front of their array, 1 and 3 from the back
-        const uint32_t idx = (uint32_t)(2 * part + (c >> 1)) * q.item_cap + ((c & 1) ? q.item_cap - 1u - slot : slot);
-        const uint32_t code = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
-        if (which == 0) {
-            q.items[idx] = code;
-            q.ibase[idx] = run;
-            q.icap[idx] = tpairs[t];
-        } else {
-            q.items_f[idx] = code;
-        }
-        if (sp) run += region_units(tents[t], tpairs[t]);
+        const uint32_t idx = (uint32_t)(2 * part + (c >> 1)) * item_cap + ((c & 1) ? item_cap - 1u - slot : slot);
+        items[idx] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
     }
 }
 
@@ -608,35 +468,8 @@ struct alignas(16) DenseLds {
     uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run (list phase: bucket counters)
     uint16_t bstart[1 << SEL1_BITS]; // first list position of every depth bucket of the near-to-far list (clamped to 65535)
-    static constexpr int SB = SEL_BITS;
 };
 static_assert(sizeof(DenseLds) * RESIDENT_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
-static_assert((1 << SEL1_BITS) / 4 <= (1 << SEL_BITS) / 2, "the first digit's 8-bit counts live in the selection histogram");
-// PHASE_A: what list + pass 1 need
-struct alignas(16) LdsA {
-    float rec[DCHUNK * FSTR];
-    uint32_t hist[(1 << SEL1_BITS) / 4 * WAVE];  // first digit: four 8-bit counts per word
-    float2 pixt[WAVE];
-    uint2 psel[WAVE];
-    int start[WAVE];
-    uint16_t bstart[1 << SEL1_BITS];
-    static constexpr int SB = SEL_BITS;
-};
-static_assert(sizeof(LdsA) * RESIDENT_PER_CU <= 160 * 1024, "phase A: LDS of the resident workgroups");
-// PHASE_B: blend / select / pass 3
-struct alignas(16) LdsB {
-    unsigned long long gacc[GCOPIES][GCHUNK * 3];
-    double plog[WAVE];
-    float4 pgrad[WAVE];
-    uint32_t hist[(1 << SEL_BITS_B) / 2 * WAVE];
-    float2 pixt[WAVE];
-    uint2 psel[WAVE];
-    static constexpr int SB = SEL_BITS_B;
-};
-static_assert(sizeof(LdsB) * RESIDENT_B <= 160 * 1024, "phase B: LDS of the resident workgroups");
-template <int PHASE> struct PhaseLds { using type = DenseLds; };
-template <> struct PhaseLds<PHASE_A> { using type = LdsA; };
-template <> struct PhaseLds<PHASE_B> { using type = LdsB; };
 
 // Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
 // VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
@@ -681,6 +514,15 @@ template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_
 // own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
 // outstanding global stores (vmcnt), which in pass 1 would stall every sweep step on the previous step's record stores.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// inclusive wave64 prefix sum in DPP (row_shr within 16-lane rows, then row_bcast across rows)
+__device__ __forceinline__ int wave_scan_add(int x) {
+#define SCAN_STEP(ctrl, rows) { x += __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); }
+    SCAN_STEP(0x111, 0xF) SCAN_STEP(0x112, 0xF) SCAN_STEP(0x114, 0xF) SCAN_STEP(0x118, 0xF)
+    SCAN_STEP(0x142, 0xA) SCAN_STEP(0x143, 0xC)
+#undef SCAN_STEP
+    return x;
+}
 
 // Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the nearest /
 // farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's vertex
@@ -749,9 +591,8 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
 // nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
 // Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
 // recovers through `out`.  bstart[d] = first position of bucket d.
-template <typename L>
 __device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
-                                                      L &lds, int lane) {
+                                                      DenseLds &lds, int lane) {
     const int n_buckets = 1 << b1;
     lds.start[lane] = 0;
     __syncthreads();
@@ -812,16 +653,13 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             r[1] = make_float4((y2 - y1) * s0, -(x2 - x1) * s0, edge_fn(cx, cy, x1, y1, x2, y2) * s0, (y0 - y2) * s1);
             r[2] = make_float4(-(x0 - x2) * s1, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);
             r[3] = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
-            float ymin, ymax;
-            blurred_box(y0, y1, y2, a.sqrt_blur, ymin, ymax);
-            int yi_lo, yi_hi;
-            pixel_range(ymin, ymax, fS, yi_lo, yi_hi);
+            const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
+            const int yi_lo = (int)ceilf(((ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - yi_hi - ty * TILE, oy0);
             b1 = min(a.S - 1 - yi_lo - ty * TILE, oy1);
         } else {
-            float xmin, xmax, ymin, ymax;
-            blurred_box(x0, x1, x2, a.sqrt_blur, xmin, xmax);
-            blurred_box(y0, y1, y2, a.sqrt_blur, ymin, ymax);
+            const float xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur, xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
+            const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
             r[0] = make_float4(xmin, xmax, ymin, ymax);
             const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
             const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
@@ -832,8 +670,7 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             r[5] = make_float4(e01x, e01y, rl01, e02x);
             r[6] = make_float4(e02y, rl02, e12x, e12y);
             r[7] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
-            int xi_lo, xi_hi;
-            pixel_range(xmin, xmax, fS, xi_lo, xi_hi);
+            const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
             b1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
         }
@@ -872,12 +709,11 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
 
 // lane = pixel: in the histogram `hist` ([bucket / 2][pixel]) find the digit that holds the `need`-th smallest key.
 // Returns the number of keys counted for this pixel; updates (pre, need) and reports the count of the chosen digit.
-template <int SB>
 __device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b, uint32_t &pre, int &need, int &n_eq) {
     int cum = 0, sel = 0, cnt_sel = 0, all = 0;
     bool found = false;
 #pragma unroll
-    for (int w_ = 0; w_ < (1 << SB) / 2; ++w_) {
+    for (int w_ = 0; w_ < (1 << SEL_BITS) / 2; ++w_) {
         const uint32_t hw = hist[w_ * WAVE + lane];
         const int h0 = (int)(hw & 0xFFFFu), h1 = (int)(hw >> 16);
         all += h0 + h1;
@@ -927,12 +763,12 @@ __device__ __forceinline__ int pick_digit8(const uint32_t *hist, int lane, int b
 
 // One radix-select sweep over `n_rec` (key, meta) pairs: among the keys of pixel p whose bits above `nbits` equal
 // psel[p].x, histogram the next `b` bits (psel[p].y == 0: pixel not taking part; key 0xFFFFFFFF: record not taking part).
-template <typename L, typename KeyFn>
-__device__ __forceinline__ void select_sweep(L &lds, const Rec3 *__restrict__ crec, int n_rec, int nbits, int b,
+template <typename KeyFn>
+__device__ __forceinline__ void select_sweep(DenseLds &lds, const Rec3 *__restrict__ crec, int n_rec, int nbits, int b,
                                              int lane, uint32_t pre, int need, KeyFn key_of) {
     const int shift = nbits - b;
     lds.psel[lane] = make_uint2(pre, (uint32_t)need);
-    for (int i_ = lane; i_ < (1 << L::SB) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
     __syncthreads();
     auto load_keys = [&](uint32_t (&kk)[KGROUP], uint32_t (&mt)[KGROUP], int g0) {
 #pragma unroll
@@ -976,12 +812,11 @@ __device__ __forceinline__ void select_sweep(L &lds, const Rec3 *__restrict__ cr
 //   above     -> dropped.
 // Returns the number of records left.  Every later sweep thus reads only the records that are still undecided (a tenth per
 // digit) instead of the whole compact stream, and the final pass only sees the last bucket.
-template <typename L>
-__device__ __forceinline__ int refine_sweep(L &lds, Rec3 *crec, int n_rec, int nbits, int b,
+__device__ __forceinline__ int refine_sweep(DenseLds &lds, Rec3 *crec, int n_rec, int nbits, int b,
                                             int lane, uint32_t pre, int need) {
     const int shift = nbits - b;
     lds.psel[lane] = make_uint2(pre, (uint32_t)need);
-    for (int i_ = lane; i_ < (1 << L::SB) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
     __syncthreads();
     int n_out = 0;
     struct CRec { uint32_t kk, mt; float lf; };
@@ -1028,40 +863,32 @@ __device__ __forceinline__ int refine_sweep(L &lds, Rec3 *crec, int n_rec, int n
     return n_out;
 }
 
-template <int MODE, int PHASE>
-__global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIMD) k_raster_dense(RasterArgs a) {
-    using Lds = typename PhaseLds<PHASE>::type;
-    constexpr int SB = Lds::SB;
-    constexpr int HIST_WORDS = (int)(sizeof(Lds::hist) / sizeof(uint32_t));
-    __shared__ Lds lds;
+template <int MODE>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs a) {
+    __shared__ DenseLds lds;
     const int lane = threadIdx.x;
-    // per-workgroup scratch: the fused kernel keeps a tile's lists and streams there, phase A its id-order list, phase B its
-    // compact stream; phases A and B keep everything else in the tile's region of the pool
     uint2 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
-    uint32_t *const slist2_ws = a.slist2 + (size_t)blockIdx.x * a.list_stride;
-    uint32_t *const scfirst_ws = a.scfirst + (size_t)blockIdx.x * a.n_cf;
+    uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
+    uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
-    Rec3 *const srec_ws = a.srec + rec0;
-    Rec3 *const crec = (PHASE == PHASE_B ? a.crec_b : a.crec) + rec0;
+    Rec3 *const srec = a.srec + rec0, *const crec = a.crec + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
-    RasterCounters *const ctr = PHASE == PHASE_ALL ? a.ctr_f : a.ctr;
-    const uint32_t *const items_all = PHASE == PHASE_ALL ? a.items_f : a.items;
     unsigned int n_items_all = 0;
     for (int q = 0; q < N_PARTS; ++q)
-        for (int c = 0; c < N_CLASSES; ++c) n_items_all += ctr->n_class[q][c];
+        for (int c = 0; c < N_CLASSES; ++c) n_items_all += a.ctr->n_class[q][c];
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
-    // the launch finishes in a fraction of one tile's serial time.  (Fused kernel only: a region holds a whole tile.)
+    // the launch finishes in a fraction of one tile's serial time.
 #ifdef RASTER_EXPERIMENT
-    const unsigned int split_log = PHASE != PHASE_ALL ? 0u : a.force_split >= 0 ? (unsigned int)a.force_split :
+    const unsigned int split_log = a.force_split >= 0 ? (unsigned int)a.force_split :
 #else
-    const unsigned int split_log = PHASE != PHASE_ALL ? 0u :
+    const unsigned int split_log =
 #endif
         n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u));
     // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
     // near to far).
-    const unsigned int split0_log = PHASE != PHASE_ALL ? 0u : SPLIT0_LOG;
+    const unsigned int split0_log = SPLIT0_LOG;
     const float fS = (float)a.S;
     unsigned int xcc;  // the XCD this workgroup runs on: which partition it drains first
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1070,15 +897,14 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
     TIMERS_INIT
     for (unsigned int turn = 0; turn < N_PARTS; ++turn) {
     const unsigned int part = (xcc + turn) & (unsigned int)(N_PARTS - 1);
-    const unsigned int nc0 = ctr->n_class[part][0], nc1 = ctr->n_class[part][1], nc2 = ctr->n_class[part][2], nc3 = ctr->n_class[part][3];
+    const unsigned int nc0 = a.ctr->n_class[part][0], nc1 = a.ctr->n_class[part][1], nc2 = a.ctr->n_class[part][2], nc3 = a.ctr->n_class[part][3];
     const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
     const unsigned int units0 = nc0 << split0_log;
     const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
-    const size_t part_off = (size_t)part * 2u * a.item_cap;
-    const uint32_t *const items = items_all + part_off;
+    const uint32_t *const items = a.items + (size_t)part * 2u * a.item_cap;
     while (n_units > 0u) {
         unsigned int unit = 0;
-        if (lane == 0) unit = atomicAdd(PHASE == PHASE_B ? &ctr->deal_b[part].next : &ctr->deal[part].next, 1u);
+        if (lane == 0) unit = atomicAdd(&a.ctr->deal[part].next, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= n_units) break;
 #ifdef DBG_TIMERS
@@ -1089,11 +915,10 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
         const unsigned int item = (u_ >> sl) + (heavy ? 0u : nc0);
         const int p_begin = (int)(u_ & ((1u << sl) - 1u)) * (WAVE >> sl), p_end = p_begin + (WAVE >> sl);
         // heaviest class first
-        const uint32_t item_idx = item < nc0 ? item
-                                : item < nc0 + nc1 ? a.item_cap - 1u - (item - nc0)
-                                : item < nc0 + nc1 + nc2 ? a.item_cap + (item - nc0 - nc1)
-                                : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
-        const uint32_t code = items[item_idx];
+        const uint32_t code = item < nc0 ? items[item]
+                            : item < nc0 + nc1 ? items[a.item_cap - 1u - (item - nc0)]
+                            : item < nc0 + nc1 + nc2 ? items[a.item_cap + (item - nc0 - nc1)]
+                            : items[2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2)];
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
@@ -1101,44 +926,23 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
         const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
         const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
-        // the tile's region (phases A and B)
-        char *const reg = PHASE == PHASE_ALL ? nullptr : a.pool + (size_t)a.ibase[part_off + item_idx] * POOL_UNIT;
-        const int rec_cap = PHASE == PHASE_A ? (int)a.icap[part_off + item_idx] : REC_CAP;  // records this tile's stream may take
-        TileHeader *const hdr = reinterpret_cast<TileHeader *>(reg);
-        uint2 *const pixsel = reinterpret_cast<uint2 *>(reg + sizeof(TileHeader));
 
-        uint32_t kmin = 0u, kmax = 0u;  // bounds of the depth keys of this tile
-        int list_total = 0, nbits0 = 0, b1 = 0, shift1 = 0;
-        bool may_truncate = false;
-        int b_n_rec = 0, b_chunks_done = 0;  // PHASE_B: what phase A left in the header
-        if constexpr (PHASE == PHASE_B) {  // wave-uniform loads of the header phase A wrote
-            b_n_rec = (int)hdr->n_rec; list_total = (int)hdr->list_total; b_chunks_done = (int)hdr->chunks_done;
-            kmin = hdr->kmin; nbits0 = hdr->nbits0; b1 = hdr->b1; shift1 = nbits0 - b1;
-            may_truncate = (hdr->flags & 1u) != 0u;
-        } else {
-            list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
-            may_truncate = list_total > K;
-            // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
-            // first digit takes the top SEL1_BITS (so it always spreads over at least half of its buckets)
-            const uint32_t krange = kmax - kmin;
-            nbits0 = krange ? 32 - __clz(krange) : 0;
-            b1 = min(SEL1_BITS, nbits0);
-            shift1 = nbits0 - b1;
-        }
-        // the walking list, the first record of every chunk and the records: in the tile's region or in the workgroup's scratch
-        uint32_t *const scfirst = PHASE == PHASE_ALL ? scfirst_ws : reinterpret_cast<uint32_t *>(reg + sizeof(TileHeader) + WAVE * sizeof(uint2));
-        uint32_t *const lst_w = PHASE == PHASE_ALL ? slist2_ws : scfirst + (list_total / DCHUNK + 2);
-        const uint32_t *const lst = lst_w;
-        Rec3 *const srec = PHASE == PHASE_ALL ? srec_ws : reinterpret_cast<Rec3 *>(reg + region_rec_offset((uint32_t)list_total));
-        if constexpr (PHASE != PHASE_B) {
-            __syncthreads();  // the list stores are visible to the loads below
-            // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
-            if (may_truncate) {
-                sort_list_near_to_far(slist, lst_w, list_total, kmin, shift1, b1, lds, lane);
-            } else {  // at most K faces: the id order is kept
-                for (int i = lane; i < list_total; i += WAVE) lst_w[i] = slist[i].x;
-                __syncthreads();
-            }
+        uint32_t kmin, kmax;  // bounds of the depth keys of this tile
+        const int list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
+        const bool may_truncate = list_total > K;
+        // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
+        // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
+        const uint32_t krange = kmax - kmin;
+        const int nbits0 = krange ? 32 - __clz(krange) : 0;
+        const int b1 = min(SEL1_BITS, nbits0), shift1 = nbits0 - b1;
+        __syncthreads();  // the list stores are visible to the loads below
+        // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
+        const uint32_t *const lst = slist2;
+        if (may_truncate) {
+            sort_list_near_to_far(slist, slist2, list_total, kmin, shift1, b1, lds, lane);
+        } else {  // at most K faces: the id order is kept
+            for (int i = lane; i < list_total; i += WAVE) slist2[i] = slist[i].x;
+            __syncthreads();
         }
         TMARK(0)
 #ifdef RASTER_EXPERIMENT
@@ -1148,7 +952,7 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
         // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
         // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
         int span = p_end - p_begin;
-        while (PHASE == PHASE_ALL && span > 1 && (long long)span * list_total > 4ll * REC_CAP) span >>= 1;  // (a region holds the whole tile)
+        while (span > 1 && (long long)span * list_total > 4ll * REC_CAP) span >>= 1;
         for (int p_lo = p_begin; p_lo < p_end;) {
             const bool mine = lane >= p_lo && lane < p_lo + span;  // this lane's pixel belongs to the sub-tile
             const int sy0 = p_lo >> 3, sy1 = (p_lo + span - 1) >> 3;                       // its rows ...
@@ -1156,23 +960,19 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
             // pixels outside the image or the sub-tile get a position no bbox can contain
             const float px = (in_img && mine) ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
             lds.pixt[lane] = make_float2(px, py);
-            if (may_truncate && PHASE != PHASE_B)
-                for (int i_ = lane; i_ < HIST_WORDS; i_ += WAVE) lds.hist[i_] = 0u;
+            if (may_truncate)
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
 
-            int vbase = PHASE == PHASE_B ? b_n_rec : 0;  // records written so far (wave-uniform)
-            int chunks_done = PHASE == PHASE_B ? b_chunks_done : 0;
-            uint32_t pre = 0u;   // selection state of this lane's pixel, set up after pass 1 (PHASE_B: read back)
-            int need = 0, n_eq = 0;
-            bool trunc = false;
-            if constexpr (PHASE != PHASE_B) {
             // ---------------- pass 1: every pair inside a face's pixel box, once --------------------------------
+            int vbase = 0;  // records written so far (wave-uniform)
             bool fits = true;
             // Pixels that cannot keep any further record ("closed"): they already hold K records in depth digits that are
             // final, i.e. below the digit of the first face not yet processed.  Lane = pixel keeps its count of final records.
             int final_digits = 0, final_cnt = 0;
             unsigned long long open_px = __ballot(in_img && mine);
             int ox0 = sx0, ox1 = sx1, oy0 = sy0, oy1 = sy1;  // bounding box of the open pixels
+            int chunks_done = 0;
             // The staging loads form a chain list entry -> vertex indices -> vertex coordinates.  The first two links are
             // fetched ahead: while chunk k is evaluated the indices of chunk k + 1 and the list entries of chunk k + 2 are in
             // flight (four registers), so a chunk starts with one memory round trip instead of three.
@@ -1217,7 +1017,7 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
                 const int off = incl - cf;          // first pair of this face in the chunk's pair list
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
                 packed |= off;                      // off <= DCHUNK * 64
-                if (vbase + n_pairs > rec_cap) { fits = false; break; }  // wave-uniform
+                if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
                 STAT(20, n_pairs)
                 // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
                 // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
@@ -1288,15 +1088,10 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
 #endif
                 lds_fence();  // rec is rewritten by the next chunk
             }
-            if (!fits) {  // wave-uniform
-                if (PHASE == PHASE_ALL) {  // try again with half the pixels
-                    span >>= 1;
-                    __syncthreads();
-                    continue;
-                }
-                // PHASE_A: the region was sized by the setup kernel from the same pixel boxes, so this does not happen; if it ever
-                // did, the tile keeps the records it has (memory safe) and the launch says so (smil_raster_stats)
-                if (lane == 0) atomicAdd(&a.stats->guard_trips, 1u);
+            if (!fits) {  // wave-uniform: try again with half the pixels
+                span >>= 1;
+                __syncthreads();
+                continue;
             }
             if (lane == 0) scfirst[chunks_done] = (uint32_t)vbase;  // (chunks behind an early exit hold no records)
             STAT(21, vbase) STAT(26, 1) STAT(27, list_total) STAT(28, chunks_done) STAT(29, (list_total + DCHUNK - 1) / DCHUNK) STAT(30, __popcll(open_px))
@@ -1305,45 +1100,31 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
 #ifdef RASTER_EXPERIMENT
             if (a.stop_after == 1 || a.stop_after == 2) { p_lo += span; continue; }
 #endif
-            // the digit that holds the K-th smallest depth of every pixel with more than K candidates (counted by pass 1)
-            if (may_truncate && vbase > 0) {
-                need = K;
-                const int tot = pick_digit8(lds.hist, lane, b1, pre, need, n_eq);
-                trunc = tot > K;
-                if (!trunc) need = 0;
-            }
-            }  // pass 1
-            if constexpr (PHASE == PHASE_A) {  // hand the tile over to phase B
-                pixsel[lane] = make_uint2(pre, (uint32_t)need | ((uint32_t)n_eq << 8) | (trunc ? 0x80000000u : 0u));
-                if (lane == 0) {
-                    hdr->n_rec = (uint32_t)vbase; hdr->list_total = (uint32_t)list_total; hdr->chunks_done = (uint32_t)chunks_done;
-                    hdr->kmin = kmin; hdr->nbits0 = nbits0; hdr->b1 = b1; hdr->flags = may_truncate ? 1u : 0u;
-                }
-                __syncthreads();  // (LDS is reused by the next tile)
-                p_lo += span;
-                continue;
-            }
-            if constexpr (PHASE == PHASE_B) {
-                const uint2 ps_ = pixsel[lane];
-                pre = ps_.x; need = (int)(ps_.y & 0xFFu); n_eq = (int)((ps_.y >> 8) & 0x7FFFFFu); trunc = (ps_.y >> 31) != 0u;
-            }
-            if constexpr (PHASE != PHASE_A) {
+
             // ---------------- select + pass 2 ---------------------------------------------------------------------
             // K-th smallest depth of every pixel that has more than K candidates, and log2 of every kept blend factor summed
             // per pixel.  threshold: depth bits of the K-th smallest (0x7F800000 = +inf bits: keep everything); tie_cut: among
             // the faces exactly at the threshold those up to this list position are kept.
             uint32_t zt_bits = 0x7F800000u;
             int tie_cut = 0x7FFFFFFF;
-            int nbits = nbits0 - b1;
+            uint32_t pre = 0u;
+            int need = 0, n_eq = 0, nbits = nbits0 - b1;
+            bool trunc = false;
+            if (may_truncate && vbase > 0) {
+                need = K;
+                const int tot = pick_digit8(lds.hist, lane, b1, pre, need, n_eq);
+                trunc = tot > K;
+                if (!trunc) need = 0;
+            }
             const bool any_trunc = __ballot(trunc) != 0ull;
             // One sweep over all records.  A record of a pixel that is not truncated, or whose first digit is below the
             // pixel's chosen one, is kept for certain: its log goes to the pixel's sum.  One inside the chosen digit goes on
             // to the compact stream (with its log) and has its second digit counted; one above it is dropped.
             lds.plog[lane] = 0.0;
             lds.psel[lane] = make_uint2(pre, (uint32_t)need);
-            const int b2 = min(SB, nbits), shift2 = nbits - b2;
+            const int b2 = min(SEL_BITS, nbits), shift2 = nbits - b2;
             if (any_trunc)
-                for (int i_ = lane; i_ < HIST_WORDS; i_ += WAVE) lds.hist[i_] = 0u;
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
             int n_cmp = 0;
             float rmax2 = 0.f;  // largest |closest point - pixel|^2 over the records: bounds the gradient sums of pass 3
@@ -1394,14 +1175,14 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
             __syncthreads();
             if (any_trunc) {
                 if (nbits > 0) {  // second digit: counted above
-                    pick_digit<SB>(lds.hist, lane, b2, pre, need, n_eq);
+                    pick_digit(lds.hist, lane, b2, pre, need, n_eq);
                     nbits -= b2;
                     __syncthreads();
                 }
                 while (nbits > 0 && __ballot(need > 0) != 0ull) {
-                    const int b = min(SB, nbits);
+                    const int b = min(SEL_BITS, nbits);
                     n_cmp = refine_sweep(lds, crec, n_cmp, nbits, b, lane, pre, need);
-                    pick_digit<SB>(lds.hist, lane, b, pre, need, n_eq);
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
                     nbits -= b;
                     __syncthreads();
                 }
@@ -1420,9 +1201,9 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
                         return at(crec, idx).a == __float_as_uint(lds.pgrad[mt & 63u].y) ? lst[(mt >> 6) & 0xFFFFu] : 0xFFFFFFFFu;
                     };
                     while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
-                        const int b = min(SB, pbits);
+                        const int b = min(SEL_BITS, pbits);
                         select_sweep(lds, crec, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
-                        pick_digit<SB>(lds.hist, lane, b, ppre, pneed, peq);
+                        pick_digit(lds.hist, lane, b, ppre, pneed, peq);
                         pbits -= b;
                         __syncthreads();
                     }
@@ -1628,7 +1409,6 @@ __global__ void __launch_bounds__(64, PHASE == PHASE_B ? WAVES_B : WAVES_PER_SIM
             }
             __syncthreads();
             TMARK(4)
-            }  // select / blend / pass 3
             p_lo += span;
         }
 #ifdef DBG_TIMERS
@@ -1662,96 +1442,44 @@ static int device_cus() {
     return cus;
 }
 
-static int tile_grid(int N, int tiles_x, int per_cu = RESIDENT_PER_CU) {
+static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
-    long long resident = (long long)device_cus() * per_cu;
+    long long resident = (long long)device_cus() * RESIDENT_PER_CU;
 #ifdef RASTER_EXPERIMENT
-    if (const char *e = getenv("SMIL_RESIDENT")) resident = (long long)device_cus() * (atoi(e) > 0 && atoi(e) <= per_cu ? atoi(e) : per_cu);
+    if (const char *e = getenv("SMIL_RESIDENT")) resident = (long long)device_cus() * (atoi(e) > 0 && atoi(e) <= RESIDENT_PER_CU ? atoi(e) : RESIDENT_PER_CU);
 #endif
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup of the fused kernel: F x {face id, nearest depth} in id order, F face ids in walking order, F / DCHUNK + 2 chunk
-// starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record).  The phase-A kernel uses the id-order lists of
-// this arena, the phase-B kernel (which runs after it and before the fused kernel) its compact streams: the arena also covers
-// RESIDENT_B workgroups per CU with one compact stream each.
+// per resident workgroup: F x {face id, nearest depth} in id order, F face ids in walking order, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
 #define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
     return (size_t)grid * (3 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
-static inline size_t arena_bytes(int N, int tiles_x, int F) {
-    const size_t fused = scratch_bytes(tile_grid(N, tiles_x), F);
-    const size_t phase_b = (size_t)tile_grid(N, tiles_x, RESIDENT_B) * (REC_CAP + REC_PAD) * sizeof(Rec3);
-    return fused > phase_b ? fused : phase_b;
-}
-
-// Record pool of the split path: POOL_PAIRS_PER_FACE (face, pixel) pairs per face and image at 256^2, scaled with the image area,
-// at most POOL_MAX_BYTES; what does not fit is rendered by the fused kernel.  Launches below SPLIT_MIN_IMAGES have none.
-static inline size_t pool_bytes_per_image(const SmilModel *m, int S) {
-    const double scale = ((double)S / 256.0) * ((double)S / 256.0);
-    const double pairs = (double)m->F * POOL_PAIRS_PER_FACE * (scale < 0.25 ? 0.25 : scale);
-    return align256((size_t)(pairs * sizeof(Rec3)) + (size_t)16 * m->F);  // (+ the walking lists: ~4 tiles per face)
-}
-// process-wide routing knobs (smil_raster_configure): tests force the split path on small batches and starve the pool
-static int g_split_min_images = SPLIT_MIN_IMAGES;
-static size_t g_pool_max_bytes = (size_t)POOL_MAX_BYTES;
-extern "C" int smil_raster_configure(int32_t split_min_images, int64_t pool_max_bytes) {
-    g_split_min_images = split_min_images > 0 ? split_min_images : SPLIT_MIN_IMAGES;
-    g_pool_max_bytes = pool_max_bytes >= 0 ? (size_t)pool_max_bytes : (size_t)POOL_MAX_BYTES;
-    return SMIL_OK;
-}
-static inline size_t pool_bytes(const SmilModel *m, int N, int S) {
-    if (N < g_split_min_images || ceil_div(S, TILE) * ceil_div(S, TILE) > COUNT_TILES_MAX) return 0;
-    const size_t want = (size_t)N * pool_bytes_per_image(m, S);
-    return (want < g_pool_max_bytes ? want : g_pool_max_bytes) & ~(size_t)255;
-}
-// Images per call up to which the pool covers the whole budget (callers that slice large batches use it as the slice size).
-extern "C" int32_t smil_raster_split_images(const SmilModel *m, int32_t S) {
-    if (!m || S <= 0) return 0;
-    const size_t n = g_pool_max_bytes / pool_bytes_per_image(m, S);
-    return (int32_t)(n > 1000000 ? 1000000 : n);
-}
-
-struct WorkspaceLayout {
-    size_t tbox, ctr, ctr_f, stats, items, items_f, ibase, icap, fzr, gbox, img_bound, arena, pool, pool_size, total;
-    uint32_t item_cap;
-};
-static WorkspaceLayout workspace_layout(const SmilModel *m, int N, int S) {
-    WorkspaceLayout w;
-    const int tiles_x = ceil_div(S, TILE);
-    const size_t tiles = (size_t)tiles_x * tiles_x;
-    w.item_cap = (uint32_t)ceil_div(N, N_PARTS) * (uint32_t)tiles;
-    const size_t list_bytes = align256((size_t)2 * N_PARTS * w.item_cap * sizeof(uint32_t));
-    size_t o = 0;
-    w.tbox = o; o += align256((size_t)N * m->F * sizeof(uint32_t));
-    w.ctr = o; o += align256(sizeof(RasterCounters));     // (the probe tool reads the counters right behind the tile boxes)
-    w.ctr_f = o; o += align256(sizeof(RasterCounters));
-    w.stats = o; o += align256(sizeof(RasterStats));
-    w.items = o; o += list_bytes;
-    w.items_f = o; o += list_bytes;
-    w.ibase = o; o += list_bytes;
-    w.icap = o; o += list_bytes;
-    w.fzr = o; o += align256((size_t)N * m->F * sizeof(float2));
-    w.gbox = o; o += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
-    w.img_bound = o; o += align256((size_t)N * sizeof(float));
-    w.arena = o; o += align256(arena_bytes(N, tiles_x, m->F));
-    w.pool = o; w.pool_size = pool_bytes(m, N, S); o += w.pool_size;
-    w.total = o + 256;
-    return w;
-}
 
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
-    return workspace_layout(m, N, S).total;
+    const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
+    // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), per-workgroup scratch
+    return align256((size_t)N * m->F * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
+           align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint32_t)) +
+           align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) +
+           align256((size_t)N * sizeof(float)) + 256 +
+           scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
 
-// Counters of the most recent rasteriser call on this workspace (device -> host copy: synchronises the stream).
-extern "C" int smil_raster_stats(const SmilModel *m, int32_t N, int32_t S, const void *workspace, void *stream_, uint32_t *out8) {
-    SMIL_REQUIRE(m && workspace && out8 && N > 0 && S > 0, "smil_raster_stats: bad argument");
-    const WorkspaceLayout w = workspace_layout(m, N, S);
-    SMIL_HIP(hipMemcpyAsync(out8, (const char *)workspace + w.stats, sizeof(RasterStats), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+// Counters of the most recent rasteriser call that used `workspace` with this N (device -> host copy: synchronises the stream).
+extern "C" int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream_, uint32_t *out4) {
+    SMIL_REQUIRE(m && workspace && out4 && N > 0, "smil_raster_stats: bad argument");
+    const RasterCounters *ctr = (const RasterCounters *)((const char *)workspace + align256((size_t)N * m->F * sizeof(uint32_t)));
+    RasterCounters h;
+    SMIL_HIP(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     SMIL_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    unsigned int tiles = 0;
+    for (int q = 0; q < N_PARTS; ++q)
+        for (int c = 0; c < N_CLASSES; ++c) tiles += h.n_class[q][c];
+    out4[0] = h.straddling; out4[1] = tiles; out4[2] = 0; out4[3] = 0;
     return SMIL_OK;
 }
 
@@ -1766,46 +1494,43 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(m->F <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP);
     const int tiles_x = ceil_div(S, TILE);
     SMIL_REQUIRE((double)N * tiles_x * tiles_x < 2147483647.0, "raster: N * tiles exceeds the work-item index range (2^31); launch in slices");
-    const WorkspaceLayout w = workspace_layout(m, N, S);
     char *ws = (char *)workspace;
-    RasterCounters *ctr = (RasterCounters *)(ws + w.ctr), *ctr_f = (RasterCounters *)(ws + w.ctr_f);
-    RasterStats *stats = (RasterStats *)(ws + w.stats);
-    // (the two counter blocks and the statistics are adjacent: one fill)
-    SMIL_HIP(hipMemsetAsync(ctr, 0, w.items - w.ctr, stream));
+    uint32_t *tbox = (uint32_t *)ws;
+    ws += align256((size_t)N * m->F * sizeof(uint32_t));
+    RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
+    ws += align256(sizeof(RasterCounters));
+    uint32_t *items = (uint32_t *)ws;
+    const uint32_t item_cap = (uint32_t)ceil_div(N, N_PARTS) * (uint32_t)(tiles_x * tiles_x);
+    ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(uint32_t));
+    float2 *fzr = (float2 *)ws;
+    ws += align256((size_t)N * m->F * sizeof(float2));
+    uint32_t *gbox = (uint32_t *)ws;
+    ws += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
+    float *img_bound = (float *)ws;
+    ws += align256((size_t)N * sizeof(float));
+    SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
-    SetupArgs q;
-    q.verts_ndc = verts_ndc; q.faces = m->faces;
-    q.tbox = (uint32_t *)(ws + w.tbox); q.gbox = (uint32_t *)(ws + w.gbox); q.fzr = (float2 *)(ws + w.fzr);
-    q.items = (uint32_t *)(ws + w.items); q.items_f = (uint32_t *)(ws + w.items_f);
-    q.ibase = (uint32_t *)(ws + w.ibase); q.icap = (uint32_t *)(ws + w.icap); q.item_cap = w.item_cap;
-    q.ctr = ctr; q.ctr_f = ctr_f; q.stats = stats;
-    q.V = m->V; q.F = m->F; q.S = S; q.tiles_x = tiles_x; q.sqrt_blur = sqrt_blur; q.z_clip = rs->z_clip;
-    q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.img_bound = (float *)(ws + w.img_bound);
-    q.max_valence = m->max_valence;
-    q.pool_units = (uint32_t)(w.pool_size / POOL_UNIT);
-    const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? 2 * n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, q);
+    const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
+                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst, img_bound, m->max_valence);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
         a.list_stride = (int)(align256((size_t)m->F * sizeof(uint32_t)) / sizeof(uint32_t));
         a.n_cf = (int)(align256((size_t)(m->F / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
-        char *p = ws + w.arena;
-        a.crec_b = (Rec3 *)p;  // (phase B has finished before the fused kernel writes here)
-        a.slist = (uint2 *)p;
-        p += grid * (size_t)a.list_stride * sizeof(uint2);
-        a.slist2 = (uint32_t *)p;
-        p += grid * (size_t)a.list_stride * sizeof(uint32_t);
-        a.scfirst = (uint32_t *)p;
-        p += grid * (size_t)a.n_cf * sizeof(uint32_t);
-        const size_t stream_bytes = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3);
-        a.srec = (Rec3 *)p; p += stream_bytes;
-        a.crec = (Rec3 *)p;
+        ws += 256;
+        a.slist = (uint2 *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(uint2);
+        a.slist2 = (uint32_t *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
+        a.scfirst = (uint32_t *)ws;
+        ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
+        const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3);
+        a.srec = (Rec3 *)ws; ws += stream;
+        a.crec = (Rec3 *)ws;
     }
-    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = q.tbox; a.gbox = q.gbox; a.fzr = q.fzr; a.img_bound = q.img_bound; a.packed = 0;
-    a.items = q.items; a.items_f = q.items_f; a.ibase = q.ibase; a.icap = q.icap; a.item_cap = w.item_cap; a.ctr = ctr; a.ctr_f = ctr_f;
-    a.stats = stats; a.pool = w.pool_size ? ws + w.pool : nullptr;
+    a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
     a.dbg = nullptr;
@@ -1888,15 +1613,9 @@ extern "C" int smil_profile_read(float *total_ms, int32_t *launches) {
 #define PROF_END(stream) \
     if (_slot >= 0) (void)hipEventRecord(g_prof_ev[_slot][1], stream)
 
-// The tiles of the split lists go through the phase-A and phase-B kernels, those of the fused lists through the fused kernel
-// (an empty list costs a launch whose workgroups leave at once).
 template <int MODE>
 static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
-    if (a.pool) {
-        hipLaunchKernelGGL((k_raster_dense<MODE, PHASE_A>), dim3(tile_grid(N, a.tiles_x)), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL((k_raster_dense<MODE, PHASE_B>), dim3(tile_grid(N, a.tiles_x, RESIDENT_B)), dim3(64), 0, stream, a);
-    }
-    hipLaunchKernelGGL((k_raster_dense<MODE, PHASE_ALL>), dim3(tile_grid(N, a.tiles_x)), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((k_raster_dense<MODE>), dim3(tile_grid(N, a.tiles_x)), dim3(64), 0, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

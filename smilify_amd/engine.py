@@ -306,49 +306,28 @@ def fov_reduce(cams: CameraSet, d_fov_img: torch.Tensor) -> torch.Tensor:
 # part of the workspace; launches are cut into slices of this many images so that the workspace stays bounded at cfg5
 # scale (147 k images per GPU).  Each slice still holds millions of tiles.
 MAX_IMAGES_PER_LAUNCH = 16384
-SPLIT_MIN_IMAGES = 64  # raster.hip: from this many images per call the split tile kernels and their record pool are used
-
-RASTER_STAT_NAMES = ("pool_units", "images_fused", "tiles_fused", "tiles_split", "guard_trips", "straddling_faces")
 
 
-def raster_configure(split_min_images: int = 0, pool_max_bytes: int = -1) -> None:
-    """Routing knobs of the tile kernels (tests / experiments): see ``smil_raster_configure``."""
-    global SPLIT_MIN_IMAGES
-    _lib.check(_lib.load().smil_raster_configure(int(split_min_images), int(pool_max_bytes)), "smil_raster_configure")
-    SPLIT_MIN_IMAGES = int(split_min_images) if split_min_images > 0 else 64
+def _slices(N: int):
+    for n0 in range(0, N, MAX_IMAGES_PER_LAUNCH):
+        yield n0, min(N, n0 + MAX_IMAGES_PER_LAUNCH)
 
 
-def _slice_images(model: "DeviceModel", N: int, S: int) -> int:
-    """Images per rasteriser call: as many as the record pool of the split kernels covers (the rest of a call's images
-    would fall back to the slower fused kernel), at most MAX_IMAGES_PER_LAUNCH."""
-    if N < SPLIT_MIN_IMAGES:
-        return N
-    cover = int(_lib.load().smil_raster_split_images(model.handle, S))
-    return max(SPLIT_MIN_IMAGES, min(MAX_IMAGES_PER_LAUNCH, cover, N))
-
-
-def _slices(N: int, step: int = MAX_IMAGES_PER_LAUNCH):
-    for n0 in range(0, N, step):
-        yield n0, min(N, n0 + step)
-
-
-def raster_stats(model: "DeviceModel", N: int, S: int) -> dict:
-    """Counters of the last rasteriser call of ``model`` (of its last slice when the batch was cut): how its tiles were
-    routed, and the faces straddling z_clip (rendered unclipped; the reference would clip them)."""
-    step = _slice_images(model, N, S)
-    n = N - ((N - 1) // step) * step  # images of the last call: the workspace layout depends on it
-    out = (ctypes.c_uint32 * 8)()
-    _lib.check(_lib.load().smil_raster_stats(model.handle, n, S, _ptr(model._ws), _stream(), out), "smil_raster_stats")
-    return dict(zip(RASTER_STAT_NAMES, list(out)[:6]))
+def raster_stats(model: DeviceModel, N: int) -> dict:
+    """Counters of the last rasteriser call of ``model`` on ``N`` images (of its last slice when the batch was cut): faces
+    straddling z_clip (rendered whole; the reference would clip them) and touched tiles.  Synchronises."""
+    last = N - ((N - 1) // MAX_IMAGES_PER_LAUNCH) * MAX_IMAGES_PER_LAUNCH
+    out = (ctypes.c_uint32 * 4)()
+    _lib.check(_lib.load().smil_raster_stats(model.handle, last, _ptr(model._ws), _stream(), out), "smil_raster_stats")
+    return {"straddling_faces": int(out[0]), "tiles": int(out[1])}
 
 
 def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=None) -> torch.Tensor:
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     sil = torch.empty(N, S, S, dtype=torch.float32, device=verts_ndc.device)
-    step = _slice_images(model, N, S)
-    ws = model.workspace(step, S)
-    for n0, n1 in _slices(N, step):
+    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
+    for n0, n1 in _slices(N):
         _lib.check(_lib.load().smil_silhouette_forward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
                                                        _ptr(sil[n0:n1]), _ptr(ws), _stream()), "smil_silhouette_forward")
     return sil
@@ -358,9 +337,8 @@ def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, gra
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=verts_ndc.device)
-    step = _slice_images(model, N, S)
-    ws = model.workspace(step, S)
-    for n0, n1 in _slices(N, step):
+    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
+    for n0, n1 in _slices(N):
         _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
                                                         _ptr(grad_sil[n0:n1]), _ptr(d_ndc[n0:n1]), _ptr(ws), _stream()),
                    "smil_silhouette_backward")
@@ -377,11 +355,10 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
     if d_ndc is None:
         d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=dev)
     sil = torch.empty(N, S, S, dtype=torch.float32, device=dev) if want_sil else None
-    step = _slice_images(model, N, S)
-    ws = model.workspace(step, S)
+    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
     if target.dtype not in (torch.float32, torch.uint8):
         raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
-    for n0, n1 in _slices(N, step):
+    for n0, n1 in _slices(N):
         _lib.check(_lib.load().smil_silhouette_l1_fused(
             model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs), _ptr(target[n0:n1]), int(target.dtype == torch.uint8),
             _ptr(target_sum[n0:n1]), _ptr(pix_scale[n0:n1]), _ptr(loss_img[n0:n1]), _ptr(d_ndc[n0:n1]),

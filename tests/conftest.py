@@ -32,30 +32,6 @@ def _native_library_built():
         __graft_entry__.build()
 
 
-RASTER_ROUTES = ("auto", "split", "starved")
-
-
-def pytest_generate_tests(metafunc):
-    """Raster tests opt in (``usefixtures("raster_route")``) to run once per routing of the tile kernels: the product's own
-    choice (small batches: fused kernel), every tile through the split phase-A / phase-B kernels, and a pool so small that a
-    batch mixes both."""
-    if "raster_route" in metafunc.fixturenames:
-        metafunc.parametrize("raster_route", RASTER_ROUTES, indirect=True)
-
-
-@pytest.fixture
-def raster_route(request):
-    from smilify_amd import engine
-
-    route = request.param
-    if route == "split":
-        engine.raster_configure(split_min_images=1)
-    elif route == "starved":
-        engine.raster_configure(split_min_images=1, pool_max_bytes=3 << 20)
-    yield route
-    engine.raster_configure()
-
-
 def oracle_model(tables):
     """Dense fp32 torch tables for the oracle from the product's flat tables (test-side densify)."""
     m = dict(

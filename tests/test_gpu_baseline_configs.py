@@ -13,7 +13,7 @@ import torch
 from conftest import oracle_model
 from oracle import fitter_ref
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("raster_route")]
+pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 # (model, frames, views, S, camera radius) of BASELINE.json configs[2..4] (stand-in models: SURVEY.md 8(d))

@@ -6,7 +6,7 @@ import torch
 from conftest import MODEL_FILES, oracle_model
 from oracle import fitter_ref, lbs_ref, render_ref
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("raster_route")]
+pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 

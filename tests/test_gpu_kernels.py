@@ -168,7 +168,6 @@ RASTER_CASES = [("synthetic", 64, 2.2, 100), ("synthetic", 40, 2.2, 6), ("stick"
                 ("mouse", 64, 4.0, 100)]
 
 
-@pytest.mark.usefixtures("raster_route")
 @pytest.mark.parametrize("key,S,dist,K", RASTER_CASES)
 def test_silhouette_forward(key, S, dist, K, tables, dmodels):
     eng = _engine()
@@ -195,7 +194,6 @@ def test_silhouette_forward(key, S, dist, K, tables, dmodels):
     assert abs(got.sum() - ref1.sum()) / ref1.sum() < 1e-4
 
 
-@pytest.mark.usefixtures("raster_route")
 def test_truncation_rule_with_exact_ties(tables, dmodels):
     """K = 6 on the synthetic mesh: nearly every truncated pixel cuts through a group of faces at exactly the same depth
     (shared clipped vertices), so the outcome is decided by the tie rule alone: (depth, face id), as oracle mode 1."""
@@ -210,7 +208,6 @@ def test_truncation_rule_with_exact_ties(tables, dmodels):
     assert np.abs(got - ref1).max() < 2e-5, np.abs(got - ref1).max()
 
 
-@pytest.mark.usefixtures("raster_route")
 @pytest.mark.parametrize("key,S,dist,K", [("synthetic", 48, 2.2, 100), ("synthetic", 40, 2.2, 6), ("stick", 64, 2.7, 100)])
 def test_silhouette_backward_and_fused(key, S, dist, K, tables, dmodels):
     eng = _engine()

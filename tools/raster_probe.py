@@ -43,7 +43,6 @@ for it in range(args.reps + 1):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.reps
 if args.quick:
-    print("raster stats:", engine.raster_stats(dm, N, args.S))
     print(f"images {N}  time/launch {dt*1e3:.3f} ms  {dt/N*1e6:.2f} us/image  [SMIL_RESIDENT={os.environ.get('SMIL_RESIDENT')} SMIL_WRAP={os.environ.get('SMIL_WRAP')}]")
     sys.exit(0)
 ws = dm._ws

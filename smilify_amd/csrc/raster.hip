@@ -1059,7 +1059,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     const int p = (int)((__umul24(dy, (pk2 >> 17) & 7u) + rr + (pk2 >> 20)) & 63u);
                     const float2 pc = lds.pixt[p];
                     const float4 pt = make_float4(pc.x, pc.y, pc.x - cx, pc.y - cy);
+#ifdef ABL_GATHER  // timing experiment (garbage results): every lane reads the same face record (LDS broadcast, no conflicts)
+                    const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + (fs & 0) * FSTR);
+#else
                     const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FSTR);
+#endif
                     PairEval e;
                     eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
                     const bool cand = valid && e.cand && ((open_px >> p) & 1ull);
@@ -1068,18 +1072,27 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
                     // ... and never nearer than the face's nearest vertex (rounding of the convex combination), so that a record's
                     // digit is at least its face's: the closing rule above relies on it
+#ifdef ABL_DEPTH  // timing experiment (garbage results): no depth arithmetic
+                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(fr.z0), kmin), kmax)) : 3.0e38f;
+#else
                     const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(fmaxf(pair_depth(fr, e), fminf(fminf(fr.z0, fr.z1), fr.z2))), kmin), kmax)) : 3.0e38f;
+#endif
                     const uint32_t zb = __float_as_uint(z);
                     const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (cand) {
+#ifdef ABL_STORE  // timing experiment: one lane stores
+                        if (lane == 0)
+#endif
                         st_stream(srec, slot, Rec3{zb, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23),
                                                    __float_as_uint(e.sd)});
+#ifndef ABL_HIST  // (timing experiment: no per-pixel digit counts)
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
                             const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
                             uint32_t *const hw = &lds.hist[(bucket >> 2) * WAVE + p];
                             const uint32_t sh = 8u * (bucket & 3u);
                             if (((*hw >> sh) & 0xFFu) < SAT8) atomicAdd(hw, 1u << sh);
                         }
+#endif
                     }
                     vbase += __popcll(cm);
                 }

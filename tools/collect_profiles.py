@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src, dst = os.path.join(REPO, "gpurun_out", tag), os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
 for w in ("cfg2b", "cfg2", "cfg3", "cfg4", "cfg5s"):
@@ -26,8 +26,9 @@ for cfg, n_img in (("cfg2b", 4096), ("cfg3", 4608)):
     if not os.path.isdir(base):
         continue
     for name in ("fetch", "write", "sq"):
-        f = os.path.join(base, name, f"{name}_counter_collection.csv")
-        if os.path.exists(f):  # keep only the tile kernel's rows (the full file also lists every torch fill kernel)
+        found = [os.path.join(d, x) for d, _, fs in os.walk(os.path.join(base, name)) for x in fs if x.endswith("counter_collection.csv")]
+        f = found[0] if found else ""
+        if f:  # keep only the tile kernel's rows (the full file also lists every torch fill kernel)
             rows = [r for r in csv.DictReader(open(f)) if "k_raster" in r["Kernel_Name"]]
             with open(os.path.join(dst, f"{tag}_pmc_{name}_{cfg}.csv"), "w", newline="") as fh:
                 w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))

@@ -3,7 +3,7 @@
 # PMC passes of the fused tile kernel at the cfg2b / cfg3 launch sizes, small-batch latency.  Results under gpurun_out/<tag>/;
 # tools/pmc_summary.py + a copy into profiles/ follow on the build host.
 #   tools/measure_round.sh r2
-tag=${1:-r2}
+tag=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag; mkdir -p $out
 python bench.py > $out/bench_cfg2b.json 2> $out/bench_cfg2b.err; echo "bench cfg2b rc=$?"

@@ -13,18 +13,22 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, n_img = sys.argv[1], int(sys.argv[2])
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r2"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r3"
 base = os.path.join(REPO, "gpurun_out", f"pmc_{tag}")
 acc = collections.defaultdict(list)
 for name in ("fetch", "write", "sq"):
-    path = os.path.join(base, name, f"{name}_counter_collection.csv")
-    if not os.path.exists(path):
+    found = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(base, name)) for f in fs if f.endswith("counter_collection.csv")]
+    if not found:
         continue
+    path = found[0]
     for r in csv.DictReader(open(path)):
         if "k_raster_dense<2>" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             acc["_vgpr"].append(float(r["VGPR_Count"])); acc["_lds"].append(float(r["LDS_Block_Size"])); acc["_grid"].append(float(r["Grid_Size"]))
 mean = {k: sum(v) / len(v) for k, v in acc.items()}
+missing = [c for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU") if c not in mean]
+if missing:  # a partial set of passes must not become the bench line's `traffic`
+    raise SystemExit(f"pmc_summary: no rows for {missing} under {base}: all three passes of tools/pmc_traffic.sh are required")
 out_path = os.path.join(REPO, "profiles", f"{rnd}_traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 entry = {"source": f"rocprofv3 --pmc, separate passes (tools/pmc_traffic.sh {tag}); kernel k_raster_dense<2>, mean over {len(acc.get('FETCH_SIZE', []))} dispatches",

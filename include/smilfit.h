@@ -151,17 +151,21 @@ int smil_project(const SmilCameras *cam, const float *pts, int32_t P, float *ndc
 int smil_project2(const SmilCameras *cam, const float *pts_a, int32_t Pa, float *ndc_a, float *yx_a, const float *pts_b,
                   int32_t Pb, float *ndc_b, float *yx_b, void *stream);
 
-/* smil_project_backward for two point sets in one launch (d_pts of both overwritten; d_fov_img added to). */
+/* smil_project_backward for two point sets in one launch (d_pts of both overwritten; d_fov_img added to).  d_ndc_scale_a:
+ * as in smil_project_backward, for set a. */
 int smil_project_backward2(const SmilCameras *cam, const float *pts_a, int32_t Pa, const float *d_ndc_a, const float *d_yx_a,
                            float *d_pts_a, const float *pts_b, int32_t Pb, const float *d_ndc_b, const float *d_yx_b,
-                           float *d_pts_b, float *d_fov_img, void *stream);
+                           float *d_pts_b, float *d_fov_img, const float *d_ndc_scale_a, void *stream);
 
 /* Backward of smil_project.  d_ndc (N,P,2) and/or d_yx (N,P,2) -> d_pts (frames,P,3) (summed over
  * views; overwritten unless accumulate) and d_fov_img (N,): per-image raw sums
  * sum_p (d x_ndc * x_ndc + d y_ndc * y_ndc), ATOMICALLY ADDED (caller zeroes once, then may call this for
- * several point sets).  smil_fov_reduce turns them into d_fov (nFov,), overwritten. */
+ * several point sets).  smil_fov_reduce turns them into d_fov (nFov,), overwritten.
+ * d_ndc_scale (N,) or NULL: the per-image decode factors smil_silhouette_l1_fused returned with a d_ndc it left packed
+ * (> 0: the row is 64-bit packed fixed point, times this factor; 0: plain floats; < 0: a packed row of zeros). */
 int smil_project_backward(const SmilCameras *cam, const float *pts, int32_t P, const float *d_ndc,
-                          const float *d_yx, float *d_pts, float *d_fov_img, int32_t accumulate, void *stream);
+                          const float *d_yx, float *d_pts, float *d_fov_img, int32_t accumulate, const float *d_ndc_scale,
+                          void *stream);
 int smil_fov_reduce(const SmilCameras *cam, const float *d_fov_img, float *d_fov, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -199,13 +203,16 @@ int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t
  * loss_img[n]) / d ndc.  target_sum[n] = sum_px target (constant, computed once by the caller) lets
  * untouched tiles skip their target read.  target is (N,S,S) fp32, or uint8 holding binary {0,1} masks when
  * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL.
- * From 64 images per call on, d_ndc is accumulated as 64-bit packed fixed point in the same buffer and decoded in place
- * before the call's work ends on the stream: the caller always sees floats; the sums are then independent of the order in
- * which tiles finish (bit-reproducible), with an absolute resolution of about 2e-6 of an image's largest component. */
+ * From 64 images per call on (and an 8-byte aligned d_ndc), d_ndc is accumulated as 64-bit packed fixed point in the same
+ * buffer: the sums are then independent of the order in which tiles finish (bit-reproducible), with an absolute resolution of
+ * about 2e-6 of an image's largest component; smaller calls use float atomics (order-dependent last bits).
+ * d_ndc_scale == NULL: packed rows are decoded in place before the call's work ends on the stream - the caller always sees
+ * floats.  d_ndc_scale (N,) given: no decode pass; d_ndc_scale[n] says how image n's row is to be read (see
+ * smil_project_backward, which takes the pair as it is and decodes while it reads). */
 int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
                              const SmilRasterSettings *rs, const void *target, int32_t target_is_u8,
                              const float *target_sum, const float *pix_scale, float *loss_img, float *d_ndc,
-                             float *sil_out, void *workspace, void *stream);
+                             float *sil_out, float *d_ndc_scale, void *workspace, void *stream);
 
 /* Measurement hook (bench.py): when enabled, every launch of the tile kernel is bracketed by HIP events on its
  * launch stream; smil_profile_read synchronises those events and returns their summed duration + count. */

@@ -104,11 +104,11 @@ def load():
     lib.smil_lbs_backward.argtypes = [c_void_p, POINTER(LbsInputs), POINTER(LbsOutputs), POINTER(LbsGrads), c_void_p]
     lib.smil_project.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
     lib.smil_project_backward.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_int32, c_void_p]
+                                          c_int32, c_void_p, c_void_p]
     lib.smil_fov_reduce.argtypes = [POINTER(Cameras), c_void_p, c_void_p, c_void_p]
     lib.smil_project2.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
     lib.smil_project_backward2.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_void_p]
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.smil_fit_epilogue.argtypes = [POINTER(FitConfig)] + [c_void_p] * 12 + [c_int32, c_void_p, c_void_p, c_int32, POINTER(Cameras),
                                                                                  c_void_p, c_void_p, c_void_p]
     lib.smil_raster_workspace_bytes.argtypes = [c_void_p, c_int32, c_int32]
@@ -119,7 +119,7 @@ def load():
     lib.smil_silhouette_backward.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p,
                                              c_void_p, c_void_p, c_void_p]
     lib.smil_silhouette_l1_fused.argtypes = [c_void_p, c_void_p, c_int32, c_int32, POINTER(RasterSettings), c_void_p, c_int32,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.smil_prior_losses.argtypes = [POINTER(FitConfig)] + [c_void_p] * 12 + [c_int32, c_void_p]
     lib.smil_mask_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
     lib.smil_joint_loss.argtypes = [POINTER(FitConfig), c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -100,6 +100,9 @@ struct ProjectBwdSet {
     const float *pts, *d_ndc, *d_yx;  // (frames,P,3), (N,P,2) or NULL, (N,P,2) or NULL
     float *d_pts;                     // (frames,P,3)
     int P, blocks, accumulate;
+    // (N,) or NULL: rows of d_ndc the fused rasteriser left as packed fixed point (smil_silhouette_l1_fused, d_ndc_scale):
+    // > 0: (x, y) of a point are two 32-bit fixed-point numbers in one 64-bit word, times this factor; 0: plain floats
+    const float *d_ndc_scale;
 };
 
 // grid (frames, blocks of set 0 + blocks of set 1): each thread owns one world point and walks the views of its frame, so
@@ -130,7 +133,17 @@ __global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, ProjectBwdSe
             const float xn = vx * cp.k00 * iz, yn = vy * cp.k11 * iz;
             const size_t o = (size_t)n * P + p;
             float dxn = 0.f, dyn = 0.f;
-            if (s.d_ndc) { dxn = s.d_ndc[o * 2]; dyn = s.d_ndc[o * 2 + 1]; }
+            if (s.d_ndc) {
+                const float2 raw = reinterpret_cast<const float2 *>(s.d_ndc)[o];
+                const float sc = s.d_ndc_scale ? s.d_ndc_scale[n] : 0.f;
+                if (sc != 0.f) {  // x * 2^32 + y in two's complement: a negative y borrowed one from the high word
+                    const int qy = __float_as_int(raw.x), qx = __float_as_int(raw.y) - (qy >> 31);
+                    dxn = sc > 0.f ? (float)qx * sc : 0.f;
+                    dyn = sc > 0.f ? (float)qy * sc : 0.f;
+                } else {
+                    dxn = raw.x; dyn = raw.y;
+                }
+            }
             if (s.d_yx) {
                 const float h = 0.5f * (float)c.S;
                 dyn -= h * s.d_yx[o * 2];
@@ -156,11 +169,12 @@ __global__ void __launch_bounds__(256) k_project_bwd(SmilCameras c, ProjectBwdSe
 }
 
 extern "C" int smil_project_backward(const SmilCameras *cam, const float *pts, int32_t P, const float *d_ndc,
-                                     const float *d_yx, float *d_pts, float *d_fov_img, int32_t accumulate, void *stream) {
+                                     const float *d_yx, float *d_pts, float *d_fov_img, int32_t accumulate, const float *d_ndc_scale,
+                                     void *stream) {
     SMIL_REQUIRE(cam && pts, "smil_project_backward: null argument");
     SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && P > 0, "smil_project_backward: bad sizes");
     SMIL_REQUIRE(d_ndc || d_yx, "smil_project_backward: no upstream gradient");
-    const ProjectBwdSet s0 = {pts, d_ndc, d_yx, d_pts, P, ceil_div(P, 256), accumulate}, none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    const ProjectBwdSet s0 = {pts, d_ndc, d_yx, d_pts, P, ceil_div(P, 256), accumulate, d_ndc_scale}, none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
     hipLaunchKernelGGL(k_project_bwd, dim3(cam->N / cam->views, s0.blocks), dim3(256), 0, (hipStream_t)stream, *cam, s0, none, d_fov_img);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
@@ -168,11 +182,12 @@ extern "C" int smil_project_backward(const SmilCameras *cam, const float *pts, i
 
 extern "C" int smil_project_backward2(const SmilCameras *cam, const float *pts_a, int32_t Pa, const float *d_ndc_a, const float *d_yx_a,
                                       float *d_pts_a, const float *pts_b, int32_t Pb, const float *d_ndc_b, const float *d_yx_b,
-                                      float *d_pts_b, float *d_fov_img, void *stream) {
+                                      float *d_pts_b, float *d_fov_img, const float *d_ndc_scale_a, void *stream) {
     SMIL_REQUIRE(cam && pts_a && pts_b && d_pts_a && d_pts_b, "smil_project_backward2: null argument");
     SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N % cam->views == 0 && Pa > 0 && Pb > 0, "smil_project_backward2: bad sizes");
     SMIL_REQUIRE((d_ndc_a || d_yx_a) && (d_ndc_b || d_yx_b), "smil_project_backward2: no upstream gradient");
-    const ProjectBwdSet s0 = {pts_a, d_ndc_a, d_yx_a, d_pts_a, Pa, ceil_div(Pa, 256), 0}, s1 = {pts_b, d_ndc_b, d_yx_b, d_pts_b, Pb, ceil_div(Pb, 256), 0};
+    const ProjectBwdSet s0 = {pts_a, d_ndc_a, d_yx_a, d_pts_a, Pa, ceil_div(Pa, 256), 0, d_ndc_scale_a},
+                        s1 = {pts_b, d_ndc_b, d_yx_b, d_pts_b, Pb, ceil_div(Pb, 256), 0, nullptr};
     hipLaunchKernelGGL(k_project_bwd, dim3(cam->N / cam->views, s0.blocks + s1.blocks), dim3(256), 0, (hipStream_t)stream, *cam, s0, s1, d_fov_img);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;

@@ -189,6 +189,17 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
 
+// Packed gradient accumulation (fused entry point, large launches).  The flush of pass 3 goes to memory-side atomics (the
+// per-XCD L2s forward every atomic), whose cost is proportional to their number: (x, y) of a vertex travel as two 32-bit
+// fixed-point numbers in ONE 64-bit integer atomic instead of two float atomics.  The scale is a power of two per image,
+// chosen so that no vertex component can overflow: |sum| <= img_bound * |pix_scale| / sqrt(sigma) (see k_raster_setup) maps into
+// [2^29, 2^30].  Integer sums are order independent: the gradient becomes reproducible bit for bit.  k_unpack_dndc turns the
+// buffer into the (N,V,2) floats the interface promises, in place.
+__device__ __forceinline__ float image_fx_scale(float img_bound, float pix_scale, float inv_sigma) {
+    const float bound = img_bound * fabsf(pix_scale) * sqrtf(inv_sigma);
+    return (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
@@ -200,12 +211,14 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
                                                       uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
                                                       RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
                                                       float z_clip, float *__restrict__ d_ndc_zero, const float *__restrict__ loss_src,
-                                                      float *__restrict__ loss_dst, float *__restrict__ img_bound, int max_valence) {
+                                                      float *__restrict__ loss_dst, float *__restrict__ img_bound, int max_valence,
+                                                      float *__restrict__ dndc_scale, const float *__restrict__ pix_scale,
+                                                      float inv_sigma, int packed) {
     __shared__ uint32_t s_maxpx;  // largest blurred pixel box of a face
     __shared__ uint32_t s_straddle;
     if (threadIdx.x == 0) { s_maxpx = 0u; s_straddle = 0u; }
     uint32_t my_px = 0u, my_straddle = 0u;
-    extern __shared__ uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
+    extern __shared__ __align__(16) uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
     const int n = blockIdx.x;
     // the fused entry point's per-image initialisation rides along (saves a 100 MB memset and a copy launch per iteration):
     // the vertex gradient of this image starts at zero, its loss at sum |0 - target|
@@ -289,7 +302,14 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
     if (my_px) atomicMax(&s_maxpx, my_px);
     if (my_straddle) atomicAdd(&s_straddle, my_straddle);
     __syncthreads();
-    if (threadIdx.x == 0 && img_bound) img_bound[n] = 1.02f * 0.4f * (float)max_valence * (float)s_maxpx;
+    if (threadIdx.x == 0 && img_bound) {
+        const float bound = 1.02f * 0.4f * (float)max_valence * (float)s_maxpx;
+        img_bound[n] = bound;
+        if (dndc_scale) {  // what the consumer of a packed gradient row multiplies by (0: the row holds plain floats)
+            const float sc = packed ? image_fx_scale(bound, pix_scale[n], inv_sigma) : 0.f;
+            dndc_scale[n] = sc > 0.f ? 1.0f / sc : (packed ? -1.0f : 0.f);  // (-1: packed row that received nothing: decodes to zeros)
+        }
+    }
     if (threadIdx.x == 0 && s_straddle) atomicAdd(&ctr->straddling, s_straddle);
     // touched tiles -> the work list of their cost class
     __shared__ uint32_t s_cnt[N_CLASSES], s_base[N_CLASSES];
@@ -412,17 +432,6 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma_log2e) {
     // sigmoid(-dist / sigma) = 1 / (1 + 2^{dist log2(e) / sigma}); v_exp_f32 + v_rcp_f32 (1 ulp each), the two constant factors
     // of the exponent folded into one on the host
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sd * inv_sigma_log2e));
-}
-
-// Packed gradient accumulation (fused entry point, large launches).  The flush of pass 3 goes to memory-side atomics (the
-// per-XCD L2s forward every atomic), whose cost is proportional to their number: (x, y) of a vertex travel as two 32-bit
-// fixed-point numbers in ONE 64-bit integer atomic instead of two float atomics.  The scale is a power of two per image,
-// chosen so that no vertex component can overflow: |sum| <= img_bound * |pix_scale| / sqrt(sigma) (see k_raster_setup) maps into
-// [2^29, 2^30].  Integer sums are order independent: the gradient becomes reproducible bit for bit.  k_unpack_dndc turns the
-// buffer into the (N,V,2) floats the interface promises, in place.
-__device__ __forceinline__ float image_fx_scale(float img_bound, float pix_scale, float inv_sigma) {
-    const float bound = img_bound * fabsf(pix_scale) * sqrtf(inv_sigma);
-    return (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_unpack_dndc(float *__restrict__ d_ndc, const float *__restrict__ img_bound,
@@ -1498,7 +1507,8 @@ extern "C" int smil_raster_stats(const SmilModel *m, int32_t N, const void *work
 
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
                          void *workspace, hipStream_t stream, RasterArgs &a, float *d_ndc_zero = nullptr,
-                         const float *loss_src = nullptr, float *loss_dst = nullptr) {
+                         const float *loss_src = nullptr, float *loss_dst = nullptr, float *dndc_scale = nullptr,
+                         const float *pix_scale = nullptr, int packed = 0) {
     SMIL_REQUIRE(m && verts_ndc && rs && workspace, "raster: null argument");
     SMIL_REQUIRE(N > 0 && S > 0 && S <= TILE * 256, "raster: bad sizes N=%d S=%d", N, S);
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
@@ -1526,7 +1536,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     const int n_tiles = tiles_x * tiles_x;
     const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
-                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst, img_bound, m->max_valence);
+                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst, img_bound, m->max_valence,
+                       dndc_scale, pix_scale, 1.0f / rs->sigma, packed);
     SMIL_LAUNCH_CHECK();
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
@@ -1667,23 +1678,24 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
 extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
                                         const SmilRasterSettings *rs, const void *target, int32_t target_is_u8,
                                         const float *target_sum, const float *pix_scale, float *loss_img, float *d_ndc,
-                                        float *sil_out, void *workspace, void *stream_) {
+                                        float *sil_out, float *d_ndc_scale, void *workspace, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     RasterArgs a;
     SMIL_REQUIRE(target && target_sum && pix_scale && loss_img && d_ndc, "smil_silhouette_l1_fused: null argument");
-    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a, d_ndc, target_sum, loss_img);
+    // large launches accumulate the vertex gradients as packed fixed point (half the memory-side atomics); small ones keep float
+    // atomics.  The packed rows are decoded in place afterwards, unless the caller takes them as they are (d_ndc_scale).
+    const int packed = (N >= PACKED_MIN_IMAGES && (reinterpret_cast<uintptr_t>(d_ndc) & 7u) == 0u) ? 1 : 0;  // (64-bit atomics need 8-byte alignment)
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a, d_ndc, target_sum, loss_img, d_ndc_scale, pix_scale, packed);
     if (rc) return rc;
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
     if (target_is_u8) a.target_u8 = (const uint8_t *)target; else a.target = (const float *)target;
     a.pix_scale = pix_scale; a.loss_img = loss_img; a.d_ndc = d_ndc; a.sil = sil_out;
-    // large launches accumulate the vertex gradients as packed fixed point (half the memory-side atomics) and decode them in
-    // place afterwards; small ones keep float atomics and save the extra launch
-    a.packed = (N >= PACKED_MIN_IMAGES && (reinterpret_cast<uintptr_t>(d_ndc) & 7u) == 0u) ? 1 : 0;  // (64-bit atomics need 8-byte alignment)
+    a.packed = packed;
     PROF_BEGIN(stream);
     launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
-    if (a.packed) {
+    if (a.packed && !d_ndc_scale) {
         hipLaunchKernelGGL(k_unpack_dndc, dim3(N, ceil_div(m->V, 256)), dim3(256), 0, stream, d_ndc, a.img_bound, pix_scale, a.inv_sigma, m->V);
         SMIL_LAUNCH_CHECK();
     }

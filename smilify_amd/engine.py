@@ -242,7 +242,7 @@ def project(cams: CameraSet, pts: torch.Tensor, want_ndc=True, want_yx=True):
 
 
 def project_backward(cams: CameraSet, pts: torch.Tensor, d_ndc=None, d_yx=None, d_pts=None, d_fov_img=None,
-                     accumulate=False):
+                     accumulate=False, d_ndc_scale=None):
     frames, P = pts.shape[0], pts.shape[1]
     N = frames * cams.views
     if d_pts is None:
@@ -252,7 +252,7 @@ def project_backward(cams: CameraSet, pts: torch.Tensor, d_ndc=None, d_yx=None, 
         d_fov_img = torch.zeros(N, dtype=torch.float32, device=pts.device)
     c = cams.struct(N)
     _lib.check(_lib.load().smil_project_backward(ctypes.byref(c), _ptr(pts), P, _ptr(d_ndc), _ptr(d_yx), _ptr(d_pts),
-                                                 _ptr(d_fov_img), int(accumulate), _stream()), "smil_project_backward")
+                                                 _ptr(d_fov_img), int(accumulate), _ptr(d_ndc_scale), _stream()), "smil_project_backward")
     return d_pts, d_fov_img
 
 
@@ -268,14 +268,16 @@ def project_verts_and_joints(cams: CameraSet, verts: torch.Tensor, joints: torch
     return ndc, yx
 
 
-def project_backward_verts_and_joints(cams: CameraSet, verts, d_ndc, joints, d_yx, d_fov_img):
-    """One launch: the backward of ``project_verts_and_joints``; returns (d_verts, d_joints), adds to d_fov_img."""
+def project_backward_verts_and_joints(cams: CameraSet, verts, d_ndc, joints, d_yx, d_fov_img, d_ndc_scale=None):
+    """One launch: the backward of ``project_verts_and_joints``; returns (d_verts, d_joints), adds to d_fov_img.
+    ``d_ndc_scale``: the decode factors of a ``d_ndc`` the fused rasteriser left packed (``silhouette_l1_fused(packed_out=True)``)."""
     V, J = verts.shape[1], joints.shape[1]
     N = verts.shape[0] * cams.views
     d_verts, d_joints = torch.empty_like(verts), torch.empty_like(joints)
     c = cams.struct(N)
     _lib.check(_lib.load().smil_project_backward2(ctypes.byref(c), _ptr(verts), V, _ptr(d_ndc), None, _ptr(d_verts), _ptr(joints), J, None,
-                                                  _ptr(d_yx), _ptr(d_joints), _ptr(d_fov_img), _stream()), "smil_project_backward2")
+                                                  _ptr(d_yx), _ptr(d_joints), _ptr(d_fov_img), _ptr(d_ndc_scale), _stream()),
+               "smil_project_backward2")
     return d_verts, d_joints
 
 
@@ -346,7 +348,10 @@ def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, gra
 
 
 def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pix_scale, rs=None, want_sil=False,
-                        loss_img=None, d_ndc=None):
+                        loss_img=None, d_ndc=None, packed_out=False):
+    """Fused soft silhouette + L1 + backward.  Returns (loss_img, d_ndc, sil), or with ``packed_out`` (loss_img, d_ndc, sil,
+    d_ndc_scale): ``d_ndc`` as the kernel accumulated it (64-bit packed fixed point for large batches) plus the per-image
+    decode factors ``project_backward`` takes - this saves the decode pass over the whole gradient."""
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     dev = verts_ndc.device
@@ -355,6 +360,7 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
     if d_ndc is None:
         d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=dev)
     sil = torch.empty(N, S, S, dtype=torch.float32, device=dev) if want_sil else None
+    scale = torch.empty(N, dtype=torch.float32, device=dev) if packed_out else None
     ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
     if target.dtype not in (torch.float32, torch.uint8):
         raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
@@ -362,8 +368,9 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
         _lib.check(_lib.load().smil_silhouette_l1_fused(
             model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs), _ptr(target[n0:n1]), int(target.dtype == torch.uint8),
             _ptr(target_sum[n0:n1]), _ptr(pix_scale[n0:n1]), _ptr(loss_img[n0:n1]), _ptr(d_ndc[n0:n1]),
-            _ptr(None if sil is None else sil[n0:n1]), _ptr(ws), _stream()), "smil_silhouette_l1_fused")
-    return loss_img, d_ndc, sil
+            _ptr(None if sil is None else sil[n0:n1]), _ptr(None if scale is None else scale[n0:n1]), _ptr(ws), _stream()),
+            "smil_silhouette_l1_fused")
+    return (loss_img, d_ndc, sil, scale) if packed_out else (loss_img, d_ndc, sil)
 
 
 def image_abs_sum(images: torch.Tensor) -> torch.Tensor:

@@ -333,13 +333,16 @@ class SMALFitter(nn.Module):
                 tgt = self._sil_dev if idx is None else self._sil_dev.index_select(0, img_idx).contiguous()
                 tsum = self._sil_sum if idx is None else self._sil_sum.index_select(0, img_idx).contiguous()
                 pscale = self._pix_scale(fc, views, S)
-                loss_img, d_ndc, _ = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings)
+                # (the vertex gradient stays as the tile kernel accumulated it: the projection backward decodes it while it reads)
+                loss_img, d_ndc, _, d_ndc_scale = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings,
+                                                                             packed_out=True)
             if both:
-                d_verts, d_joints = engine.project_backward_verts_and_joints(cams, lbs["verts"], d_ndc, lbs["joints"], d_yx, d_fov_img)
+                d_verts, d_joints = engine.project_backward_verts_and_joints(cams, lbs["verts"], d_ndc, lbs["joints"], d_yx, d_fov_img,
+                                                                             d_ndc_scale=d_ndc_scale)
             elif w_j2d > 0:
                 d_joints, _ = engine.project_backward(cams, lbs["joints"], d_yx=d_yx, d_fov_img=d_fov_img)
             else:
-                d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img)
+                d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img, d_ndc_scale=d_ndc_scale)
             d_fov_sel = torch.empty(cams.fov.numel(), dtype=torch.float32, device=dev)
             # the shared shape gradient is accumulated straight into d_betas (where the shape prior adds its own)
             g_lbs = engine.lbs_backward(dm, lbs, d_verts, d_joints, need_beta=self.betas.requires_grad,

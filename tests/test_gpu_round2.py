@@ -264,6 +264,23 @@ def test_packed_gradient_atomics_match_float_atomics_and_are_reproducible(key, S
     assert np.abs(a[3]).max() == 0.0 and np.abs(c[3]).max() == 0.0
     per_img = np.abs(a - c).reshape(N, -1).max(1) / (np.abs(c).reshape(N, -1).max(1) + 1e-30)
     assert per_img.max() < 2e-5, per_img.max()
+    # the fit iteration's hand-off: the rows stay packed and the projection backward decodes them while it reads - bit for bit
+    # what the in-place decode pass followed by the plain projection backward gives (also for the weightless image and for a
+    # call below the packing threshold, whose rows are plain floats with factor 0)
+    _, dn_p, _, sc_p = eng.silhouette_l1_fused(dm, ndc, S, f._sil_dev, f._sil_sum, scale, packed_out=True)
+    assert float(sc_p.max()) > 0.0 and not torch.equal(dn_p, dn_a)
+    dv_a, fov_a = eng.project_backward(cams, lbs["verts"], d_ndc=dn_a)
+    dv_p, fov_p = eng.project_backward(cams, lbs["verts"], d_ndc=dn_p, d_ndc_scale=sc_p)
+    assert torch.equal(dv_a, dv_p)
+    np.testing.assert_allclose(fov_a.cpu().numpy(), fov_p.cpu().numpy(), rtol=1e-5)  # (block sums meet in float atomics)
+    _, dn_s, _, sc_s = eng.silhouette_l1_fused(dm, ndc[:32].contiguous(), S, f._sil_dev[:32].contiguous(), f._sil_sum[:32].contiguous(),
+                                               scale[:32].contiguous(), packed_out=True)
+    assert float(sc_s.abs().max()) == 0.0
+    cams32 = eng.CameraSet(cam.R[:32].contiguous() if cam.R.shape[0] == N else cam.R.contiguous(),
+                           cam.T[:32].contiguous() if cam.T.shape[0] == N else cam.T.contiguous(), f.fov.detach()[:32] if f.fov.numel() == N else f.fov.detach(), None, 1, S)
+    dv_s, _ = eng.project_backward(cams32, lbs["verts"][:32].contiguous(), d_ndc=dn_s, d_ndc_scale=sc_s)
+    dv_c, _ = eng.project_backward(cams32, lbs["verts"][:32].contiguous(), d_ndc=dn_c[:32].contiguous())
+    np.testing.assert_allclose(dv_s.cpu().numpy(), dv_c.cpu().numpy(), rtol=1e-4, atol=1e-9)  # (two float-atomic runs: order noise)
 
 
 def test_graph_replay_with_packed_gradients(tables):

@@ -254,7 +254,7 @@ def main():
         parity = parity_check(fitter, tables, wl, sample, window)
     fitter.begin_stage(synthetic.STAGE1_LR, fov_lr=1.0)
     staged = args.backend == "gloo"  # gloo: stage the (tiny) collective payloads through host memory
-    hook = (lambda shared, objs: optimize.allreduce_shared(shared, objs, host_staged=staged)) if world > 1 else None
+    hook = (lambda block: optimize.allreduce_block(block, host_staged=staged)) if world > 1 else None
 
     def step():
         hp = hn = None

@@ -177,8 +177,10 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
 
 def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=True, need_theta=True,
                  need_logscale=True, need_btrans=True, need_trans=True, need_vshaped=False,
-                 need_Rs=False, d_beta_accum: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
-    """``d_beta_accum`` (shared betas only): the sum over frames is ADDED to this (nB,) tensor instead of a fresh one."""
+                 need_Rs=False, d_beta_accum: Optional[torch.Tensor] = None, out_logscale: Optional[torch.Tensor] = None,
+                 out_btrans: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
+    """``d_beta_accum`` (shared betas only): the sum over frames is ADDED to this (nB,) tensor instead of a fresh one.
+    ``out_logscale`` / ``out_btrans`` (shared tables only): (J,3) buffers that receive those gradients (overwritten)."""
     dev = model.device
     inp, fl = saved["_inputs"], saved["_flags"]
     B, J = fl["B"], model.J
@@ -197,9 +199,9 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
     if need_theta and inp["theta"] is not None:
         g["d_theta"] = f(B, J, 3)
     if need_logscale and inp["logscale"] is not None and fl["allow_limb_scaling"]:
-        g["d_logscale"] = f(J, 3) if fl["logscale_shared"] else f(B, J, 3)
+        g["d_logscale"] = (out_logscale if out_logscale is not None else f(J, 3)) if fl["logscale_shared"] else f(B, J, 3)
     if need_btrans and inp["btrans"] is not None:
-        g["d_btrans"] = f(J, 3) if fl["btrans_shared"] else f(B, J, 3)
+        g["d_btrans"] = (out_btrans if out_btrans is not None else f(J, 3)) if fl["btrans_shared"] else f(B, J, 3)
     if need_trans:
         g["d_trans"] = f(B, 3)
     scratch = dict(d_A=f(B, J, 12), d_Jrest=f(B, J, 3), d_Rs=f(B, J, 9))

@@ -284,9 +284,18 @@ class SMALFitter(nn.Module):
                                self.trans.requires_grad)
         # everything the kernels ADD into lives in one buffer with one zero fill: loss terms, the shared shape gradient,
         # the per-image fov sums
+        # ... laid out so that everything ranks have to SUM sits in one contiguous "shared block" at the front: the loss terms,
+        # the shape gradient, the fov gradient when fov is shared, the scale-table gradients when the tables are shared
         n_img = n * views
-        arena = torch.zeros(N_OBJS + nB + n_img, dtype=torch.float32, device=dev)
-        objs, d_betas, d_fov_img = arena[:N_OBJS], arena[N_OBJS:N_OBJS + nB], arena[N_OBJS + nB:]
+        fov_n = self.fov.numel()
+        n_fov = fov_n if fov_n in (1, views) else 0  # (a per-image fov belongs to its rank: not in the block)
+        n_ls = 3 * J if (ls_shared and self.log_beta_scales.requires_grad) else 0
+        n_bt = 3 * J if (bt_shared and self.betas_trans.requires_grad) else 0
+        o_fov, o_ls, o_bt = N_OBJS + nB, N_OBJS + nB + n_fov, N_OBJS + nB + n_fov + n_ls
+        n_shared = o_bt + n_bt
+        arena = torch.zeros(n_shared + n_img, dtype=torch.float32, device=dev)
+        objs, d_betas, d_fov_img = arena[:N_OBJS], arena[N_OBJS:N_OBJS + nB], arena[n_shared:]
+        self.__dict__["_shared_block"] = arena[:n_shared]
 
         # cameras: one table row per view, per image or shared; fov may be the trainable parameter
         cam = self.renderer.cameras
@@ -343,12 +352,14 @@ class SMALFitter(nn.Module):
                 d_joints, _ = engine.project_backward(cams, lbs["joints"], d_yx=d_yx, d_fov_img=d_fov_img)
             else:
                 d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img, d_ndc_scale=d_ndc_scale)
-            d_fov_sel = torch.empty(cams.fov.numel(), dtype=torch.float32, device=dev)
-            # the shared shape gradient is accumulated straight into d_betas (where the shape prior adds its own)
+            d_fov_sel = arena[o_fov:o_ls] if (n_fov and cams.fov.numel() == n_fov) else torch.empty(cams.fov.numel(), dtype=torch.float32, device=dev)
+            # the shared shape gradient is accumulated straight into d_betas (where the shape prior adds its own); the shared
+            # scale tables' gradients land in their slots of the shared block
             g_lbs = engine.lbs_backward(dm, lbs, d_verts, d_joints, need_beta=self.betas.requires_grad,
                                         need_logscale=self.log_beta_scales.requires_grad,
                                         need_btrans=self.betas_trans.requires_grad, need_trans=self.trans.requires_grad,
-                                        d_beta_accum=d_betas)
+                                        d_beta_accum=d_betas, out_logscale=arena[o_ls:o_bt].view(J, 3) if n_ls else None,
+                                        out_btrans=arena[o_bt:n_shared].view(J, 3) if n_bt else None)
         if g_lbs is not None and g_lbs["d_theta"] is not None:
             d_pose = g_lbs["d_theta"]
             d_trans = g_lbs["d_trans"] if g_lbs["d_trans"] is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
@@ -365,7 +376,7 @@ class SMALFitter(nn.Module):
         if d_fov_sel is not None and (fov.numel() in (1, views) or idx is None):
             d_fov = d_fov_sel
         else:
-            d_fov = torch.zeros_like(fov)
+            d_fov = arena[o_fov:o_ls] if n_fov else torch.zeros_like(fov)
             if d_fov_sel is not None:  # per-image fov, window of frames: scatter the selected images' gradients
                 d_fov.index_add_(0, img_idx, d_fov_sel)
 
@@ -376,18 +387,18 @@ class SMALFitter(nn.Module):
             full.index_copy_(0, idx, rows)
             return full
 
-        def table_grad(g, shared, like):
-            if g is None:
-                return torch.zeros_like(like)
+        def table_grad(g, shared, like, slot):
+            if g is None:  # (a shared table keeps its - zero - slot of the shared block)
+                return slot.view(like.shape) if slot.numel() else torch.zeros_like(like)
             return g.reshape(like.shape) if shared else scatter(g, like)
 
         grads = dict(
             betas=d_betas if self.betas.requires_grad else None,
             pose=scatter(d_pose, self._pose),
             trans=scatter(d_trans, self.trans),
-            log_beta_scales=table_grad(g_lbs["d_logscale"] if g_lbs else None, ls_shared, self.log_beta_scales)
+            log_beta_scales=table_grad(g_lbs["d_logscale"] if g_lbs else None, ls_shared, self.log_beta_scales, arena[o_ls:o_bt])
             if self.log_beta_scales.requires_grad else None,
-            betas_trans=table_grad(g_lbs["d_btrans"] if g_lbs else None, bt_shared, self.betas_trans)
+            betas_trans=table_grad(g_lbs["d_btrans"] if g_lbs else None, bt_shared, self.betas_trans, arena[o_bt:n_shared])
             if self.betas_trans.requires_grad else None,
             fov=d_fov.reshape(self.fov.shape) if self.fov.requires_grad else None,
         )
@@ -468,10 +479,12 @@ class SMALFitter(nn.Module):
     def _param_tensor(self, name: str) -> torch.Tensor:
         return self._pose if name == "pose" else getattr(self, name).data
 
-    def apply_adam(self, grads: Dict[str, Optional[torch.Tensor]]):
-        """torch.optim.Adam(betas=(0.5,0.999)) semantics on every parameter that received a gradient."""
+    def apply_adam(self, grads: Dict[str, Optional[torch.Tensor]], advance: bool = True):
+        """torch.optim.Adam(betas=(0.5,0.999)) semantics on every parameter that received a gradient.  ``advance=False``:
+        a second group of the same optimiser step (the shared parameters, once their all-reduced gradient has arrived)."""
         h = self._adam_hyper
-        self._adam_step += 1
+        if advance:
+            self._adam_step += 1
         items = []
         for name, g in grads.items():
             if g is None:
@@ -489,14 +502,26 @@ class SMALFitter(nn.Module):
                  shared_grad_hook=None):
         """One epoch over all frames of this rank: losses + gradients + Adam.  Returns objs (10,) (device).
 
-        ``shared_grad_hook(dict of shared-parameter gradients)`` runs between backward and the optimiser step; the
-        multi-GPU driver all-reduces there."""
+        Several ranks: ``shared_grad_hook(block)`` receives the shared block - one contiguous tensor ``[10 loss terms | d_betas
+        | d_fov | shared scale-table gradients]`` - right after backward, sums it over the ranks IN PLACE and returns a handle
+        (``optimize.allreduce_block``).  The per-frame parameters take their Adam step while that collective is in flight;
+        the shared ones after ``handle.wait()``."""
         window = self.config.WINDOW_SIZE if window is None else window
         objs, grads = self._loss_and_grads(None, weights, w_temp, window=window, halo_prev=halo_prev, halo_next=halo_next)
-        if shared_grad_hook is not None:
-            shared = {k: v for k, v in grads.items() if v is not None and self._is_shared(k)}
-            shared_grad_hook(shared, objs)
-        self.apply_adam(grads)
+        if shared_grad_hook is None:
+            self.apply_adam(grads)
+            return objs
+        handle = shared_grad_hook(self._shared_block)
+        in_block = lambda g: g is not None and g.untyped_storage().data_ptr() == self._shared_block.untyped_storage().data_ptr()  # noqa: E731
+        local = {k: g for k, g in grads.items() if g is not None and not self._is_shared(k)}
+        shared = {k: g for k, g in grads.items() if g is not None and self._is_shared(k)}
+        stray = [k for k, g in shared.items() if not in_block(g)]
+        if stray:  # a shared gradient that does not live in the block (never the case for the layouts _loss_and_grads builds)
+            raise RuntimeError(f"shared gradients outside the shared block: {stray}")
+        self.apply_adam(local)
+        if handle is not None:
+            handle.wait()
+        self.apply_adam(shared, advance=False)
         return objs
 
     # ---- the same epoch as one hipGraph: ~40 kernel launches replayed with a single call --------------------
@@ -574,9 +599,11 @@ class SMALFitter(nn.Module):
         return False
 
     def boundary_rows(self):
-        """(first, last) parameter rows [pose, trans] of this shard for the temporal halo exchange."""
-        rows = torch.cat([self._pose.reshape(self.num_images, -1), self.trans.detach()], 1)
-        return rows[0].contiguous(), rows[-1].contiguous()
+        """(first, last) parameter rows [pose, trans] of this shard for the temporal halo exchange: two rows are sliced, the
+        parameter matrix is not touched."""
+        pose, trans = self._pose.detach(), self.trans.detach()
+        row = lambda i: torch.cat([pose[i].reshape(-1), trans[i].reshape(-1)])  # noqa: E731
+        return row(0), row(self.num_images - 1)
 
 
 class _TemporalTerm(torch.autograd.Function):

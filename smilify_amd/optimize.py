@@ -8,8 +8,9 @@ Image / mesh export of the reference driver is out of scope.
 
 Multi-GPU (one process per GPU, ``torch.distributed`` over RCCL): frames are split into contiguous shards
 aligned to ``WINDOW_SIZE`` so the sum over windows is a plain sum over ranks.  Per epoch there are two tiny
-collectives: an all-gather of each shard's first/last parameter row (temporal halo, 2 x (3J+3) floats per
-rank) and ONE all-reduce(SUM) of the flattened shared-parameter gradients + the 10 loss terms.
+exchanges: each shard's first / last parameter row goes to its neighbour ranks (temporal halo, (3J+3) floats each way,
+point to point) and ONE in-place all-reduce(SUM) of the fitter's shared block (10 loss terms + shared-parameter
+gradients), which runs beside the Adam update of the per-frame parameters.
 """
 from __future__ import annotations
 
@@ -59,31 +60,54 @@ def plan_shards(n_total: int, world: int, window: int) -> List[ShardPlan]:
 
 def exchange_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None,
                    host_staged: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """All-gather every shard's boundary rows; return (row before my first frame, row after my last frame).
-    ``host_staged`` moves the payload through host memory (gloo rehearsals); RCCL runs keep it on the device."""
+    """Temporal halo: every shard sends its first parameter row to the rank before it and its last row to
+    the rank after it - point-to-point, one batch of non-blocking sends / receives per rank; returns (row before my first
+    frame, row after my last frame).  ``host_staged`` moves the rows through host memory (gloo rehearsals); RCCL runs keep
+    them on the device."""
     if world == 1:
         return None, None
     dev = first_row.device
-    mine = torch.stack([first_row, last_row]).contiguous()
-    if host_staged:
-        mine = mine.cpu()
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    prev_row = gathered[rank - 1][1].to(dev).contiguous() if rank > 0 else None
-    next_row = gathered[rank + 1][0].to(dev).contiguous() if rank + 1 < world else None
-    return prev_row, next_row
+    stage = (lambda t: t.detach().cpu().contiguous()) if host_staged else (lambda t: t.detach().contiguous())
+    first, last = stage(first_row), stage(last_row)
+    prev_row = torch.empty_like(first) if rank > 0 else None
+    next_row = torch.empty_like(first) if rank + 1 < world else None
+    ops = []
+    if rank > 0:
+        ops += [dist.P2POp(dist.isend, first, rank - 1, group), dist.P2POp(dist.irecv, prev_row, rank - 1, group)]
+    if rank + 1 < world:
+        ops += [dist.P2POp(dist.isend, last, rank + 1, group), dist.P2POp(dist.irecv, next_row, rank + 1, group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    back = lambda t: None if t is None else t.to(dev)  # noqa: E731
+    return back(prev_row), back(next_row)
 
 
-def allreduce_shared(shared: Dict[str, torch.Tensor], objs: torch.Tensor, group=None, host_staged: bool = False) -> None:
-    """One fused all-reduce(SUM) over [shared-parameter gradients..., loss terms]; results written back in place."""
-    names = sorted(shared)
-    flat = torch.cat([shared[k].reshape(-1) for k in names] + [objs.reshape(-1)])
+class _Done:
+    def wait(self):
+        return None
+
+
+def allreduce_block(flat: torch.Tensor, group=None, host_staged: bool = False, async_op: bool = True):
+    """All-reduce(SUM) ONE contiguous tensor in place - the fitter's shared block ``[10 loss terms | d_betas | d_fov | shared
+    scale-table gradients]``, which the kernels already wrote next to each other (no concatenation, no copy back).
+    Returns a handle whose ``wait()`` orders the result before what the current stream does next; with ``async_op`` the
+    collective runs beside whatever is launched in between (the per-frame Adam update)."""
     if host_staged:
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        flat = host.to(flat.device)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return _Done()
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if work is not None else _Done()
+
+
+def allreduce_shared(shared: Dict[str, torch.Tensor], objs: torch.Tensor, group=None, host_staged: bool = False) -> None:
+    """All-reduce(SUM) of separately allocated tensors [shared-parameter gradients..., loss terms] through one fused buffer;
+    results written back in place.  (General form; ``SMALFitter.fit_step`` reduces its shared block in place with
+    ``allreduce_block``.)"""
+    names = sorted(shared)
+    flat = torch.cat([shared[k].reshape(-1) for k in names] + [objs.reshape(-1)])
+    allreduce_block(flat, group, host_staged, async_op=False).wait()
     o = 0
     for k in names:
         n = shared[k].numel()
@@ -133,13 +157,13 @@ def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, wo
     Single rank: every stage captures its iteration (losses, backward, Adam) once in a hipGraph and replays it per epoch
     (``SMALFitter.fit_step_graph``) - the device-side schedule of SURVEY.md 8(f) row 4; ``use_graph=False`` launches
     the kernels one by one instead (identical results).  Several ranks: the eager step, because the shared-parameter
-    gradients pass through the RCCL all-reduce between backward and the optimiser step."""
+    gradients pass through the RCCL all-reduce between backward and the optimiser step of the shared parameters."""
     cfg = fitter.config
     stages = stages or stages_from_config(cfg)
     full_vis = fitter.target_visibility.clone()
     hook = None
     if world > 1:
-        hook = lambda shared, objs: allreduce_shared(shared, objs, group)  # noqa: E731
+        hook = lambda block: allreduce_block(block, group)  # noqa: E731
     graph = use_graph and world == 1
     history = []
     for stage_id, st in enumerate(stages):

@@ -1,5 +1,5 @@
-"""Multi-rank path on CPU: shard planning, the temporal halo all-gather and the fused shared-gradient all-reduce,
-exercised with world_size 2 over gloo (the same functions run over RCCL on the GPUs)."""
+"""Multi-rank path on CPU: shard planning, the point-to-point temporal halo and the in-place all-reduce of the shared block,
+exercised with world_size 2 and 3 over gloo (the same functions run over RCCL on the GPUs)."""
 import os
 import socket
 
@@ -66,13 +66,20 @@ def _worker(rank, world, port, n_total, window, out_dir):
     # temporal term: pair (i, i+1) is owned by the rank holding i
     nxt = torch.cat([mine[1:], next_row[None]]) if next_row is not None else mine[1:]
     objs[6] = ((mine[: nxt.shape[0]] - nxt) ** 2).sum()
-    optimize.allreduce_shared(shared, objs)
-    np.save(os.path.join(out_dir, f"r{rank}.npy"), torch.cat([shared["betas"], shared["fov"], objs]).numpy())
+    # the fitter's layout: ONE contiguous block [loss terms | d_betas | d_fov], summed in place while other work proceeds
+    block = torch.cat([objs, shared["betas"], shared["fov"]])
+    handle = optimize.allreduce_block(block)
+    busy = mine.sum()  # (anything: stands for the per-frame Adam update that runs beside the collective)
+    handle.wait()
+    optimize.allreduce_shared(shared, objs)  # the general form over separate tensors gives the same sums
+    assert torch.allclose(block, torch.cat([objs, shared["betas"], shared["fov"]]), rtol=1e-6, atol=1e-6) and torch.isfinite(busy)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), torch.cat([block[10:13], block[13:14], block[:10]]).numpy())
     dist.destroy_process_group()
 
 
-def test_halo_exchange_and_shared_allreduce_gloo(tmp_path):
-    world, n_total, window = 2, 50, 10
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_and_shared_allreduce_gloo(tmp_path, world):
+    n_total, window = 50, 10
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_total, window, str(tmp_path)), nprocs=world, join=True)
     g = torch.Generator().manual_seed(0)

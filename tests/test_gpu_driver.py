@@ -160,10 +160,12 @@ objs = torch.arange(10.0, device=dev)
 want = {k: v.clone() for k, v in shared.items()}
 optimize.allreduce_shared(shared, objs)                  # device tensors through RCCL, as bench.py --gpus N does
 assert all(torch.equal(shared[k], want[k]) for k in shared) and torch.equal(objs, torch.arange(10.0, device=dev))
-mine = torch.stack([torch.ones(168, device=dev), 2 * torch.ones(168, device=dev)])
-got = [torch.empty_like(mine)]
-dist.all_gather(got, mine)                               # the halo exchange's collective
-assert torch.equal(got[0], mine)
+block = torch.arange(16.0, device=dev)                   # the fitter's shared block: summed in place, asynchronously
+h = optimize.allreduce_block(block)
+side = torch.ones(8, device=dev) * 2                     # (work launched beside the collective)
+h.wait()
+assert torch.equal(block, torch.arange(16.0, device=dev)) and float(side.sum()) == 16.0
+assert optimize.exchange_halos(torch.ones(168, device=dev), torch.ones(168, device=dev), 0, 1) == (None, None)
 t = torch.tensor([1.5], device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # the bench's max-over-ranks clock
 dist.barrier()
@@ -175,8 +177,8 @@ print("RCCL_OK")
 
 def test_rccl_collectives_of_the_sharded_path_run_on_device_tensors():
     """The box has one GPU, so RCCL is exercised with a one-rank group: backend "nccl" initialises, and the fused
-    all-reduce, the halo all-gather, the MAX reduce and the barrier of the multi-GPU path accept this build's device
-    tensors (the N > 1 arithmetic is covered by the gloo tests)."""
+    all-reduce (general and in-place asynchronous forms), the MAX reduce and the barrier of the multi-GPU path accept
+    this build's device tensors (the N > 1 arithmetic and the point-to-point halo are covered by the gloo tests)."""
     import subprocess
     import sys
 

@@ -589,6 +589,25 @@ class SMALFitter(nn.Module):
         self._graph = dict(key=self._graph_key(weights, w_temp, window), graph=graph, objs=objs, t_mirror=self._adam_step)
         return self._graph
 
+    def straddling_faces(self) -> int:
+        """Faces of the most recent silhouette launch with one or two vertices nearer than ``z_clip = znear / 2``.  pytorch3d's
+        ``clip_faces`` (left on by the reference's settings, p3d_renderer.py:36-47) cuts such a face at the plane and renders
+        the part in front; this library renders it whole, so a non-zero count means the silhouette term of that evaluation
+        deviated from the reference's - in practice the mesh has drifted into the camera.  Warns once per fitter.
+        Synchronises the stream (call it between stages, not per iteration)."""
+        if self.device_model._ws is None:
+            return 0
+        n = int(engine.raster_stats(self.device_model, self.num_images * self.views)["straddling_faces"])
+        if n and not self.__dict__.get("_warned_straddling"):
+            import warnings
+
+            self.__dict__["_warned_straddling"] = True
+            warnings.warn(f"{n} mesh faces straddle the camera's clipping plane (z_clip = znear / 2): they were rendered unclipped, "
+                          "where the reference (pytorch3d clip_faces) cuts them at the plane; the silhouette loss of this "
+                          "evaluation deviates from the reference. The mesh has probably drifted into the camera (check `trans`).",
+                          RuntimeWarning, stacklevel=2)
+        return n
+
     def _is_shared(self, name: str) -> bool:
         if name in ("betas",):
             return True

@@ -184,4 +184,5 @@ def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, wo
             history.append(objs)
             if on_epoch is not None:
                 on_epoch(stage_id, epoch, objs)
+        fitter.straddling_faces()  # once per stage (it synchronises): warns when the mesh has reached the camera's clipping plane
     return history

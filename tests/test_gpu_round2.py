@@ -175,6 +175,53 @@ def test_z_clip_culls_faces_entirely_nearer_than_half_znear(tables):
     assert ref0.sum() > 1.0 and np.abs(got - ref0).mean() < 1e-4
 
 
+def test_faces_straddling_z_clip_are_counted_and_the_fitter_warns(tables):
+    """pytorch3d's clip_faces would cut a face with one or two vertices nearer than z_clip at the plane; this library renders
+    it whole - but not silently: the setup kernel counts such faces per launch (smil_raster_stats) and the fitter warns."""
+    import warnings
+
+    from smilify_amd import engine as eng
+    from smilify_amd import synthetic
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S, N = 32, 3
+    g = torch.Generator().manual_seed(1)
+    ndc = torch.empty(N, t.V, 3)
+    ndc[..., :2] = 0.6 * (torch.rand(N, t.V, 2, generator=g) - 0.5)
+    ndc[..., 2] = 1.0 + torch.rand(N, t.V, generator=g)
+    eng.silhouette_forward(dm, ndc.to(DEV), S)
+    st = eng.raster_stats(dm, N)
+    assert st["straddling_faces"] == 0 and st["tiles"] > 0
+    ndc[1, 5, 2] = 2e-4                                                # one vertex of image 1 behind z_clip = 5e-4
+    ndc[2, 7, 2] = 1e-4
+    ndc[2, 9, 2] = 3e-4
+    want = sum(int(((ndc[n][torch.from_numpy(t.faces.astype(np.int64))][..., 2] < 5e-4).any(1)
+                    & ~(ndc[n][torch.from_numpy(t.faces.astype(np.int64))][..., 2] < 5e-4).all(1)).sum()) for n in range(N))
+    eng.silhouette_forward(dm, ndc.to(DEV), S)
+    got = eng.raster_stats(dm, N)["straddling_faces"]
+    # (a straddling face that is degenerate on screen is dropped before it is counted: allow a couple)
+    assert 0 < got <= want and got >= want - 2, (got, want)
+    # the fitter: a mesh pushed into the camera plane
+    f = synthetic.make_problem(t, 2, 1, S, DEV, radius=2.2, seed=3, window=2)
+    f.begin_stage(synthetic.STAGE1_LR)
+    f.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert f.straddling_faces() == 0
+    with torch.no_grad():
+        f.trans[:, 2] += 2.2 / 1.0  # towards the camera: the body now crosses z = 0
+        cam = f.renderer.cameras
+        # move along the viewing direction of camera 0 until the mesh centre sits on the camera plane
+        f.trans.copy_((-cam.T[0] @ cam.R[0].T).expand_as(f.trans))
+    f.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)
+    with pytest.warns(RuntimeWarning, match="straddle"):
+        assert f.straddling_faces() > 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                 # once per fitter
+        assert f.straddling_faces() > 0
+
+
 def test_renderer_topology_cache_is_keyed_by_content(tables):
     from smilify_amd.p3d_renderer import Renderer
     from smilify_amd.smal_torch import SMAL

@@ -187,8 +187,9 @@ size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
 
 /* Counters of the most recent rasteriser call that used `workspace` with the same N, copied to out4[4] (synchronises the
  * stream): [0] faces straddling z_clip (one or two vertices nearer than znear / 2).  pytorch3d's clip_faces would cut such a
- * face at the plane (p3d_renderer.py:36-47 leaves that default on); this library renders it whole, so a non-zero count says
- * the silhouettes of that call deviate from the reference's.  [1] touched 8x8 tiles.  [2], [3] reserved. */
+ * face at the plane and render the part in front (p3d_renderer.py:36-47 leaves that default on); this library renders it
+ * whole, or not at all when one of its vertices is nearer than 1e-8, so a non-zero count says the silhouettes of that call
+ * deviate from the reference's.  [1] touched 8x8 tiles.  [2], [3] reserved. */
 int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream, uint32_t *out4);
 
 /* verts_ndc (N,V,3) -> sil (N,S,S) */

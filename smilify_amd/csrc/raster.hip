@@ -248,8 +248,10 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
             const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
             // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
             // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split.
+            // counted for smil_raster_stats: clip_faces() would cut a face that crosses z_clip at the plane and keep the front part;
+            // here it is rendered whole, or dropped entirely when a vertex is nearer than 1e-8 (the rule below)
+            if (finite && zmin < z_clip && !(zmax < z_clip)) ++my_straddle;
             if (finite && !(zmin < K_EPS) && !(zmax < z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
-                if (zmin < z_clip) ++my_straddle;  // clip_faces() would cut this face at z_clip; it is rendered whole (counted)
                 const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
                 const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
                 // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)

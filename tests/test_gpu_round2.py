@@ -200,8 +200,7 @@ def test_faces_straddling_z_clip_are_counted_and_the_fitter_warns(tables):
                     & ~(ndc[n][torch.from_numpy(t.faces.astype(np.int64))][..., 2] < 5e-4).all(1)).sum()) for n in range(N))
     eng.silhouette_forward(dm, ndc.to(DEV), S)
     got = eng.raster_stats(dm, N)["straddling_faces"]
-    # (a straddling face that is degenerate on screen is dropped before it is counted: allow a couple)
-    assert 0 < got <= want and got >= want - 2, (got, want)
+    assert got == want > 0, (got, want)
     # the fitter: a mesh pushed into the camera plane
     f = synthetic.make_problem(t, 2, 1, S, DEV, radius=2.2, seed=3, window=2)
     f.begin_stage(synthetic.STAGE1_LR)

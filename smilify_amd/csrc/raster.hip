@@ -128,7 +128,8 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #ifndef SPLIT0_LOG
 #define SPLIT0_LOG 0          // log2 of the pieces every class-0 tile is dealt out in (0: whole; with near-to-far lists and closing the
 #endif                        // tiles with the longest lists finish early, and pieces only repeat their list walk: measured 2 -> 0: mouse -9 %)
-#define COUNT_TILES_MAX 8192  // per-tile face counts live in LDS (4 bytes each); larger images queue everything in the last class
+#define COUNT_TILES_MAX 4096  // per-tile cost / entry counts and list cursors live in LDS (12 bytes per tile); larger images (S > 512) queue
+                              // everything in the last class and build their lists in the tile kernel
 // XCD-aware dealing.  Each of the 8 XCDs of an MI355X has its own 4 MB L2, and the tiles of one image read the same
 // per-image tables (projected vertices, face tile boxes, depth ranges: ~180 KB on STICK).  Images are therefore dealt to
 // N_PARTS work-list partitions (image % N_PARTS); a workgroup drains the partition of the XCD it runs on first
@@ -165,7 +166,10 @@ struct RasterArgs {
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
     // scratch per resident workgroup
-    uint2 *slist;            // the current tile's faces in ascending id: {face id, bits of its nearest vertex depth} ...
+    const Rec3 *lists;       // (N, list_cap) tile lists binned by the setup kernel: {face id, bits of its nearest / farthest vertex depth}
+    const uint2 *tdesc;      // (N, tiles) {first entry, entries} of a tile's binned list; entries = 0xFFFFFFFF: build it here
+    uint32_t list_cap;
+    Rec3 *slist;             // the current tile's faces when it builds its list itself (ascending id; same entry layout) ...
     uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may
                              // truncate (the sort reads the depths it needs from slist instead of gathering them per face)
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
@@ -200,60 +204,117 @@ __device__ __forceinline__ float image_fx_scale(float img_bound, float pix_scale
     return (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
 }
 
+// Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
+// VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
+#ifdef RASTER_EXPERIMENT  // tools/dbg experiments only: wrap every stream index (results are garbage, timing is not)
+__constant__ uint32_t g_wrap_mask = 0xFFFFFFFFu;
+#define WRAP_IDX(i) ((i) & g_wrap_mask)
+#else
+#define WRAP_IDX(i) (i)
+#endif
+// (12-byte elements: the index is below 2^24, so the full-rate 24-bit multiply is exact; left to itself hipcc emits the
+// quarter-rate v_mul_lo_u32, also for the shift-and-add spelling)
+template <typename T>
+__device__ __forceinline__ uint32_t byte_offset(uint32_t i) {
+    if (sizeof(T) == 12) {
+        uint32_t r;
+        asm("v_mul_u32_u24 %0, %1, 12" : "=v"(r) : "v"(i));
+        return r;
+    }
+    return i * (uint32_t)sizeof(T);
+}
+template <typename T>
+__device__ __forceinline__ T &at(T *base, uint32_t i) {
+    i = WRAP_IDX(i);
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset<T>(i));
+}
+template <typename T>
+__device__ __forceinline__ const T &at(const T *base, uint32_t i) {
+    i = WRAP_IDX(i);
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset<T>(i));
+}
+
+// inclusive wave64 prefix sum in DPP (row_shr within 16-lane rows, then row_bcast across rows)
+__device__ __forceinline__ int wave_scan_add(int x) {
+#define SCAN_STEP(ctrl, rows) { x += __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); }
+    SCAN_STEP(0x111, 0xF) SCAN_STEP(0x112, 0xF) SCAN_STEP(0x114, 0xF) SCAN_STEP(0x118, 0xF)
+    SCAN_STEP(0x142, 0xA) SCAN_STEP(0x143, 0xC)
+#undef SCAN_STEP
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // setup: per-face tile boxes + touched-tile work list
 // ---------------------------------------------------------------------------------------------
 #ifndef SETUP_THREADS
 #define SETUP_THREADS 1024
 #endif
-__global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__restrict__ verts_ndc, const int *__restrict__ faces,
-                                                      uint32_t *__restrict__ tbox, uint32_t *__restrict__ gbox,
-                                                      uint32_t *__restrict__ items, uint32_t item_cap, float2 *__restrict__ fzr,
-                                                      RasterCounters *ctr, int V, int F, int S, int tiles_x, float sqrt_blur,
-                                                      float z_clip, float *__restrict__ d_ndc_zero, const float *__restrict__ loss_src,
-                                                      float *__restrict__ loss_dst, float *__restrict__ img_bound, int max_valence,
-                                                      float *__restrict__ dndc_scale, const float *__restrict__ pix_scale,
-                                                      float inv_sigma, int packed) {
+#ifndef LIST_CAP_PER_FACE
+#define LIST_CAP_PER_FACE 8   // (tile, face) list entries an image may have per face (a face's blurred box covers ~4 tiles)
+#endif
+struct SetupArgs {
+    const float *verts_ndc; const int *faces;
+    uint32_t *tbox, *gbox, *items; uint32_t item_cap; float2 *fzr;
+    RasterCounters *ctr;
+    int V, F, S, tiles_x; float sqrt_blur, z_clip;
+    float *d_ndc_zero; const float *loss_src; float *loss_dst; float *img_bound; int max_valence;
+    float *dndc_scale; const float *pix_scale; float inv_sigma; int packed;
+    Rec3 *lists;        // (N, list_cap) binned tile lists: {face id, bits of its nearest / farthest vertex depth}
+    uint2 *tdesc;       // (N, tiles) {first entry, entries} of every tile's list; entries = 0xFFFFFFFF: not binned (the tile kernel builds it)
+    uint32_t list_cap;  // entries per image (0: no binning)
+};
+// One workgroup per image.  Pass 1: per face validity, blurred pixel box -> tile box, depth range; per covered tile ONE LDS
+// atomic adds the face's cost and list entry (64-bit: entries << 32 | cost).  Then the touched tiles go to the work lists by cost
+// class and - new in round 3 - the faces are BINNED: a prefix sum over the tiles' entry counts lays the image's tile lists
+// end to end, and pass 2 walks the faces again and appends each to the lists of the tiles its box covers.  The tile kernel
+// then starts from its list instead of scanning the tile boxes of every 64-face group that reaches its tile (build_list:
+// 13 % of the tile kernel in round 2).  Images whose lists exceed list_cap keep the old way.
+__global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
     __shared__ uint32_t s_maxpx;  // largest blurred pixel box of a face
     __shared__ uint32_t s_straddle;
     if (threadIdx.x == 0) { s_maxpx = 0u; s_straddle = 0u; }
     uint32_t my_px = 0u, my_straddle = 0u;
-    extern __shared__ __align__(16) uint32_t tcnt[];  // cost per tile (counted), or a touched-tile bitmap when the image has too many tiles
+    // per tile: entries << 32 | cost (counted), or a touched-tile bitmap when the image has too many tiles; behind it the tiles'
+    // list cursors
+    extern __shared__ __align__(16) unsigned long long tcnt64[];
     const int n = blockIdx.x;
+    const int V = q.V, F = q.F, S = q.S, tiles_x = q.tiles_x;
     // the fused entry point's per-image initialisation rides along (saves a 100 MB memset and a copy launch per iteration):
     // the vertex gradient of this image starts at zero, its loss at sum |0 - target|
-    if (d_ndc_zero) {
-        float2 *z = reinterpret_cast<float2 *>(d_ndc_zero) + (size_t)n * V;
+    if (q.d_ndc_zero) {
+        float2 *z = reinterpret_cast<float2 *>(q.d_ndc_zero) + (size_t)n * V;
         for (int i = threadIdx.x; i < V; i += blockDim.x) z[i] = make_float2(0.f, 0.f);
     }
-    if (loss_dst && threadIdx.x == 0) loss_dst[n] = loss_src[n];
+    if (q.loss_dst && threadIdx.x == 0) q.loss_dst[n] = q.loss_src[n];
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
-    const int n_words = counted ? n_tiles : (n_tiles + 31) >> 5;
-    for (int i = threadIdx.x; i < n_words; i += blockDim.x) tcnt[i] = 0u;
+    uint32_t *const tbits = reinterpret_cast<uint32_t *>(tcnt64);        // (!counted) touched-tile bitmap
+    uint32_t *const tcur = reinterpret_cast<uint32_t *>(tcnt64 + n_tiles);  // (counted) list cursor of every tile
+    if (counted) { for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) tcnt64[i] = 0ull; }
+    else { for (int i = threadIdx.x; i < (n_tiles + 31) >> 5; i += blockDim.x) tbits[i] = 0u; }
     __syncthreads();
-    const float *vn = verts_ndc + (size_t)n * V * 3;
+    const float *vn = q.verts_ndc + (size_t)n * V * 3;
     const float fS = (float)S;
     const int n_groups = (F + WAVE - 1) / WAVE;
     for (int f0 = 0; f0 < F; f0 += blockDim.x) {  // every wave handles 64 consecutive faces per round
         const int f = f0 + threadIdx.x;
         uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
         if (f < F) {
-            const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+            const int i0 = q.faces[3 * f], i1 = q.faces[3 * f + 1], i2 = q.faces[3 * f + 2];
             const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
             const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
             const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
             const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
             const float area = edge_fn(x0, y0, x1, y1, x2, y2);
             const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
-            // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
-            // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split (DESIGN.md).
             // counted for smil_raster_stats: clip_faces() would cut a face that crosses z_clip at the plane and keep the front part;
             // here it is rendered whole, or dropped entirely when a vertex is nearer than 1e-8 (the rule below)
-            if (finite && zmin < z_clip && !(zmax < z_clip)) ++my_straddle;
-            if (finite && !(zmin < K_EPS) && !(zmax < z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
-                const float xlo = fminf(fminf(x0, x1), x2) - sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
-                const float ylo = fminf(fminf(y0, y1), y2) - sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
+            if (finite && zmin < q.z_clip && !(zmax < q.z_clip)) ++my_straddle;
+            // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
+            // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split (DESIGN.md).
+            if (finite && !(zmin < K_EPS) && !(zmax < q.z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
+                const float xlo = fminf(fminf(x0, x1), x2) - q.sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + q.sqrt_blur;
+                const float ylo = fminf(fminf(y0, y1), y2) - q.sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + q.sqrt_blur;
                 // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
                 // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides
                 int xi_lo = (int)ceilf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
@@ -270,24 +331,20 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
                     for (int ty = ty0; ty <= ty1; ++ty)
                         for (int tx = tx0; tx <= tx1; ++tx) {
                             const int t = ty * tiles_x + tx;
-                            if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it
+                            if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it; one list entry
                                 const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
                                 const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
-#ifdef SETUP_NO_COUNT  // timing experiment only: how much of the setup kernel is the LDS atomics
-                                if (f == 0) atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
-#else
-                                atomicAdd(&tcnt[t], (uint32_t)(wx * wy + 8));
-#endif
+                                atomicAdd(&tcnt64[t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));
                             } else {
-                                atomicOr(&tcnt[t >> 5], 1u << (t & 31));
+                                atomicOr(&tbits[t >> 5], 1u << (t & 31));
                             }
                         }
                 }
             }
-            tbox[(size_t)n * F + f] = box;
-            fzr[(size_t)n * F + f] = make_float2(zmin, zmax);
+            q.tbox[(size_t)n * F + f] = box;
+            q.fzr[(size_t)n * F + f] = make_float2(zmin, zmax);
         }
-        // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test
+        // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test (images that are not binned)
         int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
         for (int o = 32; o > 0; o >>= 1) {
             gx0 = min(gx0, __shfl_xor(gx0, o, WAVE)); gy0 = min(gy0, __shfl_xor(gy0, o, WAVE));
@@ -295,7 +352,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
         }
         const int grp = (f0 + (int)threadIdx.x) / WAVE;
         if ((threadIdx.x & (WAVE - 1)) == 0 && grp < n_groups)
-            gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
+            q.gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
     // Bound on what one vertex component of this image can receive from pass 3, up to the factor |upstream gradient| /
     // sqrt(sigma): a kept record of probability p = sigmoid(-+r^2 / sigma) adds at most 2 r p alpha |g| / sigma to an end point,
@@ -304,49 +361,80 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(const float *__r
     if (my_px) atomicMax(&s_maxpx, my_px);
     if (my_straddle) atomicAdd(&s_straddle, my_straddle);
     __syncthreads();
-    if (threadIdx.x == 0 && img_bound) {
-        const float bound = 1.02f * 0.4f * (float)max_valence * (float)s_maxpx;
-        img_bound[n] = bound;
-        if (dndc_scale) {  // what the consumer of a packed gradient row multiplies by (0: the row holds plain floats)
-            const float sc = packed ? image_fx_scale(bound, pix_scale[n], inv_sigma) : 0.f;
-            dndc_scale[n] = sc > 0.f ? 1.0f / sc : (packed ? -1.0f : 0.f);  // (-1: packed row that received nothing: decodes to zeros)
+    if (threadIdx.x == 0 && q.img_bound) {
+        const float bound = 1.02f * 0.4f * (float)q.max_valence * (float)s_maxpx;
+        q.img_bound[n] = bound;
+        if (q.dndc_scale) {  // what the consumer of a packed gradient row multiplies by (0: the row holds plain floats)
+            const float sc = q.packed ? image_fx_scale(bound, q.pix_scale[n], q.inv_sigma) : 0.f;
+            q.dndc_scale[n] = sc > 0.f ? 1.0f / sc : (q.packed ? -1.0f : 0.f);  // (-1: packed row that received nothing: decodes to zeros)
         }
     }
-    if (threadIdx.x == 0 && s_straddle) atomicAdd(&ctr->straddling, s_straddle);
+    if (threadIdx.x == 0 && s_straddle) atomicAdd(&q.ctr->straddling, s_straddle);
     // touched tiles -> the work list of their cost class
-    __shared__ uint32_t s_cnt[N_CLASSES], s_base[N_CLASSES];
+    __shared__ uint32_t s_cnt[N_CLASSES], s_base[N_CLASSES], s_ents[SETUP_THREADS / WAVE], s_binned;
     if (threadIdx.x < N_CLASSES) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     auto tile_class = [&](int t) -> int {  // -1: untouched
-        if (!counted) return ((tcnt[t >> 5] >> (t & 31)) & 1u) ? N_CLASSES - 1 : -1;
-        const uint32_t c = tcnt[t];
+        if (!counted) return ((tbits[t >> 5] >> (t & 31)) & 1u) ? N_CLASSES - 1 : -1;
+        const uint32_t c = (uint32_t)tcnt64[t];
         return c == 0u ? -1 : (c >= CLASS_T0 ? 0 : (c >= CLASS_T1 ? 1 : (c >= CLASS_T2 ? 2 : 3)));
     };
     uint32_t mine[N_CLASSES] = {0u, 0u, 0u, 0u};
+    uint32_t my_ents = 0u;  // list entries of this thread's tiles (t = thread, thread + block, ...)
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int c = tile_class(t);
 #pragma unroll
         for (int k = 0; k < N_CLASSES; ++k) mine[k] += (c == k) ? 1u : 0u;
+        if (counted) my_ents += (uint32_t)(tcnt64[t] >> 32);
     }
     uint32_t off[N_CLASSES];
 #pragma unroll
     for (int k = 0; k < N_CLASSES; ++k) off[k] = mine[k] ? atomicAdd(&s_cnt[k], mine[k]) : 0u;
+    // lists end to end: exclusive prefix of the entry counts over the block (thread order, each thread's tiles consecutive)
+    const uint32_t incl = (uint32_t)wave_scan_add((int)my_ents);
+    if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) s_ents[threadIdx.x / WAVE] = incl;
     __syncthreads();
+    uint32_t ent_off = incl - my_ents;
+    for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) ent_off += s_ents[w];
+    if (threadIdx.x == blockDim.x - 1) s_binned = (counted && q.list_cap != 0u && ent_off + my_ents <= q.list_cap) ? 1u : 0u;
     const int part = n % N_PARTS;
-    if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr->n_class[part][threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&q.ctr->n_class[part][threadIdx.x], s_cnt[threadIdx.x]) : 0u;
     __syncthreads();
+    const bool binned = s_binned != 0u;
 #pragma unroll
     for (int k = 0; k < N_CLASSES; ++k) off[k] += s_base[k];
+    uint32_t run = ent_off;
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int c = tile_class(t);
+        if (q.tdesc) {
+            const uint32_t e = counted ? (uint32_t)(tcnt64[t] >> 32) : 0u;
+            q.tdesc[(size_t)n * n_tiles + t] = binned ? make_uint2(run, e) : make_uint2(0u, 0xFFFFFFFFu);
+            if (binned) tcur[t] = run;
+            run += e;
+        }
         if (c < 0) continue;
         uint32_t slot = 0u;
 #pragma unroll
         for (int k = 0; k < N_CLASSES; ++k)
             if (c == k) slot = off[k]++;
         // classes 0 and 2 grow from the front of their array, 1 and 3 from the back
-        const uint32_t idx = (uint32_t)(2 * part + (c >> 1)) * item_cap + ((c & 1) ? item_cap - 1u - slot : slot);
-        items[idx] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
+        const uint32_t idx = (uint32_t)(2 * part + (c >> 1)) * q.item_cap + ((c & 1) ? q.item_cap - 1u - slot : slot);
+        q.items[idx] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
+    }
+    if (!binned || !q.tdesc) return;  // (block-uniform)
+    __syncthreads();
+    // pass 2: every face to the lists of the tiles of its box (its own tile box and depth range come back from L1 / L2)
+    Rec3 *const lists = q.lists + (size_t)n * q.list_cap;
+    // (consecutive faces cover the same tiles: their entries take consecutive slots, so a wave's stores land in few cache lines;
+    // spreading the lanes over distant faces to thin out the same-address atomics was measured slower, 601 -> 658 us)
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const uint32_t box = q.tbox[(size_t)n * F + f];
+        const int tx0 = box & 0xFF, ty0 = (box >> 8) & 0xFF, tx1 = (box >> 16) & 0xFF, ty1 = box >> 24;
+        if (tx0 > tx1) continue;
+        const float2 zr = q.fzr[(size_t)n * F + f];
+        const Rec3 ent = {(uint32_t)f, __float_as_uint(zr.x), __float_as_uint(zr.y)};
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
     }
 }
 
@@ -482,36 +570,6 @@ struct alignas(16) DenseLds {
 };
 static_assert(sizeof(DenseLds) * RESIDENT_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
 
-// Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
-// VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
-#ifdef RASTER_EXPERIMENT  // tools/dbg experiments only: wrap every stream index (results are garbage, timing is not)
-__constant__ uint32_t g_wrap_mask = 0xFFFFFFFFu;
-#define WRAP_IDX(i) ((i) & g_wrap_mask)
-#else
-#define WRAP_IDX(i) (i)
-#endif
-// (12-byte elements: the index is below 2^24, so the full-rate 24-bit multiply is exact; left to itself hipcc emits the
-// quarter-rate v_mul_lo_u32, also for the shift-and-add spelling)
-template <typename T>
-__device__ __forceinline__ uint32_t byte_offset(uint32_t i) {
-    if (sizeof(T) == 12) {
-        uint32_t r;
-        asm("v_mul_u32_u24 %0, %1, 12" : "=v"(r) : "v"(i));
-        return r;
-    }
-    return i * (uint32_t)sizeof(T);
-}
-template <typename T>
-__device__ __forceinline__ T &at(T *base, uint32_t i) {
-    i = WRAP_IDX(i);
-    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset<T>(i));
-}
-template <typename T>
-__device__ __forceinline__ const T &at(const T *base, uint32_t i) {
-    i = WRAP_IDX(i);
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset<T>(i));
-}
-
 // Record-stream accesses: written once, read once or twice, never shared between workgroups.
 #ifdef STREAM_NT
 template <typename T> __device__ __forceinline__ T ld_stream(const T *base, uint32_t i) { return __builtin_nontemporal_load(&at(base, i)); }
@@ -526,15 +584,6 @@ template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_
 // outstanding global stores (vmcnt), which in pass 1 would stall every sweep step on the previous step's record stores.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// inclusive wave64 prefix sum in DPP (row_shr within 16-lane rows, then row_bcast across rows)
-__device__ __forceinline__ int wave_scan_add(int x) {
-#define SCAN_STEP(ctrl, rows) { x += __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false); }
-    SCAN_STEP(0x111, 0xF) SCAN_STEP(0x112, 0xF) SCAN_STEP(0x114, 0xF) SCAN_STEP(0x118, 0xF)
-    SCAN_STEP(0x142, 0xA) SCAN_STEP(0x143, 0xC)
-#undef SCAN_STEP
-    return x;
-}
-
 // Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the nearest /
 // farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's vertex
 // depths), which fixes the radix-select digits before pass 1 starts.  Depths are positive: the bit patterns order like
@@ -547,7 +596,7 @@ __device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
 #ifndef LGROUP
 #define LGROUP 8  // 64-face groups whose tile boxes / depth ranges are requested together by the list build
 #endif
-__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, uint2 *list, int lane, uint32_t &kmin,
+__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, Rec3 *list, int lane, uint32_t &kmin,
                                           uint32_t &kmax) {
     const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.F;
     const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.F;
@@ -577,7 +626,7 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
                 const bool hit = fidx[u] < a.F && box_has(tb[u], tx, ty);
                 const unsigned long long mask = __ballot(hit);
                 if (hit) {
-                    list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)fidx[u], __float_as_uint(zz[u].x));
+                    at(list, (uint32_t)(cnt + __popcll(mask & ((1ull << lane) - 1ull)))) = Rec3{(uint32_t)fidx[u], __float_as_uint(zz[u].x), __float_as_uint(zz[u].y)};
                     zlo = fminf(zlo, zz[u].x);
                     zhi = fmaxf(zhi, zz[u].y);
                 }
@@ -602,18 +651,18 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
 // nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
 // Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
 // recovers through `out`.  bstart[d] = first position of bucket d.
-__device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
+__device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
                                                       DenseLds &lds, int lane) {
     const int n_buckets = 1 << b1;
     lds.start[lane] = 0;
     __syncthreads();
-    auto digit_of = [&](uint2 e) { return (int)(((e.y - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
+    auto digit_of = [&](const Rec3 &e) { return (int)(((e.b - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
     // (four rows per step: the loads of a step are in flight together - at small launches a tile's time is its chain of
     // memory round trips)
     for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
-        uint2 e[4];
+        Rec3 e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = list[min(i0 + u * WAVE + lane, n - 1)];
+        for (int u = 0; u < 4; ++u) e[u] = at(list, (uint32_t)min(i0 + u * WAVE + lane, n - 1));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (i0 + u * WAVE + lane < n) atomicAdd(&lds.start[digit_of(e[u])], 1);
@@ -626,12 +675,12 @@ __device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_
     lds.start[lane] = incl - c;  // running cursor of every bucket
     __syncthreads();
     for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
-        uint2 e[4];
+        Rec3 e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = list[min(i0 + u * WAVE + lane, n - 1)];
+        for (int u = 0; u < 4; ++u) e[u] = at(list, (uint32_t)min(i0 + u * WAVE + lane, n - 1));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * WAVE + lane < n) out[atomicAdd(&lds.start[digit_of(e[u])], 1)] = e[u].x;
+            if (i0 + u * WAVE + lane < n) out[atomicAdd(&lds.start[digit_of(e[u])], 1)] = e[u].a;
     }
     __syncthreads();
 }
@@ -878,7 +927,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
     const int lane = threadIdx.x;
-    uint2 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
+    Rec3 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
@@ -939,7 +988,30 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
         uint32_t kmin, kmax;  // bounds of the depth keys of this tile
-        const int list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
+        // the faces whose blurred box reaches this tile: binned by the setup kernel (any order), or found here through the tile
+        // boxes of the 64-face groups (ascending id) when the image's lists did not fit
+        const uint2 td = a.tdesc ? a.tdesc[code] : make_uint2(0u, 0xFFFFFFFFu);
+        const bool binned = td.y != 0xFFFFFFFFu;  // (wave-uniform)
+        const Rec3 *const list_src = binned ? a.lists + (size_t)n * a.list_cap + td.x : slist;
+        int list_total;
+        if (binned) {
+            list_total = (int)td.y;
+            uint32_t lo = 0x7F7FFFFFu, hi = 0u;  // every depth of the tile lies between its faces' nearest and farthest vertices
+            for (int i0 = 0; i0 < list_total; i0 += 4 * WAVE) {
+                Rec3 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = at(list_src, (uint32_t)min(i0 + u * WAVE + lane, list_total - 1));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { lo = min(lo, e[u].b); hi = max(hi, e[u].c); }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, WAVE));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, WAVE));
+            }
+            kmin = lo; kmax = hi;
+        } else {
+            list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
+        }
         const bool may_truncate = list_total > K;
         // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
         // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
@@ -950,9 +1022,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
         const uint32_t *const lst = slist2;
         if (may_truncate) {
-            sort_list_near_to_far(slist, slist2, list_total, kmin, shift1, b1, lds, lane);
-        } else {  // at most K faces: the id order is kept
-            for (int i = lane; i < list_total; i += WAVE) slist2[i] = slist[i].x;
+            sort_list_near_to_far(list_src, slist2, list_total, kmin, shift1, b1, lds, lane);
+        } else {  // at most K faces: the order of the list is kept
+            for (int i = lane; i < list_total; i += WAVE) slist2[i] = at(list_src, (uint32_t)i).a;
             __syncthreads();
         }
         TMARK(0)
@@ -1306,9 +1378,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 // fp32 rounding of the global atomics the sums end in.  Integer sums are order independent.
                 const float csum = wave_sum(active ? fabsf(coef) : 0.f);
                 const float bound = 2.0f * sqrtf(wave_max(rmax2)) * csum;
-                const float fx_scale = (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
+                // Packed launches accumulate in the IMAGE's fixed-point scale right away (image_fx_scale: no vertex component of the
+                // image can overflow it, so no partial sum can): every contribution is rounded once, per record, and from there on
+                // all sums - LDS, flush, memory-side atomics - are integer adds, exact in any order and any grouping of faces.
+                const bool img_fixed = MODE == MODE_FUSED && a.packed;  // (wave-uniform)
+                const float fx_scale = img_fixed ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma)
+                                       : (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
                 const float fx_inv = fx_scale > 0.f ? 1.0f / fx_scale : 0.f;
-                const float img_scale = (MODE == MODE_FUSED && a.packed) ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma) : 0.f;
                 lds.pgrad[lane] = make_float4(active ? coef * fx_scale : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
                 __syncthreads();
                 constexpr int GR = GCHUNK / DCHUNK;
@@ -1413,11 +1489,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
 #ifdef RASTER_EXPERIMENT
                             if (a.stop_after == 5 && (qx | qy) != 0x12345678) continue;  // ablation: no global gradient atomics
 #endif
-                            if (MODE == MODE_FUSED && a.packed) {  // wave-uniform
-                                const int ix = __float2int_rn((float)qx * fx_inv * img_scale), iy = __float2int_rn((float)qy * fx_inv * img_scale);
-                                if ((ix | iy) != 0)
-                                    atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[h][k],
-                                              ((unsigned long long)(uint32_t)(ix + (iy >> 31)) << 32) | (unsigned long long)(uint32_t)iy);
+                            if (img_fixed) {  // wave-uniform: the sum is already in the image's scale
+                                if (tot != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[h][k], tot);
                                 continue;
                             }
                             if (qx != 0) atomicAdd(&dn[2 * vi[h][k]], (float)qx * fx_inv);
@@ -1475,21 +1548,29 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: F x {face id, nearest depth} in id order, F face ids in walking order, F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
+// per resident workgroup: F x {face id, nearest / farthest depth} in id order (tiles of images that are not binned), F face ids in walking order,
+// F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
 #define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
-    return (size_t)grid * (3 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+    return (size_t)grid * (4 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
+}
+
+// binned tile lists: LIST_CAP_PER_FACE entries per face and image (12 bytes each) + one descriptor per tile; images with more than
+// COUNT_TILES_MAX tiles are never binned
+static inline uint32_t list_cap_of(const SmilModel *m, int S) {
+    return ceil_div(S, TILE) * ceil_div(S, TILE) <= COUNT_TILES_MAX ? (uint32_t)LIST_CAP_PER_FACE * (uint32_t)m->F : 0u;
 }
 
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), per-workgroup scratch
+    // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), binned lists + tile descriptors, per-workgroup scratch
     return align256((size_t)N * m->F * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
            align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint32_t)) +
            align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) +
-           align256((size_t)N * sizeof(float)) + 256 +
+           align256((size_t)N * sizeof(float)) + align256((size_t)N * list_cap_of(m, S) * sizeof(Rec3)) +
+           align256((size_t)N * tiles * sizeof(uint2)) + 256 +
            scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
 }
 
@@ -1533,21 +1614,33 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
     float *img_bound = (float *)ws;
     ws += align256((size_t)N * sizeof(float));
+    const uint32_t list_cap = list_cap_of(m, S);
+    Rec3 *lists = (Rec3 *)ws;
+    ws += align256((size_t)N * list_cap * sizeof(Rec3));
+    uint2 *tdesc = (uint2 *)ws;
+    ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint2));
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
-    const size_t setup_lds = (size_t)(n_tiles <= COUNT_TILES_MAX ? n_tiles : (n_tiles + 31) / 32) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, verts_ndc, m->faces, tbox, gbox, items, item_cap,
-                       fzr, ctr, m->V, m->F, S, tiles_x, sqrt_blur, rs->z_clip, d_ndc_zero, loss_src, loss_dst, img_bound, m->max_valence,
-                       dndc_scale, pix_scale, 1.0f / rs->sigma, packed);
-    SMIL_LAUNCH_CHECK();
+    {
+        SetupArgs q;
+        q.verts_ndc = verts_ndc; q.faces = m->faces; q.tbox = tbox; q.gbox = gbox; q.items = items; q.item_cap = item_cap; q.fzr = fzr;
+        q.ctr = ctr; q.V = m->V; q.F = m->F; q.S = S; q.tiles_x = tiles_x; q.sqrt_blur = sqrt_blur; q.z_clip = rs->z_clip;
+        q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.img_bound = img_bound; q.max_valence = m->max_valence;
+        q.dndc_scale = dndc_scale; q.pix_scale = pix_scale; q.inv_sigma = 1.0f / rs->sigma; q.packed = packed;
+        q.lists = lists; q.tdesc = tdesc; q.list_cap = list_cap;
+        // per tile: 8 bytes of counts + 4 bytes of list cursor, or one bit
+        const size_t setup_lds = n_tiles <= COUNT_TILES_MAX ? (size_t)n_tiles * 12 : (size_t)((n_tiles + 31) / 32) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, q);
+        SMIL_LAUNCH_CHECK();
+    }
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
         a.list_stride = (int)(align256((size_t)m->F * sizeof(uint32_t)) / sizeof(uint32_t));
         a.n_cf = (int)(align256((size_t)(m->F / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
         ws += 256;
-        a.slist = (uint2 *)ws;
-        ws += grid * (size_t)a.list_stride * sizeof(uint2);
+        a.slist = (Rec3 *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(Rec3);
         a.slist2 = (uint32_t *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
@@ -1556,6 +1649,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.srec = (Rec3 *)ws; ws += stream;
         a.crec = (Rec3 *)ws;
     }
+    a.lists = lists; a.tdesc = tdesc; a.list_cap = list_cap;
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);

@@ -147,7 +147,7 @@ def parity_oracle(tables, wl, sample):
     total.backward()
     grad = torch.cat([params["global_rotation"].grad.reshape(n_frames, -1), params["joint_rotations"].grad.reshape(n_frames, -1),
                       params["trans"].grad.reshape(n_frames, -1)], 1)
-    return float(total), grad
+    return float(total.detach()), grad
 
 
 def parity_check(fitter, tables, wl, sample, window):

@@ -630,7 +630,9 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
 #endif
 
 // Per frame: d v_posed = T_R^T dv (+ regressor^T d J_rest), reduced against shapedirs -> d_beta[b],
-// and d_trans[b] = sum_v dv.  One block per frame, deterministic.
+// and d_trans[b] = sum_v dv.  One block per frame; the per-frame sums are deterministic (fixed reduction order), the SHARED
+// shape gradient is the sum of those over the frames by float atomics, i.e. reproducible to rounding only (the last bits depend
+// on the order in which the blocks arrive).
 __global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,

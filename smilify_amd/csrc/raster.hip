@@ -250,7 +250,8 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 #define SETUP_THREADS 1024
 #endif
 #ifndef LIST_CAP_PER_FACE
-#define LIST_CAP_PER_FACE 8   // (tile, face) list entries an image may have per face (a face's blurred box covers ~4 tiles)
+#define LIST_CAP_PER_FACE 8   // (tile, face) list entries an image may have per face at S <= 256 (a face's blurred box covers ~4 tiles there,
+                              // ~8 at 512^2: the blur radius is a fixed fraction of the image); doubled above 256
 #endif
 struct SetupArgs {
     const float *verts_ndc; const int *faces;
@@ -1559,7 +1560,7 @@ static inline size_t scratch_bytes(int grid, int F) {
 // binned tile lists: LIST_CAP_PER_FACE entries per face and image (12 bytes each) + one descriptor per tile; images with more than
 // COUNT_TILES_MAX tiles are never binned
 static inline uint32_t list_cap_of(const SmilModel *m, int S) {
-    return ceil_div(S, TILE) * ceil_div(S, TILE) <= COUNT_TILES_MAX ? (uint32_t)LIST_CAP_PER_FACE * (uint32_t)m->F : 0u;
+    return ceil_div(S, TILE) * ceil_div(S, TILE) <= COUNT_TILES_MAX ? (uint32_t)LIST_CAP_PER_FACE * (S > 256 ? 2u : 1u) * (uint32_t)m->F : 0u;
 }
 
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {

@@ -310,17 +310,32 @@ def fov_reduce(cams: CameraSet, d_fov_img: torch.Tensor) -> torch.Tensor:
 # part of the workspace; launches are cut into slices of this many images so that the workspace stays bounded at cfg5
 # scale (147 k images per GPU).  Each slice still holds millions of tiles.
 MAX_IMAGES_PER_LAUNCH = 16384
+MAX_WORKSPACE_BYTES = 24 << 30  # the per-image tables (incl. the binned tile lists, ~96-192 bytes per face) shrink the slice until this holds
 
 
-def _slices(N: int):
-    for n0 in range(0, N, MAX_IMAGES_PER_LAUNCH):
-        yield n0, min(N, n0 + MAX_IMAGES_PER_LAUNCH)
+def _slice_images(model: "DeviceModel", N: int, S: int) -> int:
+    """Images per rasteriser call: at most MAX_IMAGES_PER_LAUNCH, fewer when the per-image workspace tables would push the
+    workspace past MAX_WORKSPACE_BYTES (mouse-sized meshes at 512^2)."""
+    step = min(N, MAX_IMAGES_PER_LAUNCH)
+    key = (N, S)
+    cached = model.__dict__.setdefault("_slice_cache", {})
+    if key not in cached:
+        while step > 256 and int(_lib.load().smil_raster_workspace_bytes(model.handle, step, S)) > MAX_WORKSPACE_BYTES:
+            step = (step + 1) // 2
+        cached[key] = step
+    return cached[key]
+
+
+def _slices(N: int, step: int = MAX_IMAGES_PER_LAUNCH):
+    for n0 in range(0, N, step):
+        yield n0, min(N, n0 + step)
 
 
 def raster_stats(model: DeviceModel, N: int) -> dict:
     """Counters of the last rasteriser call of ``model`` on ``N`` images (of its last slice when the batch was cut): faces
     straddling z_clip (rendered whole; the reference would clip them) and touched tiles.  Synchronises."""
-    last = N - ((N - 1) // MAX_IMAGES_PER_LAUNCH) * MAX_IMAGES_PER_LAUNCH
+    step = model.__dict__.get("_last_slice", MAX_IMAGES_PER_LAUNCH)
+    last = N - ((N - 1) // step) * step
     out = (ctypes.c_uint32 * 4)()
     _lib.check(_lib.load().smil_raster_stats(model.handle, last, _ptr(model._ws), _stream(), out), "smil_raster_stats")
     return {"straddling_faces": int(out[0]), "tiles": int(out[1])}
@@ -330,8 +345,9 @@ def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=N
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     sil = torch.empty(N, S, S, dtype=torch.float32, device=verts_ndc.device)
-    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
-    for n0, n1 in _slices(N):
+    step = model._last_slice = _slice_images(model, N, S)
+    ws = model.workspace(step, S)
+    for n0, n1 in _slices(N, step):
         _lib.check(_lib.load().smil_silhouette_forward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
                                                        _ptr(sil[n0:n1]), _ptr(ws), _stream()), "smil_silhouette_forward")
     return sil
@@ -341,8 +357,9 @@ def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, gra
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=verts_ndc.device)
-    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
-    for n0, n1 in _slices(N):
+    step = model._last_slice = _slice_images(model, N, S)
+    ws = model.workspace(step, S)
+    for n0, n1 in _slices(N, step):
         _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
                                                         _ptr(grad_sil[n0:n1]), _ptr(d_ndc[n0:n1]), _ptr(ws), _stream()),
                    "smil_silhouette_backward")
@@ -363,10 +380,11 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
         d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=dev)
     sil = torch.empty(N, S, S, dtype=torch.float32, device=dev) if want_sil else None
     scale = torch.empty(N, dtype=torch.float32, device=dev) if packed_out else None
-    ws = model.workspace(min(N, MAX_IMAGES_PER_LAUNCH), S)
+    step = model._last_slice = _slice_images(model, N, S)
+    ws = model.workspace(step, S)
     if target.dtype not in (torch.float32, torch.uint8):
         raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
-    for n0, n1 in _slices(N):
+    for n0, n1 in _slices(N, step):
         _lib.check(_lib.load().smil_silhouette_l1_fused(
             model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs), _ptr(target[n0:n1]), int(target.dtype == torch.uint8),
             _ptr(target_sum[n0:n1]), _ptr(pix_scale[n0:n1]), _ptr(loss_img[n0:n1]), _ptr(d_ndc[n0:n1]),

@@ -447,14 +447,17 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
 // catastrophically.
 //   w_i(p) = A_i dx + B_i dy + C_i  = b_i(p) * z_j z_k   (perspective-correct barycentric numerators; the
 //            common denominator is positive, so inside <=> all w_i > 0)
+// The fields are ordered so that what the evaluation computes in pairs sits in adjacent registers after the 16-byte LDS reads:
+// (w0, w1), the projections on the two edges leaving v0, ... become one packed fp32 instruction each (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32) without register moves; the third of each kind stays scalar.
 struct alignas(16) FaceRec {
     float xmin, xmax, ymin, ymax;   // blurred bbox (absolute NDC)
-    float A0, B0, C0, A1;
-    float B1, C1, A2, B2;
+    float A0, A1, B0, B1;
+    float C0, C1, A2, B2;
     float C2, z0, z1, z2;
-    float x0c, y0c, x1c, y1c;       // v0, v1 relative to the tile centre
-    float e01x, e01y, rl01, e02x;   // edge vectors and 1/|e|^2 (0 for a degenerate edge)
-    float e02y, rl02, e12x, e12y;
+    float x0c, x1c, y0c, y1c;       // v0, v1 relative to the tile centre
+    float e01x, e02x, e01y, e02y;   // edge vectors and 1/|e|^2 (0 for a degenerate edge)
+    float rl01, rl02, e12x, e12y;
     float rl12;
     int i0, i1, i2;
 };
@@ -465,50 +468,59 @@ struct PairEval {
     float sd;             // signed squared distance
     float w0, w1, w2;
     // closest edge in the reference's order e01, e02, e12 with <= ties (its backward treats t as a constant):
-    // edge 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2); t = clamped projection; (rx, ry) = closest point minus pixel,
-    // sq2(rx, ry) == |sd| bit for bit
+    // edge 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2)
     int edge;
-    float t, rx, ry;
 };
 
-// |r|^2 with one fixed rounding sequence, so that a distance recomputed from a stored (rx, ry) is bit-identical
-__device__ __forceinline__ float sq2(float x, float y) { return __fmaf_rn(x, x, y * y); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
+__device__ __forceinline__ f32x2 clamp01(f32x2 v) {  // (folds into the clamp bit of the producing instruction)
+    return __builtin_elementwise_min(__builtin_elementwise_max(v, splat2(0.f)), splat2(1.f));
+}
 
 // Branch-free: every lane computes everything; `cand` says whether the pair exists.
 __device__ __forceinline__ void eval_pair(const FaceRec &f, float px, float py, float dxp, float dyp, float blur, PairEval &e) {
     // inside [xmin, xmax] x [ymin, ymax] <=> the median of (p, lo, hi) is p itself (two instructions per axis; a masked
     // pixel sits at 3e38 and fails; face coordinates are finite, the setup kernel drops the others)
     const bool in_bb = (__builtin_amdgcn_fmed3f(px, f.xmin, f.xmax) == px) & (__builtin_amdgcn_fmed3f(py, f.ymin, f.ymax) == py);
-    e.w0 = fmaf(f.A0, dxp, fmaf(f.B0, dyp, f.C0));
-    e.w1 = fmaf(f.A1, dxp, fmaf(f.B1, dyp, f.C1));
+    const f32x2 dx = splat2(dxp), dy = splat2(dyp);
+    const f32x2 w01 = __builtin_elementwise_fma((f32x2){f.A0, f.A1}, dx, __builtin_elementwise_fma((f32x2){f.B0, f.B1}, dy, (f32x2){f.C0, f.C1}));
+    e.w0 = w01.x; e.w1 = w01.y;
     e.w2 = fmaf(f.A2, dxp, fmaf(f.B2, dyp, f.C2));
     e.inside = (e.w0 > 0.f) && (e.w1 > 0.f) && (e.w2 > 0.f);
-    const float dx0 = dxp - f.x0c, dy0 = dyp - f.y0c, dx1 = dxp - f.x1c, dy1 = dyp - f.y1c;
-    const float t01 = __builtin_amdgcn_fmed3f((f.e01x * dx0 + f.e01y * dy0) * f.rl01, 0.f, 1.f);
-    const float t02 = __builtin_amdgcn_fmed3f((f.e02x * dx0 + f.e02y * dy0) * f.rl02, 0.f, 1.f);
-    const float t12 = __builtin_amdgcn_fmed3f((f.e12x * dx1 + f.e12y * dy1) * f.rl12, 0.f, 1.f);
-    const float r01x = fmaf(t01, f.e01x, -dx0), r01y = fmaf(t01, f.e01y, -dy0);
-    const float r02x = fmaf(t02, f.e02x, -dx0), r02y = fmaf(t02, f.e02y, -dy0);
-    const float r12x = fmaf(t12, f.e12x, -dx1), r12y = fmaf(t12, f.e12y, -dy1);
-    const float d01 = sq2(r01x, r01y), d02 = sq2(r02x, r02y), d12 = sq2(r12x, r12y);
+    // pixel relative to v0 (.x) and to v1 (.y)
+    const f32x2 qx = dx - (f32x2){f.x0c, f.x1c}, qy = dy - (f32x2){f.y0c, f.y1c};
+    // edges 01 and 02 leave v0: one packed lane each; edge 12 leaves v1: scalar
+    const f32x2 ex = {f.e01x, f.e02x}, ey = {f.e01y, f.e02y};
+    const f32x2 q0x = splat2(qx.x), q0y = splat2(qy.x);
+    const f32x2 t0 = clamp01((ex * q0x + ey * q0y) * (f32x2){f.rl01, f.rl02});
+    const float t12 = __builtin_amdgcn_fmed3f((f.e12x * qx.y + f.e12y * qy.y) * f.rl12, 0.f, 1.f);
+    const f32x2 rx = __builtin_elementwise_fma(t0, ex, -q0x), ry = __builtin_elementwise_fma(t0, ey, -q0y);
+    const float r12x = fmaf(t12, f.e12x, -qx.y), r12y = fmaf(t12, f.e12y, -qy.y);
+    const f32x2 d0 = __builtin_elementwise_fma(rx, rx, ry * ry);
+    const float d01 = d0.x, d02 = d0.y, d12 = fmaf(r12x, r12x, r12y * r12y);
     const float dist = fminf(fminf(d01, d02), d12);
     e.cand = in_bb && (e.inside || dist < blur);
     e.sd = e.inside ? -dist : dist;
     const bool c01 = (d01 <= d02) && (d01 <= d12);
     const bool c02 = !c01 && (d02 <= d01) && (d02 <= d12);
     e.edge = c01 ? 0 : (c02 ? 1 : 2);
-    e.t = c01 ? t01 : (c02 ? t02 : t12);
-    e.rx = c01 ? r01x : (c02 ? r02x : r12x);
-    e.ry = c01 ? r01y : (c02 ? r02y : r12y);
 }
 
 // depth at the clipped, renormalised perspective-correct barycentrics:
 // c_i = max(p_i,0) / max(sum, 1e-5), p_i = w_i / den; 1/den cancels: c_i = max(w_i,0) / max(sum max(w,0), 1e-5 den).
 // When a single weight survives the clip the depth is EXACTLY that vertex's depth, so faces sharing the vertex tie
 // exactly (as x / x == 1 does in the reference) and the (depth, face id) order stays well defined.
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e) {
     const float den = fmaxf(e.w0 + e.w1 + e.w2, K_EPS);
-    const float m0 = fmaxf(e.w0, 0.f), m1 = fmaxf(e.w1, 0.f), m2 = fmaxf(e.w2, 0.f);
+    // (v_max_f32 spelled out: hipcc puts a canonicalising v_max x, x in front of every fmaxf whose input it cannot prove canonical,
+    // and these inputs - results of fma instructions - always are)
+    const float m0 = vmax_raw(e.w0, 0.f), m1 = vmax_raw(e.w1, 0.f), m2 = vmax_raw(e.w2, 0.f);
     const float cs = fmaxf(m0 + m1 + m2, 1e-5f * den);
     const float rc = __builtin_amdgcn_rcpf(cs);
     const float pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
@@ -711,8 +723,8 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
             // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
             const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
-            r[1] = make_float4((y2 - y1) * s0, -(x2 - x1) * s0, edge_fn(cx, cy, x1, y1, x2, y2) * s0, (y0 - y2) * s1);
-            r[2] = make_float4(-(x0 - x2) * s1, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);
+            r[1] = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);                                      // A0 A1 B0 B1
+            r[2] = make_float4(edge_fn(cx, cy, x1, y1, x2, y2) * s0, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);  // C0 C1 A2 B2
             r[3] = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
             const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
             const int yi_lo = (int)ceilf(((ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
@@ -727,9 +739,9 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
             const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
             const float rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
-            r[4] = make_float4(x0 - cx, y0 - cy, x1 - cx, y1 - cy);
-            r[5] = make_float4(e01x, e01y, rl01, e02x);
-            r[6] = make_float4(e02y, rl02, e12x, e12y);
+            r[4] = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
+            r[5] = make_float4(e01x, e02x, e01y, e02y);
+            r[6] = make_float4(rl01, rl02, e12x, e12y);
             r[7] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
             const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
@@ -1159,7 +1171,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
 #ifdef ABL_DEPTH  // timing experiment (garbage results): no depth arithmetic
                     const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(fr.z0), kmin), kmax)) : 3.0e38f;
 #else
-                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(fmaxf(pair_depth(fr, e), fminf(fminf(fr.z0, fr.z1), fr.z2))), kmin), kmax)) : 3.0e38f;
+                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(vmax_raw(pair_depth(fr, e), fminf(fminf(fr.z0, fr.z1), fr.z2))), kmin), kmax)) : 3.0e38f;
 #endif
                     const uint32_t zb = __float_as_uint(z);
                     const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));

@@ -177,7 +177,7 @@ typedef struct {
     float sigma;              /* 1e-4 */
     int32_t faces_per_pixel;  /* K = 100 */
     float z_clip;             /* MeshRasterizer's z_clip_value = znear / 2 = 5e-4: faces whose three vertices are all
-                                 nearer than this are culled (clip_faces); straddling faces are not split */
+                                 nearer than this are culled, faces that cross it are cut there (clip_faces) */
 } SmilRasterSettings;
 
 /* Caller-owned scratch for N images of side S: per-face tile boxes / depth ranges, the tile work list, and the pair-record
@@ -186,10 +186,12 @@ typedef struct {
 size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
 
 /* Counters of the most recent rasteriser call that used `workspace` with the same N, copied to out4[4] (synchronises the
- * stream): [0] faces straddling z_clip (one or two vertices nearer than znear / 2).  pytorch3d's clip_faces would cut such a
- * face at the plane and render the part in front (p3d_renderer.py:36-47 leaves that default on); this library renders it
- * whole, or not at all when one of its vertices is nearer than 1e-8, so a non-zero count says the silhouettes of that call
- * deviate from the reference's.  [1] touched 8x8 tiles.  [2], [3] reserved. */
+ * stream): [0] faces that cross z_clip (one or two vertices nearer than znear / 2): cut at the plane like pytorch3d's
+ * clip_faces, which p3d_renderer.py:36-47 leaves on - the front part is rendered as one or two extra triangles whose new
+ * vertices hand their gradient back to the cut edge's end points (interpolation coefficients held constant; no gradient on
+ * the depths).  [1] touched 8x8 tiles.  [2] cut candidates beyond the per-image clip tables (256 front-part triangles, 512 new
+ * vertices): rendered whole, or not at all when a vertex is nearer than 1e-8 - the one case in which a call still deviates.
+ * [3] reserved. */
 int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream, uint32_t *out4);
 
 /* verts_ndc (N,V,3) -> sil (N,S,S) */

@@ -32,8 +32,9 @@
 #define K_EPS 1e-8f
 /* MeshRasterizer passes z_clip_value = znear / 2 (renderer/mesh/rasterizer.py; the reference sets znear = 1e-3,
  * p3d_renderer.py:24,36-38) to clip_faces(): a face whose three vertices are all nearer than that is removed before the
- * kernel runs.  Faces that straddle the value are split there; that case is NOT restated (geometry within half a
- * millimetre of the camera plane), they are rasterised whole unless the kernel rule zmin < 1e-8 drops them. */
+ * kernel runs.  Faces that straddle the value are split there: oracle/render_ref.py::clip_faces_np restates that step and
+ * hands this file the clipped mesh of such an image (new vertices on the plane, the front parts as extra faces); called
+ * directly, this file rasterises a straddling face whole unless the kernel rule zmin < 1e-8 drops it. */
 static float g_z_clip = 5e-4f;
 void oracle_set_z_clip(float z) { g_z_clip = z; }
 

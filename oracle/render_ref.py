@@ -70,9 +70,76 @@ class select_mode:
         return False
 
 
+_Z_CLIP = ZNEAR / 2.0
+
+
 def set_z_clip(z: float) -> None:
     """z_clip_value of the rasteriser (default znear / 2 = 5e-4, as the reference's camera gives it)."""
+    global _Z_CLIP
+    _Z_CLIP = float(z)
     _lib().oracle_set_z_clip(ctypes.c_float(float(z)))
+
+
+def clip_faces_np(verts: np.ndarray, faces: np.ndarray, z_clip: float):
+    """pytorch3d ``clip_faces`` (renderer/mesh/clip.py, 0.7.x; un-vendored, restated from its published algorithm - PARITY
+    UNPINNED) for ONE mesh in the rasteriser's input space ``(x_ndc, y_ndc, z_view)``, as MeshRasterizer applies it with
+    ``z_clip_value = znear / 2`` and ``cull_to_frustum = False`` (reference p3d_renderer.py:36-47 leaves both defaults):
+
+    * a vertex is "behind" when ``z < z_clip``; faces with no vertex behind are kept, with all three behind removed;
+    * ONE behind (p1; p2, p3 in front, cyclic order kept): the front part is a quadrilateral, split into (p4, p2, p3) and
+      (p4, p3, p5); TWO behind (p1 in front; p2, p3 behind): the front part is the triangle (p1, p4, p5);
+      p4 / p5 = where the edges p1-p2 / p1-p3 cross the plane, interpolated in VIEW space (perspective_correct): with
+      ``w_b = (z_a - z_clip) / (z_a - z_b)``, ``xy = (xy_a z_a (1 - w_b) + xy_b z_b w_b) / z_clip``, ``z = z_clip``.
+
+    Returns ``(verts_aug (V + X, 3), faces_aug (F + E, 3), src (X, 2) int, coef (X, 2) float64)``: rows 0..F-1 of ``faces_aug``
+    keep the face ids (a clipped face becomes a zero-area placeholder), the front parts follow at F...; every new vertex j is
+    ``coef[j,0] xy[src[j,0]] + coef[j,1] xy[src[j,1]]``.  Gradients: the rasteriser's xy gradient of a new vertex goes back
+    to its two source vertices with those coefficients HELD CONSTANT (pytorch3d differentiates through them as well, which
+    also yields gradients on the source depths; not restated - the HIP path implements the same constant-coefficient rule)."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    behind = v[:, 2][f] < z_clip                      # (F, 3)
+    nb = behind.sum(1)
+    clip_ids = np.nonzero((nb == 1) | (nb == 2))[0]
+    if clip_ids.size == 0:
+        return np.asarray(verts, np.float32), np.asarray(faces, np.int32), np.zeros((0, 2), np.int64), np.zeros((0, 2))
+    V = v.shape[0]
+    new_v, src, coef, new_f = [], [], [], []
+    f_aug = f.copy()
+
+    def cross(a, b):  # plane crossing of the segment from vertex a to vertex b
+        wb = (v[a, 2] - z_clip) / (v[a, 2] - v[b, 2])
+        ca, cb = v[a, 2] * (1.0 - wb) / z_clip, v[b, 2] * wb / z_clip
+        new_v.append([ca * v[a, 0] + cb * v[b, 0], ca * v[a, 1] + cb * v[b, 1], z_clip])
+        src.append([a, b]); coef.append([ca, cb])
+        return V + len(new_v) - 1
+
+    for fi in clip_ids:
+        tri, bh = f[fi], behind[fi]
+        k = int(np.nonzero(bh)[0][0]) if nb[fi] == 1 else int(np.nonzero(~bh)[0][0])  # the isolated vertex
+        p1, p2, p3 = int(tri[k]), int(tri[(k + 1) % 3]), int(tri[(k + 2) % 3])
+        p4, p5 = cross(p1, p2), cross(p1, p3)
+        if nb[fi] == 1:
+            new_f += [[p4, p2, p3], [p4, p3, p5]]
+        else:
+            new_f += [[p1, p4, p5]]
+        f_aug[fi] = [tri[0], tri[0], tri[0]]          # placeholder: zero area, never rendered
+    verts_aug = np.concatenate([v, np.asarray(new_v)]).astype(np.float32)
+    faces_aug = np.concatenate([f_aug, np.asarray(new_f, np.int64)]).astype(np.int32)
+    return verts_aug, faces_aug, np.asarray(src, np.int64), np.asarray(coef, np.float64)
+
+
+def _clip_plan(verts_ndc: np.ndarray, faces: np.ndarray):
+    """Per image: None (nothing crosses z_clip) or the clipped mesh of ``clip_faces_np``."""
+    z = verts_ndc[..., 2]
+    plans = []
+    for n in range(verts_ndc.shape[0]):
+        if _Z_CLIP > 0.0 and bool((z[n] < _Z_CLIP).any()):
+            va, fa, src, coef = clip_faces_np(verts_ndc[n], faces, _Z_CLIP)
+            plans.append((va, fa, src, coef) if src.shape[0] else None)
+        else:
+            plans.append(None)
+    return plans
 
 
 def num_threads() -> int:
@@ -88,9 +155,15 @@ def _ip(a):
 
 
 def silhouette_forward_np(verts_ndc, faces, S, blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL,
-                          want_fragments=False):
+                          want_fragments=False, _clipped=False):
     verts_ndc = np.ascontiguousarray(verts_ndc, np.float32)
     faces = np.ascontiguousarray(faces, np.int32)
+    if not _clipped and not want_fragments:
+        plans = _clip_plan(verts_ndc, faces)
+        if any(p is not None for p in plans):  # images with faces across z_clip are rendered one by one from their clipped mesh
+            outs = [silhouette_forward_np(verts_ndc[n:n + 1] if p is None else p[0][None], faces if p is None else p[1], S, blur, sigma, K,
+                                          _clipped=True) for n, p in enumerate(plans)]
+            return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
     N, V, _ = verts_ndc.shape
     F = faces.shape[0]
     sil = np.empty((N, S, S), np.float32)
@@ -111,10 +184,27 @@ def silhouette_forward_np(verts_ndc, faces, S, blur=BLUR_RADIUS, sigma=SIGMA, K=
     return sil, ncand
 
 
-def silhouette_backward_np(verts_ndc, faces, S, grad_sil, blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL):
+def silhouette_backward_np(verts_ndc, faces, S, grad_sil, blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL, _clipped=False):
     verts_ndc = np.ascontiguousarray(verts_ndc, np.float32)
     faces = np.ascontiguousarray(faces, np.int32)
     grad_sil = np.ascontiguousarray(grad_sil, np.float32)
+    if not _clipped:
+        plans = _clip_plan(verts_ndc, faces)
+        if any(p is not None for p in plans):
+            V0 = verts_ndc.shape[1]
+            out = np.zeros((verts_ndc.shape[0], V0, 3), np.float32)
+            for n, p in enumerate(plans):
+                if p is None:
+                    out[n] = silhouette_backward_np(verts_ndc[n:n + 1], faces, S, grad_sil[n:n + 1], blur, sigma, K, _clipped=True)[0]
+                    continue
+                va, fa, src, coef = p
+                g = silhouette_backward_np(va[None], fa, S, grad_sil[n:n + 1], blur, sigma, K, _clipped=True)[0].astype(np.float64)
+                acc = g[:V0].copy()
+                for j in range(src.shape[0]):  # new vertex -> its two source vertices, coefficients held constant
+                    acc[src[j, 0], :2] += coef[j, 0] * g[V0 + j, :2]
+                    acc[src[j, 1], :2] += coef[j, 1] * g[V0 + j, :2]
+                out[n] = acc.astype(np.float32)
+            return out
     N, V, _ = verts_ndc.shape
     gv = np.empty((N, V, 3), np.float32)
     rc = _lib().oracle_silhouette_backward(_fp(verts_ndc), _ip(faces), N, V, faces.shape[0], S, blur, sigma, K,

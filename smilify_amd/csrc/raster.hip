@@ -139,10 +139,39 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 struct RasterCounters {
     unsigned int n_class[N_PARTS][N_CLASSES];
     struct { unsigned int next, pad[15]; } deal[N_PARTS];  // one cache line per partition's cursor
-    unsigned int straddling;  // faces with zmin < z_clip <= zmax in this launch: rendered unclipped (smil_raster_stats)
+    unsigned int straddling;  // faces that cross z_clip in this launch: cut at the plane (smil_raster_stats) ...
+    unsigned int unclipped;   // ... except these: beyond the per-image clip tables, rendered whole or dropped
 };
 
 struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
+
+// clip_faces (pytorch3d renderer/mesh/clip.py, as MeshRasterizer applies it with z_clip_value = znear / 2; the reference leaves that
+// default on, p3d_renderer.py:36-47): a face with one or two vertices nearer than z_clip is cut at the plane and its front part
+// (one triangle, or a quadrilateral as two) rendered instead.  Such faces are rare (the mesh must reach the camera), so they are
+// handled beside the mesh, per image: up to CLIP_FX front-part triangles get face ids from FP = F rounded up to 64 on, their
+// new vertices (on the plane) vertex ids from V on, both in small side tables; every fetch of a face's vertex indices or of a
+// vertex's coordinates / gradient row goes through one compare that picks the table.  A new vertex is
+// c_a xy[a] + c_b xy[b] of the cut edge's end points (interpolated in view space); its gradient goes back to them with the
+// coefficients held constant (k_clip_backward).  Faces beyond the tables' capacity are rendered as before and counted.
+#define CLIP_FX 256   // front-part triangles per image
+#define CLIP_VX 512   // new vertices per image (two per cut face)
+#define CLIP_CUTS (CLIP_FX / 2)  // cut faces per image: each owns two face and two vertex slots
+struct ClipTables {
+    float *xv;          // (N, CLIP_VX, 3) new vertices (x_ndc, y_ndc, z_clip)
+    int *xf;            // (N, CLIP_FX, 3) vertex ids of the front-part triangles (>= V: new vertices)
+    int2 *xsrc;         // (N, CLIP_VX) end points (a, b) of the edge a new vertex lies on
+    float2 *xcoef;      // (N, CLIP_VX) (c_a, c_b)
+    float *xg;          // (N, CLIP_VX, 2) gradient rows of the new vertices (same representation as d_ndc)
+    uint32_t *xcount;   // (N) new vertices of the image
+};
+__host__ __device__ __forceinline__ int faces_padded(int F) { return (F + WAVE - 1) / WAVE * WAVE; }
+// vertex ids of face f of image n / coordinates of vertex i of image n, through the clip tables
+__device__ __forceinline__ int face_vertex(const int *__restrict__ faces, const int *__restrict__ xf_n, int F, int f, int k) {
+    return f < F ? faces[3 * f + k] : xf_n[3 * (f - faces_padded(F)) + k];
+}
+__device__ __forceinline__ const float *vertex_ptr(const float *__restrict__ vn, const float *__restrict__ xv_n, int V, int i) {
+    return i < V ? vn + 3 * i : xv_n + 3 * (i - V);
+}
 
 struct RasterArgs {
     const float *verts_ndc;  // (N,V,3)
@@ -154,6 +183,8 @@ struct RasterArgs {
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
     int N, V, F, S, tiles_x, K;
+    int FT;                  // rows of the per-image face tables: F rounded up to 64 + CLIP_FX (front parts of cut faces)
+    ClipTables clip;
     float blur, sqrt_blur, inv_sigma, inv_sigma_log2e;
     // outputs / inputs per mode
     float *sil;              // (N,S,S) FWD (or optional in FUSED)
@@ -254,6 +285,7 @@ __device__ __forceinline__ int wave_scan_add(int x) {
                               // ~8 at 512^2: the blur radius is a fixed fraction of the image); doubled above 256
 #endif
 struct SetupArgs {
+    ClipTables clip;
     const float *verts_ndc; const int *faces;
     uint32_t *tbox, *gbox, *items; uint32_t item_cap; float2 *fzr;
     RasterCounters *ctr;
@@ -270,7 +302,7 @@ struct SetupArgs {
 // end to end, and pass 2 walks the faces again and appends each to the lists of the tiles its box covers.  The tile kernel
 // then starts from its list instead of scanning the tile boxes of every 64-face group that reaches its tile (build_list:
 // 13 % of the tile kernel in round 2).  Images whose lists exceed list_cap keep the old way.
-__global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
+__global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) {  // (two blocks per CU: <= 64 VGPRs)
     __shared__ uint32_t s_maxpx;  // largest blurred pixel box of a face
     __shared__ uint32_t s_straddle;
     if (threadIdx.x == 0) { s_maxpx = 0u; s_straddle = 0u; }
@@ -296,54 +328,83 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
     __syncthreads();
     const float *vn = q.verts_ndc + (size_t)n * V * 3;
     const float fS = (float)S;
-    const int n_groups = (F + WAVE - 1) / WAVE;
-    for (int f0 = 0; f0 < F; f0 += blockDim.x) {  // every wave handles 64 consecutive faces per round
-        const int f = f0 + threadIdx.x;
+    const int FP = faces_padded(F), FT = FP + CLIP_FX;  // ids of the front parts of cut faces start at FP; tables are FT long
+    const int n_groups = FT / WAVE;
+    __shared__ uint32_t s_ncut, s_unclipped;
+    __shared__ int s_cut[CLIP_CUTS];
+    if (threadIdx.x == 0) { s_ncut = 0u; s_unclipped = 0u; }
+    for (int i = threadIdx.x; i < FT - F; i += blockDim.x) q.tbox[(size_t)n * FT + F + i] = 0x0000FFFFu;  // (ids F .. FT-1: empty unless a cut face fills them)
+    __syncthreads();
+    float *const xv_n = q.clip.xv + (size_t)n * CLIP_VX * 3;
+    int *const xf_n = q.clip.xf + (size_t)n * CLIP_FX * 3;
+    // one face (an original one or the front part of a cut one): validity, blurred pixel box -> tile box, cost / entry per tile
+    auto emit = [&](int fid, float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2, float z2) -> uint32_t {
         uint32_t box = 0x0000FFFFu;  // empty: tx0 = ty0 = 255 > tx1 = ty1 = 0
-        if (f < F) {
-            const int i0 = q.faces[3 * f], i1 = q.faces[3 * f + 1], i2 = q.faces[3 * f + 2];
-            const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
-            const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
-            const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
-            const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
-            const float area = edge_fn(x0, y0, x1, y1, x2, y2);
-            const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
-            // counted for smil_raster_stats: clip_faces() would cut a face that crosses z_clip at the plane and keep the front part;
-            // here it is rendered whole, or dropped entirely when a vertex is nearer than 1e-8 (the rule below)
-            if (finite && zmin < q.z_clip && !(zmax < q.z_clip)) ++my_straddle;
-            // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
-            // z_clip_value (znear / 2) and clip_faces() removes it.  Faces straddling z_clip are not split.
-            if (finite && !(zmin < K_EPS) && !(zmax < q.z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
-                const float xlo = fminf(fminf(x0, x1), x2) - q.sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + q.sqrt_blur;
-                const float ylo = fminf(fminf(y0, y1), y2) - q.sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + q.sqrt_blur;
-                // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
-                // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides
-                int xi_lo = (int)ceilf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-                int yi_lo = (int)ceilf(((ylo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((yhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
-                xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
-                xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
-                if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
-                    my_px = max(my_px, (uint32_t)((xi_hi - xi_lo + 1) * (yi_hi - yi_lo + 1)));
-                    // output column xo = S-1-xi
-                    const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
-                    const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
-                    box = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-                    const int xo0 = S - 1 - xi_hi, xo1 = S - 1 - xi_lo, yo0 = S - 1 - yi_hi, yo1 = S - 1 - yi_lo;
-                    for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) {
-                            const int t = ty * tiles_x + tx;
-                            if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it; one list entry
-                                const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
-                                const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
-                                atomicAdd(&tcnt64[t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));
-                            } else {
-                                atomicOr(&tbits[t >> 5], 1u << (t & 31));
-                            }
+        const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
+        const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+        const bool finite = (x0 == x0) && (x1 == x1) && (x2 == x2) && (y0 == y0) && (y1 == y1) && (y2 == y2);
+        // zmin < 1e-8: the rasteriser's own rule; zmax < z_clip: the face lies entirely nearer than MeshRasterizer's
+        // z_clip_value (znear / 2) and clip_faces() removes it
+        if (finite && !(zmin < K_EPS) && !(zmax < q.z_clip) && !(area <= K_EPS && area >= -K_EPS)) {
+            const float xlo = fminf(fminf(x0, x1), x2) - q.sqrt_blur, xhi = fmaxf(fmaxf(x0, x1), x2) + q.sqrt_blur;
+            const float ylo = fminf(fminf(y0, y1), y2) - q.sqrt_blur, yhi = fmaxf(fmaxf(y0, y1), y2) + q.sqrt_blur;
+            // pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo,hi] are ceil(v_lo)..floor(v_hi)
+            // with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding of both sides (clamped in float first: the
+            // front part of a cut face can reach far outside the image)
+            const float vxl = fminf(fmaxf(((xlo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f, -1.0f), fS), vxh = fminf(fmaxf(((xhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f, -1.0f), fS);
+            const float vyl = fminf(fmaxf(((ylo + 1.0f) * fS - 1.0f) * 0.5f - 0.01f, -1.0f), fS), vyh = fminf(fmaxf(((yhi + 1.0f) * fS - 1.0f) * 0.5f + 0.01f, -1.0f), fS);
+            int xi_lo = (int)ceilf(vxl), xi_hi = (int)floorf(vxh), yi_lo = (int)ceilf(vyl), yi_hi = (int)floorf(vyh);
+            xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0);
+            xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
+            if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
+                my_px = max(my_px, (uint32_t)((xi_hi - xi_lo + 1) * (yi_hi - yi_lo + 1)));
+                // output column xo = S-1-xi
+                const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
+                const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
+                box = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                const int xo0 = S - 1 - xi_hi, xo1 = S - 1 - xi_lo, yo0 = S - 1 - yi_hi, yo1 = S - 1 - yi_lo;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        const int t = ty * tiles_x + tx;
+                        if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it; one list entry
+                            const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
+                            const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
+                            atomicAdd(&tcnt64[t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));
+                        } else {
+                            atomicOr(&tbits[t >> 5], 1u << (t & 31));
                         }
+                    }
+            }
+        }
+        q.tbox[(size_t)n * FT + fid] = box;
+        q.fzr[(size_t)n * FT + fid] = make_float2(zmin, zmax);
+        return box;
+    };
+    for (int f0 = 0; f0 < FP; f0 += blockDim.x) {  // every wave handles 64 consecutive faces per round
+        const int f = f0 + threadIdx.x;
+        uint32_t box = 0x0000FFFFu;
+        if (f < F) {
+            const int ii[3] = {q.faces[3 * f], q.faces[3 * f + 1], q.faces[3 * f + 2]};
+            float X[3], Y[3], Z[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { X[k] = vn[3 * ii[k]]; Y[k] = vn[3 * ii[k] + 1]; Z[k] = vn[3 * ii[k] + 2]; }
+            const int nb = (Z[0] < q.z_clip ? 1 : 0) + (Z[1] < q.z_clip ? 1 : 0) + (Z[2] < q.z_clip ? 1 : 0);  // vertices behind the plane
+            const bool finite = (X[0] == X[0]) && (X[1] == X[1]) && (X[2] == X[2]) && (Y[0] == Y[0]) && (Y[1] == Y[1]) && (Y[2] == Y[2]) &&
+                                (Z[0] == Z[0]) && (Z[1] == Z[1]) && (Z[2] == Z[2]);
+            bool cut = false;
+            if (finite && (nb == 1 || nb == 2)) {  // crosses the plane: set aside for the cut loop below (rare: kept out of this loop's registers)
+                ++my_straddle;
+                const uint32_t c = q.clip.xv ? atomicAdd(&s_ncut, 1u) : (uint32_t)CLIP_CUTS;
+                if (c < (uint32_t)CLIP_CUTS) {
+                    s_cut[c] = f;
+                    cut = true;
+                    q.tbox[(size_t)n * FT + f] = 0x0000FFFFu;  // the face itself is replaced by its front part
+                    q.fzr[(size_t)n * FT + f] = make_float2(fminf(fminf(Z[0], Z[1]), Z[2]), fmaxf(fmaxf(Z[0], Z[1]), Z[2]));
+                } else {
+                    atomicAdd(&s_unclipped, 1u);  // beyond the tables: rendered whole, or dropped when a vertex is nearer than 1e-8 (counted)
                 }
             }
-            q.tbox[(size_t)n * F + f] = box;
-            q.fzr[(size_t)n * F + f] = make_float2(zmin, zmax);
+            if (!cut) box = emit(f, X[0], Y[0], Z[0], X[1], Y[1], Z[1], X[2], Y[2], Z[2]);
         }
         // union of the wave's 64 boxes: the tile kernel skips whole groups of faces with one test (images that are not binned)
         int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
@@ -352,9 +413,61 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
             gx1 = max(gx1, __shfl_xor(gx1, o, WAVE)); gy1 = max(gy1, __shfl_xor(gy1, o, WAVE));
         }
         const int grp = (f0 + (int)threadIdx.x) / WAVE;
-        if ((threadIdx.x & (WAVE - 1)) == 0 && grp < n_groups)
+        if ((threadIdx.x & (WAVE - 1)) == 0 && grp < FP / WAVE)
             q.gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
+    __syncthreads();
+    // the faces that cross the plane: cut c owns the new vertices 2c, 2c + 1 and the front-part faces FP + 2c, FP + 2c + 1
+    const uint32_t n_cut = min(s_ncut, (uint32_t)CLIP_CUTS);
+    for (uint32_t c = threadIdx.x; c < n_cut; c += blockDim.x) {
+        const int f = s_cut[c];
+        const int ii[3] = {q.faces[3 * f], q.faces[3 * f + 1], q.faces[3 * f + 2]};
+        float X[3], Y[3], Z[3];
+        for (int k = 0; k < 3; ++k) { X[k] = vn[3 * ii[k]]; Y[k] = vn[3 * ii[k] + 1]; Z[k] = vn[3 * ii[k] + 2]; }
+        const int nb = (Z[0] < q.z_clip ? 1 : 0) + (Z[1] < q.z_clip ? 1 : 0) + (Z[2] < q.z_clip ? 1 : 0);
+        // the isolated vertex first (the one behind, or the one in front), cyclic order kept
+        const int k1 = nb == 1 ? (Z[0] < q.z_clip ? 0 : (Z[1] < q.z_clip ? 1 : 2)) : (!(Z[0] < q.z_clip) ? 0 : (!(Z[1] < q.z_clip) ? 1 : 2));
+        const int o1 = k1, o2 = (k1 + 1) % 3, o3 = (k1 + 2) % 3;
+        const uint32_t jv = 2u * c;
+        float nx[2], ny[2];
+        for (int e = 0; e < 2; ++e) {  // where the edges p1-p2 and p1-p3 cross the plane (view-space interpolation)
+            const int a = o1, b = e == 0 ? o2 : o3;
+            const float wb = (Z[a] - q.z_clip) / (Z[a] - Z[b]);
+            const float ca = Z[a] * (1.0f - wb) / q.z_clip, cb = Z[b] * wb / q.z_clip;
+            nx[e] = ca * X[a] + cb * X[b]; ny[e] = ca * Y[a] + cb * Y[b];
+            float *o = xv_n + 3 * (jv + e);
+            o[0] = nx[e]; o[1] = ny[e]; o[2] = q.z_clip;
+            q.clip.xsrc[(size_t)n * CLIP_VX + jv + e] = make_int2(ii[a], ii[b]);
+            q.clip.xcoef[(size_t)n * CLIP_VX + jv + e] = make_float2(ca, cb);
+        }
+        const int v4 = V + (int)jv, v5 = v4 + 1;
+        int *xf = xf_n + 3 * (2 * c);
+        if (nb == 1) {  // quadrilateral (p4, p2, p3, p5) as (p4, p2, p3) + (p4, p3, p5)
+            xf[0] = v4; xf[1] = ii[o2]; xf[2] = ii[o3]; xf[3] = v4; xf[4] = ii[o3]; xf[5] = v5;
+            emit(FP + 2 * (int)c, nx[0], ny[0], q.z_clip, X[o2], Y[o2], Z[o2], X[o3], Y[o3], Z[o3]);
+            emit(FP + 2 * (int)c + 1, nx[0], ny[0], q.z_clip, X[o3], Y[o3], Z[o3], nx[1], ny[1], q.z_clip);
+        } else {        // triangle (p1, p4, p5)
+            xf[0] = ii[o1]; xf[1] = v4; xf[2] = v5;
+            emit(FP + 2 * (int)c, X[o1], Y[o1], Z[o1], nx[0], ny[0], q.z_clip, nx[1], ny[1], q.z_clip);
+        }
+    }
+    __syncthreads();  // the front parts' tile boxes are in place (written by whichever thread cut their face)
+    if (threadIdx.x < CLIP_FX) {  // their group boxes
+        const uint32_t box = n_cut ? q.tbox[(size_t)n * FT + FP + threadIdx.x] : 0x0000FFFFu;
+        int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
+        for (int o = 32; o > 0; o >>= 1) {
+            gx0 = min(gx0, __shfl_xor(gx0, o, WAVE)); gy0 = min(gy0, __shfl_xor(gy0, o, WAVE));
+            gx1 = max(gx1, __shfl_xor(gx1, o, WAVE)); gy1 = max(gy1, __shfl_xor(gy1, o, WAVE));
+        }
+        if ((threadIdx.x & (WAVE - 1)) == 0)
+            q.gbox[(size_t)n * n_groups + FP / WAVE + threadIdx.x / WAVE] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
+    }
+    if (q.clip.xcount) {
+        const uint32_t nxv = 2u * n_cut;
+        if (threadIdx.x == 0) q.clip.xcount[n] = nxv;
+        for (int i = threadIdx.x; i < (int)nxv * 2; i += blockDim.x) q.clip.xg[(size_t)n * CLIP_VX * 2 + i] = 0.f;
+    }
+    if (threadIdx.x == 0 && s_unclipped) atomicAdd(&q.ctr->unclipped, s_unclipped);
     // Bound on what one vertex component of this image can receive from pass 3, up to the factor |upstream gradient| /
     // sqrt(sigma): a kept record of probability p = sigmoid(-+r^2 / sigma) adds at most 2 r p alpha |g| / sigma to an end point,
     // alpha <= 1 - p, and r p (1 - p) <= 0.197 sqrt(sigma) for every r (maximum of sqrt(u) s(u) (1 - s(u)), u = r^2 / sigma);
@@ -366,8 +479,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
         const float bound = 1.02f * 0.4f * (float)q.max_valence * (float)s_maxpx;
         q.img_bound[n] = bound;
         if (q.dndc_scale) {  // what the consumer of a packed gradient row multiplies by (0: the row holds plain floats)
-            const float sc = q.packed ? image_fx_scale(bound, q.pix_scale[n], q.inv_sigma) : 0.f;
-            q.dndc_scale[n] = sc > 0.f ? 1.0f / sc : (q.packed ? -1.0f : 0.f);  // (-1: packed row that received nothing: decodes to zeros)
+            // (an image with cut faces accumulates in plain floats: the gradients its new vertices hand back are scaled by z / z_clip
+            // factors that no a-priori bound covers)
+            const bool pk = q.packed && s_ncut == 0u;
+            const float sc = pk ? image_fx_scale(bound, q.pix_scale[n], q.inv_sigma) : 0.f;
+            q.dndc_scale[n] = sc > 0.f ? 1.0f / sc : (pk ? -1.0f : 0.f);  // (-1: packed row that received nothing: decodes to zeros)
         }
     }
     if (threadIdx.x == 0 && s_straddle) atomicAdd(&q.ctr->straddling, s_straddle);
@@ -428,11 +544,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) k_raster_setup(SetupArgs q) {
     Rec3 *const lists = q.lists + (size_t)n * q.list_cap;
     // (consecutive faces cover the same tiles: their entries take consecutive slots, so a wave's stores land in few cache lines;
     // spreading the lanes over distant faces to thin out the same-address atomics was measured slower, 601 -> 658 us)
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        const uint32_t box = q.tbox[(size_t)n * F + f];
+    for (int f = threadIdx.x; f < FT; f += blockDim.x) {
+        const uint32_t box = q.tbox[(size_t)n * FT + f];
         const int tx0 = box & 0xFF, ty0 = (box >> 8) & 0xFF, tx1 = (box >> 16) & 0xFF, ty1 = box >> 24;
         if (tx0 > tx1) continue;
-        const float2 zr = q.fzr[(size_t)n * F + f];
+        const float2 zr = q.fzr[(size_t)n * FT + f];
         const Rec3 ent = {(uint32_t)f, __float_as_uint(zr.x), __float_as_uint(zr.y)};
         for (int ty = ty0; ty <= ty1; ++ty)
             for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
@@ -538,9 +654,10 @@ __device__ __forceinline__ float face_prob(float sd, float inv_sigma_log2e) {
 }
 
 __global__ void __launch_bounds__(256) k_unpack_dndc(float *__restrict__ d_ndc, const float *__restrict__ img_bound,
-                                                     const float *__restrict__ pix_scale, float inv_sigma, int V) {
+                                                     const float *__restrict__ pix_scale, float inv_sigma, int V,
+                                                     const uint32_t *__restrict__ xcount) {
     const int n = blockIdx.x, v = blockIdx.y * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+    if (v >= V || (xcount && xcount[n] != 0u)) return;  // (images with cut faces hold plain floats already)
     const float sc = image_fx_scale(img_bound[n], pix_scale[n], inv_sigma);
     const float inv = sc > 0.f ? 1.0f / sc : 0.f;
     unsigned long long *p = reinterpret_cast<unsigned long long *>(d_ndc) + (size_t)n * V + v;
@@ -548,6 +665,23 @@ __global__ void __launch_bounds__(256) k_unpack_dndc(float *__restrict__ d_ndc, 
     const int qy = (int)(uint32_t)tot;
     const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
     *reinterpret_cast<float2 *>(p) = make_float2((float)qx * inv, (float)qy * inv);
+}
+
+// Gradient of the new vertices of cut faces back to the end points of the edges they lie on: xy_new = c_a xy_a + c_b xy_b with the
+// coefficients held constant (see ClipTables).  One workgroup per image; images without cut faces leave at once.  Images with
+// cut faces accumulate in plain floats, so these are float atomics on d_ndc (two new vertices may share an end point).
+__global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__restrict__ d_ndc, int V) {
+    const int n = blockIdx.x;
+    const uint32_t nx = c.xcount[n];
+    for (uint32_t j = threadIdx.x; j < nx; j += blockDim.x) {
+        const float gx = c.xg[((size_t)n * CLIP_VX + j) * 2], gy = c.xg[((size_t)n * CLIP_VX + j) * 2 + 1];
+        if (gx == 0.f && gy == 0.f) continue;
+        const int2 ab = c.xsrc[(size_t)n * CLIP_VX + j];
+        const float2 co = c.xcoef[(size_t)n * CLIP_VX + j];
+        float *da = d_ndc + ((size_t)n * V + ab.x) * 2, *db = d_ndc + ((size_t)n * V + ab.y) * 2;
+        atomicAdd(da, co.x * gx); atomicAdd(da + 1, co.x * gy);
+        atomicAdd(db, co.y * gx); atomicAdd(db + 1, co.y * gy);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,9 +745,9 @@ __device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
 #endif
 __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, Rec3 *list, int lane, uint32_t &kmin,
                                           uint32_t &kmax) {
-    const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.F;
-    const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.F;
-    const int n_groups = (a.F + WAVE - 1) / WAVE;
+    const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.FT;
+    const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.FT;
+    const int n_groups = a.FT / WAVE;
     const uint32_t *__restrict__ gbox_n = a.gbox + (size_t)n * n_groups;
     int cnt = 0;
     float zlo = 3.0e38f, zhi = 0.f;
@@ -629,14 +763,14 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
             for (int u = 0; u < LGROUP; ++u) {
                 const int gi = gm ? g0 + (int)__builtin_ctzll(gm) : -1;
                 gm &= gm - 1ull;  // 0 stays 0
-                fidx[u] = gi >= 0 ? gi * WAVE + lane : a.F;
-                const int fc = min(fidx[u], a.F - 1);
+                fidx[u] = gi >= 0 ? gi * WAVE + lane : a.FT;
+                const int fc = min(fidx[u], a.FT - 1);
                 tb[u] = tbox_n[fc];
                 zz[u] = fzr_n[fc];
             }
 #pragma unroll
             for (int u = 0; u < LGROUP; ++u) {
-                const bool hit = fidx[u] < a.F && box_has(tb[u], tx, ty);
+                const bool hit = fidx[u] < a.FT && box_has(tb[u], tx, ty);
                 const unsigned long long mask = __ballot(hit);
                 if (hit) {
                     at(list, (uint32_t)(cnt + __popcll(mask & ((1ull << lane) - 1ull)))) = Rec3{(uint32_t)fidx[u], __float_as_uint(zz[u].x), __float_as_uint(zz[u].y)};
@@ -707,16 +841,17 @@ __device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t
 // centres inside [lo, hi] are ceil(v_lo) .. floor(v_hi) with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding
 // (a superset; eval_pair applies the exact test).
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
-__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, int i0, int i1, int i2, int m,
+__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const float *__restrict__ xv_n, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
                                             int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2) {
     const int slot = lane & (DCHUNK - 1);
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
     if (slot < m) {
-        const float x0 = vn[3 * i0], y0 = vn[3 * i0 + 1], z0 = vn[3 * i0 + 2];
-        const float x1 = vn[3 * i1], y1 = vn[3 * i1 + 1], z1 = vn[3 * i1 + 2];
-        const float x2 = vn[3 * i2], y2 = vn[3 * i2 + 1], z2 = vn[3 * i2 + 2];
+        const float *p0 = vertex_ptr(vn, xv_n, a.V, i0), *p1 = vertex_ptr(vn, xv_n, a.V, i1), *p2 = vertex_ptr(vn, xv_n, a.V, i2);
+        const float x0 = p0[0], y0 = p0[1], z0 = p0[2];
+        const float x1 = p1[0], y1 = p1[1], z1 = p1[2];
+        const float x2 = p2[0], y2 = p2[1], z2 = p2[2];
         float4 *r = reinterpret_cast<float4 *>(rec + slot * FSTR);
         if (!hi) {
             // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
@@ -998,6 +1133,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         const bool in_img = xo < a.S && yo < a.S;
         const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
         const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
+        const float *const xv_n = a.clip.xv + (size_t)n * CLIP_VX * 3;   // the image's clip tables (touched only by cut faces)
+        const int *const xf_n = a.clip.xf + (size_t)n * CLIP_FX * 3;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
         uint32_t kmin, kmax;  // bounds of the depth keys of this tile
@@ -1076,7 +1213,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             auto list_at = [&](int c) { return (int)lst[min(c + slot_, list_total - 1)]; };
             int f_nx = list_at(DCHUNK);
             int ia, ib, ic;
-            { const int f_ = list_at(0); ia = a.faces[3 * f_]; ib = a.faces[3 * f_ + 1]; ic = a.faces[3 * f_ + 2]; }
+            { const int f_ = list_at(0); ia = face_vertex(a.faces, xf_n, a.F, f_, 0); ib = face_vertex(a.faces, xf_n, a.F, f_, 1); ic = face_vertex(a.faces, xf_n, a.F, f_, 2); }
             for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
                 if (may_truncate) {
                     // digit of this chunk's first face = number of buckets that start at or before it, minus one
@@ -1100,9 +1237,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 const int m = min(DCHUNK, list_total - c0);
                 int cf, packed2, packed = 0;
                 const int i0 = ia, i1 = ib, i2 = ic;
-                ia = a.faces[3 * f_nx]; ib = a.faces[3 * f_nx + 1]; ic = a.faces[3 * f_nx + 2];  // chunk c0 + DCHUNK
+                ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + DCHUNK
                 f_nx = list_at(c0 + 2 * DCHUNK);
-                stage_faces(a, vn, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2);
+                stage_faces(a, vn, xv_n, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2);
                 if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
@@ -1302,7 +1439,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     // select on the list position among the records whose depth equals the pixel's threshold
                     lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
                     __syncthreads();
-                    int pbits = 32 - __clz(max(a.F - 1, 1));  // the tie key is the face id (the list is in near-to-far order)
+                    int pbits = 32 - __clz(max(a.FT - 1, 1));  // the tie key is the face id (the list is in near-to-far order)
                     uint32_t ppre = 0u;
                     int pneed = split ? need : 0, peq = 0;
                     auto pos_key = [&](uint32_t idx, uint32_t mt) {
@@ -1394,7 +1531,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 // Packed launches accumulate in the IMAGE's fixed-point scale right away (image_fx_scale: no vertex component of the
                 // image can overflow it, so no partial sum can): every contribution is rounded once, per record, and from there on
                 // all sums - LDS, flush, memory-side atomics - are integer adds, exact in any order and any grouping of faces.
-                const bool img_fixed = MODE == MODE_FUSED && a.packed;  // (wave-uniform)
+                // (an image with cut faces stays on float atomics, see k_raster_setup)
+                const bool img_fixed = MODE == MODE_FUSED && a.packed && a.clip.xcount[n] == 0u;  // (wave-uniform)
+                float *const dnx = a.clip.xg + ((size_t)n * CLIP_VX - (size_t)a.V) * 2;  // gradient rows of the image's new vertices, indexed by vertex id
                 const float fx_scale = img_fixed ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma)
                                        : (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
                 const float fx_inv = fx_scale > 0.f ? 1.0f / fx_scale : 0.f;
@@ -1419,9 +1558,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                         vi[h][0] = vi[h][1] = vi[h][2] = 0;
                         if (fch < list_total) {
                             const int f = (int)lst[fch];
-                            vi[h][0] = a.faces[3 * f]; vi[h][1] = a.faces[3 * f + 1]; vi[h][2] = a.faces[3 * f + 2];
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) fv[(h * WAVE + lane) * 3 + k] = make_float2(vn[3 * vi[h][k]], vn[3 * vi[h][k] + 1]);
+                            for (int k = 0; k < 3; ++k) {
+                                vi[h][k] = face_vertex(a.faces, xf_n, a.F, f, k);
+                                const float *pv = vertex_ptr(vn, xv_n, a.V, vi[h][k]);
+                                fv[(h * WAVE + lane) * 3 + k] = make_float2(pv[0], pv[1]);
+                            }
                         }
                     }
                     for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
@@ -1506,11 +1648,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                                 if (tot != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[h][k], tot);
                                 continue;
                             }
-                            if (qx != 0) atomicAdd(&dn[2 * vi[h][k]], (float)qx * fx_inv);
+                            float *const row = vi[h][k] < a.V ? dn : dnx;  // (a vertex of a cut face's front part: its own table)
+                            if (qx != 0) atomicAdd(&row[2 * vi[h][k]], (float)qx * fx_inv);
 #ifdef RASTER_EXPERIMENT
                             if (a.stop_after == 6) continue;  // ablation: half of the global gradient atomics
 #endif
-                            if (qy != 0) atomicAdd(&dn[2 * vi[h][k] + 1], (float)qy * fx_inv);
+                            if (qy != 0) atomicAdd(&row[2 * vi[h][k] + 1], (float)qy * fx_inv);
                         }
                     }
                     lds_fence();  // the accumulators are read before the next group clears them; unlike __syncthreads() this does
@@ -1575,29 +1718,36 @@ static inline uint32_t list_cap_of(const SmilModel *m, int S) {
     return ceil_div(S, TILE) * ceil_div(S, TILE) <= COUNT_TILES_MAX ? (uint32_t)LIST_CAP_PER_FACE * (S > 256 ? 2u : 1u) * (uint32_t)m->F : 0u;
 }
 
+static inline int face_rows(const SmilModel *m) { return faces_padded(m->F) + CLIP_FX; }
+// per-image clip tables: new vertices (12 B) + their gradient rows (8 B) + end points (8 B) + coefficients (8 B), front-part faces (12 B), count
+static inline size_t clip_bytes(int N) {
+    return align256((size_t)N * CLIP_VX * 12) + 3 * align256((size_t)N * CLIP_VX * 8) + align256((size_t)N * CLIP_FX * 12) + align256((size_t)N * 4);
+}
+
 extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S) {
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
-    // tile boxes (N,F), counters, work lists (2, N, tiles), per-face depth ranges (N,F), binned lists + tile descriptors, per-workgroup scratch
-    return align256((size_t)N * m->F * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
+    const size_t FT = (size_t)face_rows(m);
+    // tile boxes (N,FT), counters, work lists (2, N, tiles), per-face depth ranges (N,FT), binned lists + tile descriptors, clip tables, per-workgroup scratch
+    return align256((size_t)N * FT * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
            align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint32_t)) +
-           align256((size_t)N * m->F * sizeof(float2)) + align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t)) +
+           align256((size_t)N * FT * sizeof(float2)) + align256((size_t)N * (FT / WAVE) * sizeof(uint32_t)) +
            align256((size_t)N * sizeof(float)) + align256((size_t)N * list_cap_of(m, S) * sizeof(Rec3)) +
-           align256((size_t)N * tiles * sizeof(uint2)) + 256 +
-           scratch_bytes(tile_grid(N, ceil_div(S, TILE)), m->F);
+           align256((size_t)N * tiles * sizeof(uint2)) + clip_bytes(N) + 256 +
+           scratch_bytes(tile_grid(N, ceil_div(S, TILE)), face_rows(m));
 }
 
 // Counters of the most recent rasteriser call that used `workspace` with this N (device -> host copy: synchronises the stream).
 extern "C" int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream_, uint32_t *out4) {
     SMIL_REQUIRE(m && workspace && out4 && N > 0, "smil_raster_stats: bad argument");
-    const RasterCounters *ctr = (const RasterCounters *)((const char *)workspace + align256((size_t)N * m->F * sizeof(uint32_t)));
+    const RasterCounters *ctr = (const RasterCounters *)((const char *)workspace + align256((size_t)N * face_rows(m) * sizeof(uint32_t)));
     RasterCounters h;
     SMIL_HIP(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     SMIL_HIP(hipStreamSynchronize((hipStream_t)stream_));
     unsigned int tiles = 0;
     for (int q = 0; q < N_PARTS; ++q)
         for (int c = 0; c < N_CLASSES; ++c) tiles += h.n_class[q][c];
-    out4[0] = h.straddling; out4[1] = tiles; out4[2] = 0; out4[3] = 0;
+    out4[0] = h.straddling; out4[1] = tiles; out4[2] = h.unclipped; out4[3] = 0;
     return SMIL_OK;
 }
 
@@ -1610,21 +1760,22 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
                  "raster: faces_per_pixel=%d outside 1..%d", rs->faces_per_pixel, SMIL_MAX_FACES_PER_PIXEL);
     SMIL_REQUIRE(rs->sigma > 0.f && rs->blur_radius >= 0.f, "raster: bad blend settings");
-    SMIL_REQUIRE(m->F <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP);
+    SMIL_REQUIRE(face_rows(m) <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP - CLIP_FX - WAVE);
     const int tiles_x = ceil_div(S, TILE);
     SMIL_REQUIRE((double)N * tiles_x * tiles_x < 2147483647.0, "raster: N * tiles exceeds the work-item index range (2^31); launch in slices");
     char *ws = (char *)workspace;
+    const int FT = face_rows(m);
     uint32_t *tbox = (uint32_t *)ws;
-    ws += align256((size_t)N * m->F * sizeof(uint32_t));
+    ws += align256((size_t)N * FT * sizeof(uint32_t));
     RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
     ws += align256(sizeof(RasterCounters));
     uint32_t *items = (uint32_t *)ws;
     const uint32_t item_cap = (uint32_t)ceil_div(N, N_PARTS) * (uint32_t)(tiles_x * tiles_x);
     ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(uint32_t));
     float2 *fzr = (float2 *)ws;
-    ws += align256((size_t)N * m->F * sizeof(float2));
+    ws += align256((size_t)N * FT * sizeof(float2));
     uint32_t *gbox = (uint32_t *)ws;
-    ws += align256((size_t)N * ceil_div(m->F, WAVE) * sizeof(uint32_t));
+    ws += align256((size_t)N * (FT / WAVE) * sizeof(uint32_t));
     float *img_bound = (float *)ws;
     ws += align256((size_t)N * sizeof(float));
     const uint32_t list_cap = list_cap_of(m, S);
@@ -1632,6 +1783,13 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += align256((size_t)N * list_cap * sizeof(Rec3));
     uint2 *tdesc = (uint2 *)ws;
     ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint2));
+    ClipTables clip;
+    clip.xv = (float *)ws; ws += align256((size_t)N * CLIP_VX * 12);
+    clip.xg = (float *)ws; ws += align256((size_t)N * CLIP_VX * 8);
+    clip.xsrc = (int2 *)ws; ws += align256((size_t)N * CLIP_VX * 8);
+    clip.xcoef = (float2 *)ws; ws += align256((size_t)N * CLIP_VX * 8);
+    clip.xf = (int *)ws; ws += align256((size_t)N * CLIP_FX * 12);
+    clip.xcount = (uint32_t *)ws; ws += align256((size_t)N * 4);
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
@@ -1641,7 +1799,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         q.ctr = ctr; q.V = m->V; q.F = m->F; q.S = S; q.tiles_x = tiles_x; q.sqrt_blur = sqrt_blur; q.z_clip = rs->z_clip;
         q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.img_bound = img_bound; q.max_valence = m->max_valence;
         q.dndc_scale = dndc_scale; q.pix_scale = pix_scale; q.inv_sigma = 1.0f / rs->sigma; q.packed = packed;
-        q.lists = lists; q.tdesc = tdesc; q.list_cap = list_cap;
+        q.lists = lists; q.tdesc = tdesc; q.list_cap = list_cap; q.clip = clip;
         // per tile: 8 bytes of counts + 4 bytes of list cursor, or one bit
         const size_t setup_lds = n_tiles <= COUNT_TILES_MAX ? (size_t)n_tiles * 12 : (size_t)((n_tiles + 31) / 32) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, q);
@@ -1649,8 +1807,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     }
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
-        a.list_stride = (int)(align256((size_t)m->F * sizeof(uint32_t)) / sizeof(uint32_t));
-        a.n_cf = (int)(align256((size_t)(m->F / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
+        a.list_stride = (int)(align256((size_t)FT * sizeof(uint32_t)) / sizeof(uint32_t));
+        a.n_cf = (int)(align256((size_t)(FT / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
         ws += 256;
         a.slist = (Rec3 *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(Rec3);
@@ -1662,7 +1820,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.srec = (Rec3 *)ws; ws += stream;
         a.crec = (Rec3 *)ws;
     }
-    a.lists = lists; a.tdesc = tdesc; a.list_cap = list_cap;
+    a.lists = lists; a.tdesc = tdesc; a.list_cap = list_cap; a.clip = clip; a.FT = FT;
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
@@ -1781,6 +1939,8 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
     launch_tiles<MODE_BWD>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V);  // (new vertices of cut faces -> their edges' end points)
+    SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
 
@@ -1804,8 +1964,10 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);
     SMIL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V);  // (new vertices of cut faces -> their edges' end points)
+    SMIL_LAUNCH_CHECK();
     if (a.packed && !d_ndc_scale) {
-        hipLaunchKernelGGL(k_unpack_dndc, dim3(N, ceil_div(m->V, 256)), dim3(256), 0, stream, d_ndc, a.img_bound, pix_scale, a.inv_sigma, m->V);
+        hipLaunchKernelGGL(k_unpack_dndc, dim3(N, ceil_div(m->V, 256)), dim3(256), 0, stream, d_ndc, a.img_bound, pix_scale, a.inv_sigma, m->V, a.clip.xcount);
         SMIL_LAUNCH_CHECK();
     }
     return SMIL_OK;

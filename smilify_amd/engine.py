@@ -338,7 +338,7 @@ def raster_stats(model: DeviceModel, N: int) -> dict:
     last = N - ((N - 1) // step) * step
     out = (ctypes.c_uint32 * 4)()
     _lib.check(_lib.load().smil_raster_stats(model.handle, last, _ptr(model._ws), _stream(), out), "smil_raster_stats")
-    return {"straddling_faces": int(out[0]), "tiles": int(out[1])}
+    return {"straddling_faces": int(out[0]), "tiles": int(out[1]), "unclipped_faces": int(out[2])}
 
 
 def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=None) -> torch.Tensor:

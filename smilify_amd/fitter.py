@@ -590,22 +590,22 @@ class SMALFitter(nn.Module):
         return self._graph
 
     def straddling_faces(self) -> int:
-        """Faces of the most recent silhouette launch with one or two vertices nearer than ``z_clip = znear / 2``.  pytorch3d's
-        ``clip_faces`` (left on by the reference's settings, p3d_renderer.py:36-47) cuts such a face at the plane and renders
-        the part in front; this library renders it whole, so a non-zero count means the silhouette term of that evaluation
-        deviated from the reference's - in practice the mesh has drifted into the camera.  Warns once per fitter.
-        Synchronises the stream (call it between stages, not per iteration)."""
+        """Faces of the most recent silhouette launch with one or two vertices nearer than ``z_clip = znear / 2``.  They are cut
+        at the plane like pytorch3d's ``clip_faces`` does (left on by the reference's settings, p3d_renderer.py:36-47): the
+        part in front is rendered.  A non-zero count still deserves a look - the mesh has reached the camera - so the first
+        one warns; faces beyond the per-image clip tables (256 front-part triangles) are rendered unclipped and always
+        reported.  Synchronises the stream (call it between stages, not per iteration)."""
         if self.device_model._ws is None:
             return 0
-        n = int(engine.raster_stats(self.device_model, self.num_images * self.views)["straddling_faces"])
+        st = engine.raster_stats(self.device_model, self.num_images * self.views)
+        n, lost = int(st["straddling_faces"]), int(st["unclipped_faces"])
         if n and not self.__dict__.get("_warned_straddling"):
             import warnings
 
             self.__dict__["_warned_straddling"] = True
-            warnings.warn(f"{n} mesh faces straddle the camera's clipping plane (z_clip = znear / 2): they were rendered unclipped, "
-                          "where the reference (pytorch3d clip_faces) cuts them at the plane; the silhouette loss of this "
-                          "evaluation deviates from the reference. The mesh has probably drifted into the camera (check `trans`).",
-                          RuntimeWarning, stacklevel=2)
+            warnings.warn(f"{n} mesh faces straddle the camera's clipping plane (z_clip = znear / 2) and were cut there, as the "
+                          f"reference's rasteriser does ({lost} of them beyond the clip tables: rendered unclipped). The mesh has "
+                          "probably drifted into the camera (check `trans`).", RuntimeWarning, stacklevel=2)
         return n
 
     def _is_shared(self, name: str) -> bool:

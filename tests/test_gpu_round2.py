@@ -176,8 +176,8 @@ def test_z_clip_culls_faces_entirely_nearer_than_half_znear(tables):
 
 
 def test_faces_straddling_z_clip_are_counted_and_the_fitter_warns(tables):
-    """pytorch3d's clip_faces would cut a face with one or two vertices nearer than z_clip at the plane; this library renders
-    it whole - but not silently: the setup kernel counts such faces per launch (smil_raster_stats) and the fitter warns."""
+    """Faces with one or two vertices nearer than z_clip are cut at the plane (next test) and counted per launch by the setup
+    kernel (smil_raster_stats); the fitter warns once: the mesh has reached the camera."""
     import warnings
 
     from smilify_amd import engine as eng
@@ -372,3 +372,70 @@ def test_hardcoded_body_joints_of_35_joint_models():
     assert theta.grad is not None and float(theta.grad.abs().max()) > 0
     plain = SMAL(DEV, tables=t, config=cfgmod.FitterConfig.from_tables(t))
     assert plain(beta, theta.detach())[1].shape == (2, 35, 3)
+
+
+def _mesh_through_the_clip_plane(t, N, S, seed, n_behind):
+    """Random vertices in the rasteriser's input space with a few of them nearer than z_clip (some behind the camera)."""
+    g = torch.Generator().manual_seed(seed)
+    ndc = torch.empty(N, t.V, 3)
+    ndc[..., :2] = 0.9 * (torch.rand(N, t.V, 2, generator=g) - 0.5)
+    ndc[..., 2] = 0.8 + torch.rand(N, t.V, generator=g)
+    for n in range(N):
+        idx = torch.randperm(t.V, generator=g)[:n_behind]
+        ndc[n, idx, 2] = torch.tensor([-0.4, 2e-4, -1.5, 1e-5, 4e-4, -0.05, 3e-4, -0.7][:n_behind])
+        ndc[n, idx, :2] *= 0.3  # (keep the cut edges' crossings from flying off to 1e4 NDC units: fp32 of both sides stays comparable)
+    return ndc
+
+
+def test_faces_that_cross_z_clip_are_cut_at_the_plane(tables):
+    """clip_faces (pytorch3d, left on by the reference's RasterizationSettings, p3d_renderer.py:36-47): a face with one or two
+    vertices nearer than z_clip = znear / 2 is cut at the plane and its front part rendered.  HIP (per-image clip tables
+    filled by the setup kernel) against the oracle's restatement (render_ref.clip_faces_np): silhouette and vertex gradient,
+    the latter with the new vertices' gradients handed back to the cut edges' end points."""
+    from smilify_amd import engine as eng
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S, N = 48, 3
+    ndc = _mesh_through_the_clip_plane(t, N, S, 5, 6)
+    faces = t.faces
+    # known answer first (oracle only): the crossing points are where the VIEW-space segments meet the plane
+    va, fa, src, coef = render_ref.clip_faces_np(ndc[0].numpy(), faces, 5e-4)
+    assert src.shape[0] >= 4 and fa.shape[0] > faces.shape[0]
+    v64 = ndc[0].numpy().astype(np.float64)
+    for j in range(src.shape[0]):
+        a, b = src[j]
+        pa, pb = np.array([v64[a, 0] * v64[a, 2], v64[a, 1] * v64[a, 2], v64[a, 2]]), np.array([v64[b, 0] * v64[b, 2], v64[b, 1] * v64[b, 2], v64[b, 2]])
+        q = pa + (5e-4 - pa[2]) / (pb[2] - pa[2]) * (pb - pa)
+        np.testing.assert_allclose(va[t.V + j, :2], q[:2] / 5e-4, rtol=2e-5, atol=1e-4)
+    sil = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
+    st = eng.raster_stats(dm, N)
+    assert st["straddling_faces"] > 0 and st["unclipped_faces"] == 0
+    with render_ref.select_mode(1):
+        ref, _ = render_ref.silhouette_forward_np(ndc.numpy(), faces, S)
+    d = np.abs(sil - ref)
+    assert ref.sum() > 50 and d.mean() < 2e-5 and np.mean(d > 1e-3) < 2e-3, (ref.sum(), d.mean(), np.mean(d > 1e-3), d.max())
+    # the cut matters: rendering the same mesh with the cut faces simply left out differs visibly
+    keep = ~((ndc[0, :, 2][torch.from_numpy(faces.astype(np.int64))] < 5e-4).any(1)).numpy()
+    assert np.abs(render_ref.silhouette_forward_np(ndc[:1].numpy(), faces[keep], S)[0] - ref[:1]).sum() > 1.0
+    # gradient
+    gs = torch.from_numpy(np.cos(0.3 * np.arange(N * S * S)).astype(np.float32).reshape(N, S, S))
+    got = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
+    with render_ref.select_mode(1):
+        want = render_ref.silhouette_backward_np(ndc.numpy(), faces, S, gs.numpy())[..., :2]
+    scale = np.abs(want).max()
+    # (the front parts carry vertices at |xy| ~ 1e2 NDC units: fp32 cancellation in both implementations)
+    assert scale > 0 and np.abs(got - want).max() < 6e-3 * scale, (np.abs(got - want).max(), scale)
+    # the fused path on a batch large enough for packed gradients: images with cut faces fall back to float rows, the others stay packed
+    Nb = 70
+    big = _mesh_through_the_clip_plane(t, Nb, S, 9, 0)
+    big[5] = ndc[0]; big[33] = ndc[1]
+    target = (torch.rand(Nb, S, S, generator=torch.Generator().manual_seed(2)) > 0.5).float()
+    scale_img = torch.full((Nb,), 1.0 / (S * S), device=DEV)
+    li, dn, _ = eng.silhouette_l1_fused(dm, big.to(DEV), S, target.to(DEV), eng.image_abs_sum(target.to(DEV)), scale_img)
+    for n in (5, 6, 33):
+        li1, dn1, _ = eng.silhouette_l1_fused(dm, big[n:n + 1].to(DEV).contiguous(), S, target[n:n + 1].to(DEV).contiguous(),
+                                              eng.image_abs_sum(target[n:n + 1].to(DEV).contiguous()), scale_img[:1].contiguous())
+        np.testing.assert_allclose(li[n].item(), li1[0].item(), rtol=1e-5)
+        a, b = dn[n].cpu().numpy(), dn1[0].cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-12, (n, np.abs(a - b).max(), np.abs(b).max())

@@ -61,11 +61,23 @@ def test_backface_rendered_and_behind_camera_skipped():
     behind[..., 2] = -1.0
     c, n = rr.silhouette_forward_np(behind, f, S)
     assert c.sum() == 0 and n.sum() == 0
-    # one vertex behind the camera plane: z_invalid -> skipped as a whole
+    # one vertex behind the camera plane: the kernel alone would skip the face (z_invalid), but clip_faces runs first and cuts it
+    # at z_clip - the front part (a quadrilateral on the plane's near side, two triangles) is what gets rendered
     strad = front.copy()
     strad[0, 0, 2] = -0.1
     c, n = rr.silhouette_forward_np(strad, f, S)
-    assert c.sum() == 0
+    va, fa, src, coef = rr.clip_faces_np(strad[0], f, 5e-4)
+    assert va.shape == (5, 3) and fa.shape == (3, 3) and (fa[0] == fa[0][0]).all()       # placeholder + two front triangles
+    assert np.allclose(va[3:, 2], 5e-4) and src.tolist() == [[0, 1], [0, 2]]
+    np.testing.assert_allclose(coef.sum(1), 1.0, rtol=1e-12)                             # c_a z_a... the crossing is an affine combination in view space
+    want, _ = rr.silhouette_forward_np(va[None], fa, S, _clipped=True)
+    assert c.sum() > 10 and np.array_equal(c, want)
+    rr.set_z_clip(0.0)                                                                   # clipping off: the raw kernel rule drops the face
+    try:
+        c0, _ = rr.silhouette_forward_np(strad, f, S)
+    finally:
+        rr.set_z_clip(5e-4)
+    assert c0.sum() == 0
 
 
 def test_top_k_keeps_nearest_by_depth():

@@ -46,10 +46,11 @@ if args.quick:
     print(f"images {N}  time/launch {dt*1e3:.3f} ms  {dt/N*1e6:.2f} us/image  [SMIL_RESIDENT={os.environ.get('SMIL_RESIDENT')} SMIL_WRAP={os.environ.get('SMIL_WRAP')}]")
     sys.exit(0)
 ws = dm._ws
-off = ((N * dm.F * 4 + 255) // 256) * 256
+FT = (dm.F + 63) // 64 * 64 + 256  # rows of the per-image face tables (raster.hip: faces_padded(F) + CLIP_FX)
+off = ((N * FT * 4 + 255) // 256) * 256
 ctr = ws[off:off + 128].view(torch.int32).cpu().numpy().reshape(8, 4).sum(0)  # (partition, cost class) counters
 n_work = int(ctr[:4].sum())
-tb = ws[: N * dm.F * 4].view(torch.int32).reshape(N, dm.F).cpu().numpy().astype(np.uint32)
+tb = ws[: N * FT * 4].view(torch.int32).reshape(N, FT).cpu().numpy().astype(np.uint32)
 tx0, ty0, tx1, ty1 = tb & 255, (tb >> 8) & 255, (tb >> 16) & 255, tb >> 24
 valid = tx0 <= tx1
 tiles_per_face = np.where(valid, (tx1.astype(int) - tx0 + 1) * (ty1.astype(int) - ty0 + 1), 0)

@@ -45,6 +45,9 @@ def require_gpu(device) -> torch.device:
     return device
 
 
+_SHARED_WS: Dict = {}  # (device type, index) -> the device's rasteriser workspace
+
+
 class DeviceModel:
     """Model constants resident on one GPU (``SmilModel*``)."""
 
@@ -99,9 +102,17 @@ class DeviceModel:
         return self._faces_dev
 
     def workspace(self, N: int, S: int) -> torch.Tensor:
+        """Rasteriser workspace: ONE buffer per device, shared by every model and topology on it (most of it is the scratch
+        arena of the resident workgroups, 6.6 GB whatever the mesh), grown when a call needs more.  Calls are stream ordered and
+        every call rewrites what it reads, so models may take turns; a captured hipGraph keeps the tensor it was captured with
+        alive through ``_ws``."""
         need = int(_lib.load().smil_raster_workspace_bytes(self.handle, N, S))
+        key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+        ws = _SHARED_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _SHARED_WS[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = ws
         return self._ws
 
 

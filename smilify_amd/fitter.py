@@ -427,11 +427,11 @@ class SMALFitter(nn.Module):
         return torch.cat([self.global_rotation[:, None], self.joint_rotations], dim=1)
 
     def get_temporal(self, w_temp):
-        """Reference fitter.py:337-350: (joint_loss, global_loss, trans_loss) over consecutive frames."""
-        total, objs = _TemporalTerm.apply(self, float(w_temp), self._pose_leaf(), self.trans)
-        # the three terms share one backward; hand the graph to the first and return the others detached
-        joint = total - (objs[7] + objs[8]).detach()
-        return joint, objs[7].detach(), objs[8].detach()
+        """Reference fitter.py:337-350: (joint_loss, global_loss, trans_loss) over consecutive frames - three scalars, each
+        carrying its own graph like the reference's: the joint term depends on ``joint_rotations`` only, the global term on
+        ``global_rotation`` only, the translation term on ``trans`` only, so the one evaluated gradient splits exactly."""
+        joint, glob, tr = _TemporalTerm.apply(self, float(w_temp), self._pose_leaf(), self.trans)
+        return joint, glob, tr
 
     def load_checkpoint(self, checkpoint_path, epoch):
         """Reference fitter.py:352-371: per-frame ``<frame>/<epoch>.pkl`` parameter dicts; betas/scales averaged."""
@@ -626,13 +626,16 @@ class SMALFitter(nn.Module):
 
 
 class _TemporalTerm(torch.autograd.Function):
+    """(joint, global, translation) temporal terms; rows of the pose gradient belong to exactly one of them."""
+
     @staticmethod
     def forward(ctx, fitter, w_temp, pose, trans):
         objs, grads = fitter._loss_and_grads(None, [0.0] * 6, w_temp, window=None)
         ctx.grads = grads
-        return objs[6] + objs[7] + objs[8], objs.clone()
+        return objs[6].clone(), objs[7].clone(), objs[8].clone()
 
     @staticmethod
-    def backward(ctx, g_total, _g):
+    def backward(ctx, g_joint, g_global, g_trans):
         g = ctx.grads
-        return None, None, g["pose"] * g_total, g["trans"] * g_total
+        d_pose = torch.cat([g["pose"][:, :1] * g_global, g["pose"][:, 1:] * g_joint], dim=1)
+        return None, None, d_pose, g["trans"] * g_trans

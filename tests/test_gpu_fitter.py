@@ -220,3 +220,33 @@ def test_graph_captured_step_equals_eager_step(tables):
         for n in PARAMS:  # float atomics make the gradient sums order dependent: compare to Adam-step resolution
             np.testing.assert_allclose(par[n].numpy(), ref_par[n].numpy(), atol=2e-4, err_msg=f"{mode}: {n}")
     assert float(ref_objs[-1].sum()) < float(ref_objs[0].sum())
+
+
+def test_temporal_terms_are_three_independent_graphs(tables):
+    """Reference fitter.py:337-350 returns three scalars that each carry a graph; a caller may weight or drop any of them.
+    Every term against the oracle's, each differentiated ALONE: the joint term reaches joint_rotations only, the global term
+    global_rotation only, the translation term trans only."""
+    from oracle import fitter_ref
+    from smilify_amd import synthetic
+
+    t = tables("synthetic")
+    f = synthetic.make_problem(t, 6, 1, 32, DEV, radius=2.2, seed=4, window=3)
+    cpu = lambda x: x.detach().cpu().clone().requires_grad_()  # noqa: E731
+    params = dict(global_rotation=cpu(f.global_rotation), joint_rotations=cpu(f.joint_rotations), trans=cpu(f.trans))
+    want = fitter_ref.temporal(params, 37.0)
+    names = ("joint_rotations", "global_rotation", "trans")
+    for i, own in enumerate(names):
+        for p in (f.global_rotation, f.joint_rotations, f.trans):
+            p.grad = None
+        for p in params.values():
+            p.grad = None
+        got = f.get_temporal(37.0)
+        assert abs(got[i].item() - want[i].item()) <= 1e-5 * abs(want[i].item()) + 1e-9
+        (2.5 * got[i]).backward()
+        (2.5 * want[i]).backward()
+        for n in names:
+            g = getattr(f, n).grad
+            if n == own:
+                np.testing.assert_allclose(g.cpu().numpy(), params[n].grad.numpy(), rtol=2e-4, atol=1e-7, err_msg=f"{own}/{n}")
+            else:
+                assert g is None or float(g.abs().max()) == 0.0, (own, n)

@@ -144,8 +144,13 @@ def test_graph_replay_is_invalidated_by_camera_mask_and_workspace_changes(tables
     both()
     assert fg._graph["graph"] is third          # ... without a re-capture
     np.testing.assert_allclose(fg._pose.cpu().numpy(), fe._pose.cpu().numpy(), rtol=2e-4, atol=2e-6)
-    fg.device_model._ws = None                  # as a larger Renderer call on the same model would do: workspace replaced
+    from smilify_amd import engine as _eng
+
+    held = dict(_eng._SHARED_WS)  # (kept alive: the next buffer gets another address)
+    _eng._SHARED_WS.clear()
+    fg.device_model._ws = None                  # as a larger call on this device would do: workspace replaced
     both()
+    del held
     assert fg._graph["graph"] is not third
 
 

@@ -207,8 +207,11 @@ int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t
  * untouched tiles skip their target read.  target is (N,S,S) fp32, or uint8 holding binary {0,1} masks when
  * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL.
  * From 64 images per call on (and an 8-byte aligned d_ndc), d_ndc is accumulated as 64-bit packed fixed point in the same
- * buffer: the sums are then independent of the order in which tiles finish (bit-reproducible), with an absolute resolution of
- * about 2e-6 of an image's largest component; smaller calls use float atomics (order-dependent last bits).
+ * buffer: every (face, pixel) contribution is rounded once to 2^-30 of a per-image worst-case bound (vertex valence x largest
+ * face pixel box x 0.4 |pix_scale| / sqrt(sigma)) and all further sums are integer adds - independent of the order in which
+ * tiles finish and of how faces are grouped (bit-reproducible).  Relative to an image's largest gradient component that is
+ * ~2e-6 on ordinary meshes and up to a few 1e-4 when one face fills the image (the bound grows with the largest face box);
+ * smaller calls, and images with faces cut at z_clip, use float atomics (order-dependent last bits).
  * d_ndc_scale == NULL: packed rows are decoded in place before the call's work ends on the stream - the caller always sees
  * floats.  d_ndc_scale (N,) given: no decode pass; d_ndc_scale[n] says how image n's row is to be read (see
  * smil_project_backward, which takes the pair as it is and decodes while it reads). */

@@ -438,9 +438,59 @@ def test_faces_that_cross_z_clip_are_cut_at_the_plane(tables):
     target = (torch.rand(Nb, S, S, generator=torch.Generator().manual_seed(2)) > 0.5).float()
     scale_img = torch.full((Nb,), 1.0 / (S * S), device=DEV)
     li, dn, _ = eng.silhouette_l1_fused(dm, big.to(DEV), S, target.to(DEV), eng.image_abs_sum(target.to(DEV)), scale_img)
+    _, _, _, row_scale = eng.silhouette_l1_fused(dm, big.to(DEV), S, target.to(DEV), eng.image_abs_sum(target.to(DEV)), scale_img, packed_out=True)
+    assert float(row_scale[5]) == 0.0 and float(row_scale[33]) == 0.0 and float(row_scale[6]) > 0.0  # float rows / packed rows
     for n in (5, 6, 33):
         li1, dn1, _ = eng.silhouette_l1_fused(dm, big[n:n + 1].to(DEV).contiguous(), S, target[n:n + 1].to(DEV).contiguous(),
                                               eng.image_abs_sum(target[n:n + 1].to(DEV).contiguous()), scale_img[:1].contiguous())
         np.testing.assert_allclose(li[n].item(), li1[0].item(), rtol=1e-5)
         a, b = dn[n].cpu().numpy(), dn1[0].cpu().numpy()
         assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-12, (n, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_packed_gradients_keep_their_resolution_next_to_an_image_filling_face(tables):
+    """The fixed-point scale of a packed launch comes from a worst-case bound per image (valence x largest face box): one face
+    that fills the image coarsens the resolution of that image's whole gradient.  With such a face in the mesh the packed
+    gradient (>= 64 images) must still agree with the float-atomic one (same images in small launches) well inside the
+    gradient tolerance used against the oracle (1e-3 of the largest component): every record is rounded once to 2^-30 of the
+    BOUND, so with a bound ~1e3 times the actual largest component and ~1e3 records per vertex the noise is a few 1e-4 here
+    (a few 1e-6 on ordinary meshes, previous test) - and with the oracle."""
+    from smilify_amd import engine as eng
+    from smilify_amd import model_io, synthetic
+
+    base = tables("synthetic")
+    S, N = 40, 64
+    f0 = synthetic.make_problem(base, N, 1, S, DEV, radius=2.3, seed=12, window=N)
+    f0._refresh_targets()
+    lbs = eng.lbs_forward(f0.device_model, f0.betas.detach(), f0._pose, trans=f0.trans.detach().contiguous(), shared_beta=True, trans_after_joints=True)
+    cam = f0.renderer.cameras
+    cams = eng.CameraSet(cam.R.contiguous(), cam.T.contiguous(), f0.fov.detach(), None, 1, S)
+    ndc, _ = eng.project(cams, lbs["verts"], want_yx=False)
+    # a second topology: the same vertices plus one far, image-filling triangle over three of them
+    faces = np.concatenate([base.faces, np.array([[0, 1, 2]], base.faces.dtype)])
+    ndc = ndc.clone()
+    ndc[:, 0] = torch.tensor([-0.95, -0.9, 9.0], device=DEV)
+    ndc[:, 1] = torch.tensor([0.95, -0.9, 9.0], device=DEV)
+    ndc[:, 2] = torch.tensor([0.0, 0.95, 9.0], device=DEV)
+    from smilify_amd.p3d_renderer import _MeshTopology
+
+    dm = _MeshTopology(np.ascontiguousarray(faces.astype(np.int32)), base.V, torch.device(DEV)).dm
+    target = (torch.rand(N, S, S, generator=torch.Generator().manual_seed(3)) > 0.5).float().to(DEV)
+    tsum = eng.image_abs_sum(target)
+    scale = torch.full((N,), 1.0 / (S * S), device=DEV)
+    _, dn_packed, _ = eng.silhouette_l1_fused(dm, ndc, S, target, tsum, scale)                       # 64 images: packed
+    dn_float = torch.empty_like(dn_packed)
+    for n0 in range(0, N, 16):
+        sl = slice(n0, n0 + 16)
+        eng.silhouette_l1_fused(dm, ndc[sl].contiguous(), S, target[sl].contiguous(), tsum[sl].contiguous(), scale[sl].contiguous(),
+                                d_ndc=dn_float[sl], loss_img=torch.empty(16, device=DEV))
+    a, b = dn_packed.cpu().numpy(), dn_float.cpu().numpy()
+    per_img = np.abs(a - b).reshape(N, -1).max(1) / np.abs(b).reshape(N, -1).max(1)
+    assert np.abs(b).max() > 0 and per_img.max() < 5e-4, per_img.max()
+    # and against the oracle on two of the images (sign(sil - target) / S^2 is the upstream gradient of the L1 term)
+    sil = eng.silhouette_forward(dm, ndc[:2].contiguous(), S).cpu()
+    gs = (torch.sign(sil - target[:2].cpu()) / (S * S)).numpy()
+    with render_ref.select_mode(1):
+        want = render_ref.silhouette_backward_np(ndc[:2].cpu().numpy(), faces, S, gs)[..., :2]
+    sc = np.abs(want).max()
+    assert np.abs(a[:2] - want).max() < 2e-3 * sc, (np.abs(a[:2] - want).max(), sc)

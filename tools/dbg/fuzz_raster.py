@@ -19,26 +19,32 @@ def scene(t, N, S, dist, seed, scale=1.0):
     R, T = render_ref.look_at_view_transform(dist, float(g.initial_seed() % 60), torch.linspace(0, 300, N))
     return render_ref.project_to_ndc(verts, R, T, torch.full((N,), 60.0)).contiguous()
 bad = 0
+CLIP = len(sys.argv) > 3 and sys.argv[3] == "clip"  # camera INSIDE the mesh's reach: faces cross z_clip and get cut (clip_faces)
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)
     key = ["synthetic", "stick", "mouse"][int(rng.integers(0, 3))]
     t, dm = models[key], dms[key]
     S = int(rng.integers(9, 140)); K = int(rng.choice([1, 2, 5, 17, 64, 100, 128]))
     dist = float(np.exp(rng.uniform(np.log(1.2), np.log(40.0)))) * (1.5 if key == "mouse" else 1.0)
+    if CLIP:
+        dist = float(rng.uniform(0.05, 0.9)) * (1.5 if key == "mouse" else 1.0)
     N = int(rng.integers(1, 4))
     ndc = scene(t, N, S, dist, seed)
     with render_ref.select_mode(1):
         ref1, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)
     got = engine.silhouette_forward(dm, ndc.to(DEV), S, engine.raster_settings(K=K)).cpu().numpy()
     d1 = np.abs(got - ref1)
-    ok = d1.mean() < 5e-6 and np.mean(d1 > 1e-4) < 5e-3 and d1[ncand <= K].max(initial=0.0) < 3e-4
+    # (cut faces carry vertices at |xy| up to 1e3 NDC units: fp32 cancellation on both sides; looser there)
+    ok = d1.mean() < (2e-4 if CLIP else 5e-6) and np.mean(d1 > 1e-4) < (3e-2 if CLIP else 5e-3) and (CLIP or d1[ncand <= K].max(initial=0.0) < 3e-4)
     gs = torch.from_numpy(rng.standard_normal((N, S, S)).astype(np.float32))
     with render_ref.select_mode(1):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy(), K=K)[..., :2]
     gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), engine.raster_settings(K=K)).cpu().numpy()
     nrm = np.linalg.norm(want)
     cos = (gotg * want).sum() / (np.linalg.norm(gotg) * nrm + 1e-30) if nrm > 0 else 1.0
-    ok = ok and (cos > 0.99 or nrm < 1e-6) and np.isfinite(gotg).all()
+    ok = ok and (cos > (0.97 if CLIP else 0.99) or nrm < 1e-6) and np.isfinite(gotg).all()
+    st = engine.raster_stats(dm, N)
+    print(f"cut={st['straddling_faces']:4d} lost={st['unclipped_faces']:3d} ", end="")
     print(f"seed {seed:3d} {key:9s} N={N} S={S:3d} K={K:3d} dist={dist:6.2f} maxcand={ncand.max():5d} mean|d|={d1.mean():.2e} frac>1e-4={np.mean(d1>1e-4):.1e} cos={cos:.5f} {'ok' if ok else 'FAIL'}", flush=True)
     bad += (not ok)
 print("failures", bad)

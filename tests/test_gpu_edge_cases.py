@@ -101,8 +101,8 @@ def test_dense_tile_processed_in_sub_tiles(key, dist, tables):
     gs = torch.ones(1, S, S)
     want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
     gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
-    cos = (gotg * want).sum() / (np.linalg.norm(gotg) * np.linalg.norm(want) + 1e-30)
-    assert cos > 0.995, cos
+    rel = np.linalg.norm(gotg - want) / np.linalg.norm(want)
+    assert rel < 1e-4 and np.abs(gotg - want).max() < 1e-4 * np.abs(want).max(), rel   # (measured: 1.2e-6 relative L2)
 
 
 def test_full_size_properties_cfg2(tables):
@@ -339,10 +339,10 @@ def test_sixty_thousand_faces_in_a_handful_of_tiles():
     assert ncand.max() > 4000
     got = eng.silhouette_forward(dm, ndc.to(DEV), S).cpu().numpy()
     d = np.abs(got - ref)
-    assert d.mean() < 2e-4 and np.mean(d > 1e-2) < 0.005, (d.mean(), d.max())
+    assert d.mean() < 1e-6 and d.max() < 1e-4, (d.mean(), d.max())   # (measured: 4e-9 / 4e-7)
     gs = torch.ones(1, S, S)
     with render_ref.select_mode(1):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())[..., :2]
     gotg = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV)).cpu().numpy()
-    cos = (gotg * want).sum() / (np.linalg.norm(gotg) * np.linalg.norm(want) + 1e-30)
-    assert cos > 0.995, cos
+    rel = np.linalg.norm(gotg - want) / np.linalg.norm(want)
+    assert rel < 1e-4 and np.abs(gotg - want).max() < 1e-4 * np.abs(want).max(), rel   # (measured: 1.2e-6 relative L2)

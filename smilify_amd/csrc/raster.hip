@@ -98,14 +98,20 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 // -DRASTER_EXPERIMENT: ablation knobs read from the environment by the host side (SMIL_STOP, SMIL_WRAP, SMIL_RESIDENT);
 // results are garbage under SMIL_WRAP / SMIL_STOP by design - timing experiments only, never in libsmilfit.so.
 #ifdef DBG_TIMERS
-#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0;
+#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0; unsigned long long tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub_last = tlast;
+#define TSUB(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tsub[k] += now_ - tsub_last; tsub_last = now_; }  // finer marks, independent of TMARK
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
+#ifdef DBG_STATS  // work counters: thousands of waves adding to the same few words - the launch runs several times longer, so the timers are read without them
 #define STAT(k, v) { const unsigned long long v_ = (unsigned long long)(v); /* (all lanes: v may hold a ballot) */ if (a.dbg && lane == 0) atomicAdd(&a.dbg[k], v_); }
+#else
+#define STAT(k, v)
+#endif
 #define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
         atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); \
-        atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); }
+        atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.dbg[32 + k_], tsub[k_]); }
 #else
 #define TIMERS_INIT
+#define TSUB(k)
 #define TMARK(k)
 #define STAT(k, v)
 #define TIMERS_FLUSH
@@ -1112,6 +1118,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
     const uint32_t *const items = a.items + (size_t)part * 2u * a.item_cap;
     while (n_units > 0u) {
         unsigned int unit = 0;
+        TSUB(0)
         if (lane == 0) unit = atomicAdd(&a.ctr->deal[part].next, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= n_units) break;
@@ -1142,6 +1149,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         // boxes of the 64-face groups (ascending id) when the image's lists did not fit
         const uint2 td = a.tdesc ? a.tdesc[code] : make_uint2(0u, 0xFFFFFFFFu);
         const bool binned = td.y != 0xFFFFFFFFu;  // (wave-uniform)
+        TSUB(1)
         const Rec3 *const list_src = binned ? a.lists + (size_t)n * a.list_cap + td.x : slist;
         int list_total;
         if (binned) {
@@ -1163,6 +1171,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
         }
         const bool may_truncate = list_total > K;
+        TSUB(2)
         // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
         // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
         const uint32_t krange = kmax - kmin;
@@ -1178,6 +1187,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             __syncthreads();
         }
         TMARK(0)
+        TSUB(3)
 #ifdef RASTER_EXPERIMENT
         if (a.stop_after == 0) continue;
 #endif
@@ -1372,6 +1382,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             if (any_trunc)
                 for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
+            TSUB(0)
             int n_cmp = 0;
             float rmax2 = 0.f;  // largest |closest point - pixel|^2 over the records: bounds the gradient sums of pass 3
             if (vbase > 0) {
@@ -1419,6 +1430,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 }
             }
             __syncthreads();
+            TSUB(4)
             if (any_trunc) {
                 if (nbits > 0) {  // second digit: counted above
                     pick_digit(lds.hist, lane, b2, pre, need, n_eq);
@@ -1485,6 +1497,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 __syncthreads();
             }
             TMARK(2)
+            TSUB(5)
 #ifdef RASTER_EXPERIMENT
             if (a.stop_after == 3) { p_lo += span; continue; }
 #endif
@@ -1517,6 +1530,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
             const float coef = -g * alpha * a.inv_sigma;
             const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
+            TSUB(6)
             STAT(25, __popcll(__ballot(active)))
             if (MODE != MODE_FWD && __ballot(active) != 0ull) {
                 float *dn = a.d_ndc + (size_t)n * a.V * 2;
@@ -1662,6 +1676,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             }
             __syncthreads();
             TMARK(4)
+            TSUB(7)
             p_lo += span;
         }
 #ifdef DBG_TIMERS
@@ -1839,9 +1854,11 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
 #ifdef DBG_TIMERS
     {
         static unsigned long long *dbg_dev = nullptr;
-        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 256); (void)hipMemset(dbg_dev, 0, 256); }
-        unsigned long long h[32];
-        (void)hipMemcpy(h, dbg_dev, 256, hipMemcpyDeviceToHost);  // totals of the launches so far
+        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 512); (void)hipMemset(dbg_dev, 0, 512); }
+        unsigned long long h[64];
+        (void)hipMemcpy(h, dbg_dev, 512, hipMemcpyDeviceToHost);  // totals of the launches so far
+        fprintf(stderr, "[dbg sub] other %.3e  item fetch %.3e  list bounds %.3e  sort %.3e  blend sweep %.3e  select %.3e  epilogue %.3e  pass3 %.3e\n",
+                (double)h[32], (double)h[33], (double)h[34], (double)h[35], (double)h[36], (double)h[37], (double)h[38], (double)h[39]);
         fprintf(stderr, "[dbg timers] list %.3e  pass1 sweep %.3e  blend+select %.3e  pass1 staging %.3e  pass3 %.3e cycles (summed over waves); "
                 "first wave exit %.3e, last wave exit %.3e cycles after the first start\n",
                 (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)(h[6] - h[5]), (double)(h[7] - h[5]));
@@ -1851,7 +1868,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e; chunks walked %.4e of %.4e, pixels still open at the end %.4e\n",
                 (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25], (double)h[28], (double)h[29], (double)h[30]);
         fprintf(stderr, "[dbg stats] staged faces with a non-empty pixel box %.4e\n", (double)h[31]);
-        (void)hipMemset(dbg_dev, 0, 256);
+        (void)hipMemset(dbg_dev, 0, 512);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;
     }

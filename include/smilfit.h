@@ -168,6 +168,20 @@ int smil_project_backward(const SmilCameras *cam, const float *pts, int32_t P, c
                           void *stream);
 int smil_fov_reduce(const SmilCameras *cam, const float *d_fov_img, float *d_fov, void *stream);
 
+/* smil_lbs_backward taking its upstream gradients on the IMAGE PLANE, as the fit iteration has them: d_ndc (N,V,2) on the
+ * projected vertices (rows may be the packed fixed point smil_silhouette_l1_fused leaves, with d_ndc_scale (N,) as in
+ * smil_project_backward) and d_yx_joints (N,J,2) on the projected joints (y, x) in pixels; either may be NULL.  One kernel per
+ * frame does what smil_project_backward2 + smil_lbs_backward do (backward of p3d_renderer.py:137-146 into the backward of
+ * smal_torch.py:240-351) without writing the (B,V,3) vertex gradient to memory.  g->d_verts, g->d_joints and g->d_del_v
+ * must be NULL; d_joints (B,J,3) receives the world-space joint gradient (an output); d_fov_img (N,) or NULL is ADDED to
+ * as by smil_project_backward.  saved->verts and saved->joints are read.  Results equal the two-call route up to fp32
+ * summation order.  smil_lbs_backward_ndc_supported: 1 when this entry handles the model (no pose blend shapes, the frame's
+ * vertex gradient and rest vertices fit 80 KB of LDS) with nB_used shape coefficients (<= 9) and `views` views per frame (<= 32). */
+int smil_lbs_backward_ndc(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *saved, const SmilLbsGrads *g,
+                          const SmilCameras *cam, const float *d_ndc, const float *d_ndc_scale, const float *d_yx_joints,
+                          float *d_joints, float *d_fov_img, void *stream);
+int smil_lbs_backward_ndc_supported(const SmilModel *m, int32_t nB_used, int32_t views);
+
 /* ------------------------------------------------------------------------------------------
  * Soft silhouette.  Replaces MeshRasterizer(naive, K faces per pixel, blur) + SoftSilhouetteShader
  * (p3d_renderer.py:41-52,142-146; arithmetic in un-vendored pytorch3d 0.7.8).

@@ -59,10 +59,13 @@ struct SmilModel {
     int *jreg_colptr = nullptr;   // CSC by vertex (V+1)
     int *jreg_row = nullptr;      // joint ids
     float *jreg_cval = nullptr;
+    int2 *jreg_vfirst = nullptr;  // (V) the first CSC entry of every vertex inline: {joint | entries << 16, weight bits} (most have <= 1)
     int *bone_ptr = nullptr;      // skin weights by bone (J+1)
     int *bone_vid = nullptr;
     float *bone_w = nullptr;
     float *J_static = nullptr;    // (J,3)
+    float *jreg_shape = nullptr;  // (nB,J,3) = J_regressor @ shapedirs[k]: d beta through the rest joints without a pass over the vertices
+    int *bone_order = nullptr;    // (J) bones by falling vertex count (balanced dealing of the bone lists to waves)
     float *posedirs = nullptr;    // (9(J-1),3V) or null
     std::vector<void *> allocations;
 };
@@ -103,3 +106,60 @@ __device__ __forceinline__ float block_sum(float v, float *smem /* >= 16 floats 
     }
     return r;
 }
+
+// Sums of up to TWELVE values per lane over the 64 lanes in 30 instructions (twelve wave_sum calls: 130).  gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / odd and even 16-lane rows between two registers, so one swap and
+// one add fold a PAIR of values to half the lanes each: 12 values -> 6 registers (component i in lanes 0-31, i + 6 in lanes
+// 32-63) -> 3 registers (rows hold components i, i + 3, i + 6, i + 9), then four DPP adds inside the rows.
+// On return every lane of row r (lanes 16 r .. 16 r + 15) holds the sum of component i + 3 r in q[i], i = 0 .. 2.
+// (spelled in assembly: with the __builtin_amdgcn_permlane*_swap builtins hipcc 7.2 adds the FIRST result to itself - it loses the
+// second, in-place updated operand; tools/dbg/sum12_test.hip checks this function against a serial sum)
+__device__ __forceinline__ float swap32_add(float a, float b) {  // lanes 0-31: a[l] + a[l + 32]; lanes 32-63: b[l - 32] + b[l]
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {  // rows 0, 2: a's row + a's next row; rows 1, 3: b's previous row + b's row
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ void wave_sum12(const float (&v)[12], float (&q)[3]) {
+    float h[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = swap32_add(v[i], v[i + 6]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float x = swap16_add(h[i], h[i + 3]);
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));  // row_mirror
+        q[i] = x;
+    }
+}
+
+// ---- FoV-perspective camera of image n (project.hip; also read by the fused LBS backward in lbs.hip) ----
+#define SMIL_ZNEAR 0.001f  // Renderer.DEFAULT_ZNEAR (p3d_renderer.py:24)
+
+struct CamParams {
+    float R[9];
+    float T[3];
+    float k00, k11, tanh_;  // tan(fov/2)
+};
+
+__device__ __forceinline__ CamParams load_camera(const SmilCameras &c, int n) {
+    CamParams p;
+    const float *R = c.R + (size_t)(n % c.nR) * 9;
+    const float *T = c.T + (size_t)(n % c.nT) * 3;
+    for (int i = 0; i < 9; ++i) p.R[i] = R[i];
+    for (int i = 0; i < 3; ++i) p.T[i] = T[i];
+    const float fov = c.fov[n % c.nFov];
+    const float asp = c.aspect ? c.aspect[n % c.nAspect] : 1.0f;
+    const float t = tanf((fov * 0.017453292519943295f) / 2.0f);
+    const float max_y = t * SMIL_ZNEAR;
+    const float max_x = max_y * asp;
+    p.k00 = 2.0f * SMIL_ZNEAR / (max_x - (-max_x));
+    p.k11 = 2.0f * SMIL_ZNEAR / (max_y - (-max_y));
+    p.tanh_ = t;
+    return p;
+}
+

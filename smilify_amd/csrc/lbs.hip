@@ -8,6 +8,8 @@
 // row-major (12 floats) instead of the reference's 4x4 (the last row is constant).  The skin table is
 // one packed uint32 (4 x u8 bone ids) + one float4 of weights per vertex: 20 B/vertex, read
 // coalesced; the per-frame joint transforms (J x 48 B) are staged in LDS by each workgroup.
+#include <algorithm>
+
 #include "common.h"
 
 #define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels
@@ -481,6 +483,11 @@ struct ChainBwdArgs {
     float *d_theta, *d_logscale, *d_btrans, *d_Jrest;
     float *d_Rs_out;          // (B,J,9) gradient on the rotation matrices themselves (matrix-valued theta), or NULL
     int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
+    // the shape gradient that flows through the REST JOINTS, d beta[k] += sum_j d J_rest[j] . (J_regressor shapedirs[k])[j]
+    // (model table jreg_shape): added here when the caller's vertex pass leaves it out (smil_lbs_backward_ndc), else NULL
+    const float *jreg_shape;
+    float *d_beta_frame, *d_beta_shared;  // (B,nB_used) rows ADDED to / (nB_used,) atomically added to; one of them
+    int nB_used;
 };
 
 // Reverse walk of the kinematic chain, one wavefront per frame, LDS accumulators for the gradients
@@ -621,6 +628,27 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                 for (int k = 0; k < 3; ++k) a.d_btrans[o * 3 + k] = 0.f;
         }
     }
+    if (a.jreg_shape) {  // (uniform)
+        float *red = sG;  // this wave's transforms are no longer needed: [wave][k] partial sums at the start of every wave's area
+        for (int k = 0; k < a.nB_used; ++k) {
+            float r = 0.f;
+            if (live)
+                for (int i = lane; i < 3 * J; i += WAVE) r += sdJ[i] * a.jreg_shape[(size_t)k * 3 * J + i];
+            r = wave_sum(r);
+            if (lane == 0) {
+                if (a.d_beta_frame) { if (live) a.d_beta_frame[fb * a.nB_used + k] += r; }
+                else red[k] = r;
+            }
+        }
+        if (a.d_beta_shared) {  // the block's frames first, then one atomic per shape coefficient and block
+            __syncthreads();
+            if ((int)threadIdx.x < a.nB_used) {
+                float r = 0.f;
+                for (int w = 0; w < FRAMES_PER_BLOCK; ++w) r += smem[(size_t)w * J * 30 + threadIdx.x];
+                if (r != 0.f) atomicAdd(&a.d_beta_shared[threadIdx.x], r);
+            }
+        }
+    }
 }
 
 #define BETA_CHUNK 8
@@ -733,6 +761,313 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     }
 }
 
+
+// =============================================================================================
+// backward from the image plane in one pass per frame: projection backward (vertices and joints), skinning backward and
+// shape backward, with the frame's world-space vertex gradient held in LDS instead of a (B,V,3) tensor in memory.
+// Replaces k_project_bwd + k_skin_bwd_transforms + k_shape_bwd for the fit iteration (SMALFitter.forward's backward through
+// p3d_renderer.py:137-146 and smal_torch.py:240-351); the shape gradient through the rest joints is added by k_chain_bwd from
+// the jreg_shape table.  One workgroup walks frames blockIdx.x, + gridDim.x, ...; thread t owns vertices t, t + NT, ...
+// in every phase, so the phases of a frame need one barrier (before the bone lists gather other threads' vertices).
+// =============================================================================================
+#ifndef NDC_BWD_THREADS
+#define NDC_BWD_THREADS 512
+#endif
+#ifndef NDC_BWD_MIN_WAVES
+#define NDC_BWD_MIN_WAVES 4   // waves per SIMD the register allocation is held to (two workgroups of 512 threads per CU)
+#endif
+#define NDC_BWD_MAX_BETAS 9   // + 3 translation terms = the twelve values wave_sum12 folds at once
+#define NDC_BWD_MAX_VIEWS 32
+
+struct LbsBwdNdcArgs {
+    SmilCameras cam;
+    const float *verts, *joints, *A, *v_skin;   // saved forward tensors (B,V,3), (B,J,3), (B,J,12), (nS,V,3)
+    const float *d_ndc, *d_ndc_scale, *d_yx;    // (N,V,2) [packed rows: see smil_project_backward], (N,), (N,J,2); any may be NULL
+    const uint32_t *skin_idx;
+    const float4 *skin_w;
+    const int *bone_ptr, *bone_vid, *bone_order;
+    const float *bone_w;
+    const int *colptr, *row;
+    const int2 *vfirst;
+    const float *cval, *sd;
+    float *d_A, *d_joints, *d_beta_frame, *d_beta_shared, *d_trans, *d_fov_img;
+    int B, V, J, nS, nB_used, regress, trans_after;
+};
+
+__device__ __forceinline__ void project_point_bwd(const float *cp /* 15 floats: R, T, k00, k11, - */, float x, float y, float z,
+                                                  float dxn, float dyn, float &gx, float &gy, float &gz, float &fsum) {
+    const float vx = x * cp[0] + y * cp[3] + z * cp[6] + cp[9];
+    const float vy = x * cp[1] + y * cp[4] + z * cp[7] + cp[10];
+    const float vz = x * cp[2] + y * cp[5] + z * cp[8] + cp[11];
+    const float iz = 1.0f / vz;
+    const float xn = vx * cp[12] * iz, yn = vy * cp[13] * iz;
+    const float dvx = dxn * cp[12] * iz, dvy = dyn * cp[13] * iz;
+    const float dvz = -(xn * dxn + yn * dyn) * iz;
+    gx += cp[0] * dvx + cp[1] * dvy + cp[2] * dvz;
+    gy += cp[3] * dvx + cp[4] * dvy + cp[5] * dvz;
+    gz += cp[6] * dvx + cp[7] * dvy + cp[8] * dvz;
+    fsum += dxn * xn + dyn * yn;
+}
+
+// Every loop over the thread's vertices works on NDC_UNR of them at a time, loads first: with two workgroups per CU the time of
+// a frame is its chain of memory round trips, and one round trip then covers NDC_UNR vertices (measured on 4096 STICK frames:
+// 308 us with one vertex per round trip, see profiles/r3_small_kernels.md).
+#define NDC_UNR 3    // phase 1 (five registers per vertex in flight)
+#define NDC_UNR2 2   // phase 2 (seven + three per shape coefficient)
+
+// NBT: shape coefficients held in registers per vertex (3, 6 or 9: the smallest that covers nB_used).
+template <int NBT>
+__global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_ndc(LbsBwdNdcArgs a) {
+    extern __shared__ float smem[];
+    const int V = a.V, J = a.J, views = a.cam.views;
+    constexpr int NT = NDC_BWD_THREADS, NW = NT / WAVE;
+    float *dvL = smem;                  // (V,3) the frame's vertex gradient
+    float *vpL = dvL + 3 * V;           // (V,3) the vertices the skinning transforms were applied to (v_shaped / v_posed)
+    float *sA = smem + ((6 * V + 3) & ~3);  // (J,12), 16-byte aligned
+    float *sDJ = sA + 12 * J;           // (J,3) gradient on the posed joints
+    float *sCam = sDJ + 3 * J;          // (views,16)
+    float *sFov = sCam + 16 * views;    // (views) raw fov sums of the frame's images
+    float *red = sFov + views;          // (NW,12)
+    int *sBone = reinterpret_cast<int *>(red + NW * 12);  // (J,3) {first entry, end, bone} in the order the waves take them
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const float h = 0.5f * (float)a.cam.S;
+    for (int o = tid; o < J; o += NT) {
+        const int j = a.bone_order[o];
+        sBone[3 * o] = a.bone_ptr[j]; sBone[3 * o + 1] = a.bone_ptr[j + 1]; sBone[3 * o + 2] = j;
+    }
+    if (a.nS == 1)  // one set of rest vertices for every frame: staged once (each thread its own vertices; phase 3 is behind a barrier)
+        for (int v = tid; v < V; v += NT) { vpL[3 * v] = a.v_skin[3 * v]; vpL[3 * v + 1] = a.v_skin[3 * v + 1]; vpL[3 * v + 2] = a.v_skin[3 * v + 2]; }
+    float beta_acc = 0.f;               // thread k < nB_used: the shared shape gradient summed over this workgroup's frames
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        // ---- phase 0: the frame's transforms, cameras and joint gradient ----
+        for (int i = tid; i < 12 * J; i += NT) sA[i] = a.A[(size_t)b * J * 12 + i];
+        if (tid < views) {
+            const CamParams cp = load_camera(a.cam, b * views + tid);
+            float *o = sCam + 16 * tid;
+            for (int i = 0; i < 9; ++i) o[i] = cp.R[i];
+            for (int i = 0; i < 3; ++i) o[9 + i] = cp.T[i];
+            o[12] = cp.k00; o[13] = cp.k11;
+            sFov[tid] = 0.f;
+        }
+        __syncthreads();
+        if (tid < WAVE) {  // one wave: lane = joint (strided)
+            for (int j0 = 0; j0 < J; j0 += WAVE) {
+                const int j = j0 + lane;
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+                float x = 0.f, y = 0.f, z = 1.f;
+                if (j < J && a.d_yx) { const float *X = a.joints + ((size_t)b * J + j) * 3; x = X[0]; y = X[1]; z = X[2]; }
+                for (int view = 0; view < views; ++view) {
+                    float fsum = 0.f;
+                    if (j < J && a.d_yx) {
+                        const size_t o = (size_t)(b * views + view) * J + j;
+                        project_point_bwd(sCam + 16 * view, x, y, z, -h * a.d_yx[o * 2 + 1], -h * a.d_yx[o * 2], gx, gy, gz, fsum);
+                    }
+                    if (a.d_fov_img && a.d_yx) {
+                        const float r = wave_sum(fsum);
+                        if (lane == 0 && r != 0.f) atomicAdd(&sFov[view], r);
+                    }
+                }
+                if (j < J) {
+                    sDJ[3 * j] = gx; sDJ[3 * j + 1] = gy; sDJ[3 * j + 2] = gz;
+                    if (a.d_joints) { float *o = a.d_joints + ((size_t)b * J + j) * 3; o[0] = gx; o[1] = gy; o[2] = gz; }
+                }
+            }
+        }
+        // ---- phase 1: projection backward of the vertices, view by view, into this thread's rows of dvL ----
+        const float *vb = a.verts + (size_t)b * V * 3;
+        if (a.nS != 1) {
+            const float *vpb = a.v_skin + (size_t)b * V * 3;
+            for (int v = tid; v < V; v += NT) { vpL[3 * v] = vpb[3 * v]; vpL[3 * v + 1] = vpb[3 * v + 1]; vpL[3 * v + 2] = vpb[3 * v + 2]; }
+        }
+        if (!a.d_ndc)
+            for (int v = tid; v < V; v += NT) { dvL[3 * v] = 0.f; dvL[3 * v + 1] = 0.f; dvL[3 * v + 2] = 0.f; }
+        else
+            for (int view = 0; view < views; ++view) {
+                const int n = b * views + view;
+                const float *cp = sCam + 16 * view;
+                const float sc = a.d_ndc_scale ? a.d_ndc_scale[n] : 0.f;
+                const float2 *dn = reinterpret_cast<const float2 *>(a.d_ndc) + (size_t)n * V;
+                float fsum = 0.f;
+                for (int v0 = tid; v0 < V; v0 += NDC_UNR * NT) {
+                    float2 raw[NDC_UNR];
+                    float X[NDC_UNR][3];
+#pragma unroll
+                    for (int u = 0; u < NDC_UNR; ++u) {
+                        const int v = min(v0 + u * NT, V - 1);
+                        raw[u] = dn[v];
+                        X[u][0] = vb[3 * v]; X[u][1] = vb[3 * v + 1]; X[u][2] = vb[3 * v + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NDC_UNR; ++u) {
+                        const int v = v0 + u * NT;
+                        if (v >= V) continue;
+                        float dxn = raw[u].x, dyn = raw[u].y;
+                        if (sc != 0.f) {  // x * 2^32 + y in two's complement: a negative y borrowed one from the high word
+                            const int qy = __float_as_int(raw[u].x), qx = __float_as_int(raw[u].y) - (qy >> 31);
+                            dxn = sc > 0.f ? (float)qx * sc : 0.f;
+                            dyn = sc > 0.f ? (float)qy * sc : 0.f;
+                        }
+                        float gx = 0.f, gy = 0.f, gz = 0.f;
+                        project_point_bwd(cp, X[u][0], X[u][1], X[u][2], dxn, dyn, gx, gy, gz, fsum);
+                        if (view > 0) { gx += dvL[3 * v]; gy += dvL[3 * v + 1]; gz += dvL[3 * v + 2]; }
+                        dvL[3 * v] = gx; dvL[3 * v + 1] = gy; dvL[3 * v + 2] = gz;
+                    }
+                }
+                if (a.d_fov_img) {
+                    const float r = wave_sum(fsum);
+                    if (lane == 0 && r != 0.f) atomicAdd(&sFov[view], r);
+                }
+            }
+        __syncthreads();  // sDJ (and the fov sums) complete
+        // ---- phase 2: + regressor^T d_joints; translation and shape terms ----
+        float term[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) term[i] = 0.f;
+#ifdef NDC_ABL_NO_REG  // (timing experiment, garbage results)
+        const bool reg = false;
+#else
+        const bool reg = a.regress && a.d_yx;
+#endif
+        for (int v0 = tid; v0 < V; v0 += NDC_UNR2 * NT) {
+            uint32_t ids[NDC_UNR2];
+            float4 w4[NDC_UNR2];
+            int2 first[NDC_UNR2];  // the vertex's first regressor entry {joint | entries << 16, weight bits}
+            float s3[NDC_UNR2][NBT][3];
+#pragma unroll
+            for (int u = 0; u < NDC_UNR2; ++u) {
+                const int v = min(v0 + u * NT, V - 1);
+                ids[u] = a.skin_idx[v];
+                w4[u] = a.skin_w[v];
+                first[u] = reg ? a.vfirst[v] : make_int2(0, 0);
+#pragma unroll
+                for (int k = 0; k < NBT; ++k)
+                    if (k < a.nB_used) {
+                        const float *p = a.sd + (size_t)k * 3 * V + 3 * v;
+                        s3[u][k][0] = p[0]; s3[u][k][1] = p[1]; s3[u][k][2] = p[2];
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < NDC_UNR2; ++u) {
+                const int v = v0 + u * NT;
+                if (v >= V) continue;
+                float dv[3] = {dvL[3 * v], dvL[3 * v + 1], dvL[3 * v + 2]};
+                if (a.trans_after) { term[9] += dv[0]; term[10] += dv[1]; term[11] += dv[2]; }
+                const int n_ent = first[u].x >> 16;
+                if (n_ent > 0) {
+                    const float w0 = __int_as_float(first[u].y);
+                    const float *dj0 = sDJ + 3 * (first[u].x & 0xFFFF);
+                    dv[0] += w0 * dj0[0]; dv[1] += w0 * dj0[1]; dv[2] += w0 * dj0[2];
+                    if (n_ent > 1)  // (rare: a vertex that several joints regress from)
+                        for (int e = a.colptr[v] + 1; e < a.colptr[v + 1]; ++e) {
+                            const float w = a.cval[e];
+                            const float *dj = sDJ + 3 * a.row[e];
+                            dv[0] += w * dj[0]; dv[1] += w * dj[1]; dv[2] += w * dj[2];
+                        }
+                    dvL[3 * v] = dv[0]; dvL[3 * v + 1] = dv[1]; dvL[3 * v + 2] = dv[2];
+                }
+                if (!a.trans_after) { term[9] += dv[0]; term[10] += dv[1]; term[11] += dv[2]; }
+#ifdef NDC_ABL_NO_SHAPE  // (timing experiment, garbage results)
+                continue;
+#endif
+                if (a.nB_used == 0) continue;
+                const float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+                float T[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) T[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < SMIL_MAX_BONES; ++k) {
+                    if (w[k] == 0.f) continue;
+                    const float4 *Ak = reinterpret_cast<const float4 *>(sA) + 3 * ((ids[u] >> (8 * k)) & 0xFF);  // (three 16-byte LDS reads per bone)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const float4 r = Ak[m];
+                        T[3 * m] += w[k] * r.x; T[3 * m + 1] += w[k] * r.y; T[3 * m + 2] += w[k] * r.z;
+                    }
+                }
+                float dvp[3];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dvp[n] = T[n] * dv[0] + T[3 + n] * dv[1] + T[6 + n] * dv[2];
+#pragma unroll
+                for (int k = 0; k < NBT; ++k)
+                    if (k < a.nB_used) term[k] += s3[u][k][0] * dvp[0] + s3[u][k][1] * dvp[1] + s3[u][k][2] * dvp[2];
+            }
+        }
+        if (a.trans_after && tid < J) { term[9] += sDJ[3 * tid]; term[10] += sDJ[3 * tid + 1]; term[11] += sDJ[3 * tid + 2]; }
+        {
+            float q[3];
+            wave_sum12(term, q);
+            if ((lane & 15) == 0)
+                for (int i = 0; i < 3; ++i) red[wid * 12 + i + 3 * (lane >> 4)] = q[i];
+        }
+        __syncthreads();  // every vertex row of dvL is final; the wave sums are in `red`
+        if (tid < 12) {
+            float r = 0.f;
+            for (int w = 0; w < NW; ++w) r += red[w * 12 + tid];
+            if (tid < NDC_BWD_MAX_BETAS) {
+                if (tid < a.nB_used) {
+                    if (a.d_beta_frame) a.d_beta_frame[(size_t)b * a.nB_used + tid] = r;
+                    else beta_acc += r;
+                }
+            } else if (a.d_trans) {
+                a.d_trans[3 * b + tid - NDC_BWD_MAX_BETAS] = r;
+            }
+        }
+        if (a.d_fov_img && tid < views && sFov[tid] != 0.f) atomicAdd(&a.d_fov_img[b * views + tid], sFov[tid]);
+        // ---- phase 3: d_A[j] = sum_{v in bone j} w (dv (x) [v_skin; 1]), one wave per bone, longest lists first.  The list
+        // entries of the NEXT 64-entry segment (of this bone or of the wave's next one) are requested before this segment's
+        // gathers: those come from LDS, so the list is the only memory round trip and it is hidden ----
+#ifdef NDC_ABL_NO_BONES  // (timing experiment, garbage results)
+        int o = J;
+#else
+        int o = wid;
+#endif
+        int e0 = 0, e1 = 0;
+        if (o < J) { e0 = sBone[3 * o]; e1 = sBone[3 * o + 1]; }
+        int vid_n = 0;
+        float w_n = 0.f;
+        if (o < J && e0 + lane < e1) { vid_n = a.bone_vid[e0 + lane]; w_n = a.bone_w[e0 + lane]; }
+        float acc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+        while (o < J) {  // (wave-uniform)
+            const int vid = vid_n;
+            const float w = w_n;  // (0 beyond the end of the list)
+            // where the next segment starts
+            const int j_cur = sBone[3 * o + 2];
+            const bool bone_done = e0 + WAVE >= e1;
+            int o_nx = o, e0_nx = e0 + WAVE, e1_nx = e1;
+            if (bone_done) {
+                o_nx = o + NW;
+                e0_nx = e1_nx = 0;
+                if (o_nx < J) { e0_nx = sBone[3 * o_nx]; e1_nx = sBone[3 * o_nx + 1]; }
+            }
+            vid_n = 0; w_n = 0.f;
+            if (o_nx < J && e0_nx + lane < e1_nx) { vid_n = a.bone_vid[e0_nx + lane]; w_n = a.bone_w[e0_nx + lane]; }
+            {
+                const float x = vpL[3 * vid], y = vpL[3 * vid + 1], z = vpL[3 * vid + 2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float g = w * dvL[3 * vid + r];
+                    acc[4 * r] += g * x; acc[4 * r + 1] += g * y; acc[4 * r + 2] += g * z; acc[4 * r + 3] += g;
+                }
+            }
+            if (bone_done) {
+                float q[3];
+                wave_sum12(acc, q);
+                if ((lane & 15) == 0) {
+                    float *o12 = a.d_A + ((size_t)b * J + j_cur) * 12 + 3 * (lane >> 4);
+                    o12[0] = q[0]; o12[1] = q[1]; o12[2] = q[2];
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+            }
+            o = o_nx; e0 = e0_nx; e1 = e1_nx;
+        }
+        __syncthreads();  // the next frame overwrites dvL, sA, sDJ
+    }
+    if (a.d_beta_shared && tid < a.nB_used && beta_acc != 0.f) atomicAdd(&a.d_beta_shared[tid], beta_acc);
+}
+
 // out[c] = sum_b in[b][c]; grid ceil(C/64), block (64,4)
 __global__ void k_reduce_rows(const float *__restrict__ in, float *__restrict__ out, int B, int C) {
     __shared__ float part[4][64];
@@ -751,13 +1086,52 @@ int smil_reduce_rows(const float *in, float *out, int B, int C, hipStream_t stre
     return SMIL_OK;
 }
 
+// What smil_lbs_backward_ndc passes instead of (B,V,3) / (B,J,3) upstream gradients.
+struct NdcUpstream {
+    const SmilCameras *cam;
+    const float *d_ndc, *d_ndc_scale, *d_yx;
+    float *d_joints, *d_fov_img;
+};
+
+static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views) {
+    return ((size_t)6 * m->V + 4 + 18 * m->J + 17 * views + (NDC_BWD_THREADS / WAVE) * 12) * sizeof(float);
+}
+
+extern "C" int smil_lbs_backward_ndc_supported(const SmilModel *m, int32_t nB_used, int32_t views) {
+    return m && !m->posedirs && nB_used >= 0 && nB_used <= NDC_BWD_MAX_BETAS && views >= 1 && views <= NDC_BWD_MAX_VIEWS &&
+           ndc_bwd_lds_bytes(m, views) <= 80 * 1024;  // (two workgroups per CU)
+}
+
+static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv, const SmilLbsGrads *g,
+                             const NdcUpstream *up, hipStream_t stream);
+
 extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv,
                                  const SmilLbsGrads *g, void *stream_) {
     SMIL_REQUIRE(m && in && sv && g, "smil_lbs_backward: null argument");
-    hipStream_t stream = (hipStream_t)stream_;
+    SMIL_REQUIRE(g->d_verts || g->d_joints, "smil_lbs_backward: no upstream gradient");
+    return lbs_backward_impl(m, in, sv, g, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int smil_lbs_backward_ndc(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv, const SmilLbsGrads *g,
+                                     const SmilCameras *cam, const float *d_ndc, const float *d_ndc_scale, const float *d_yx_joints,
+                                     float *d_joints, float *d_fov_img, void *stream_) {
+    SMIL_REQUIRE(m && in && sv && g && cam, "smil_lbs_backward_ndc: null argument");
+    SMIL_REQUIRE(d_ndc || d_yx_joints, "smil_lbs_backward_ndc: no upstream gradient");
+    SMIL_REQUIRE(!g->d_verts && !g->d_joints && !g->d_del_v, "smil_lbs_backward_ndc: d_verts / d_joints / d_del_v belong to smil_lbs_backward");
+    SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N == in->B * cam->views, "smil_lbs_backward_ndc: %d images for %d frames x %d views",
+                 cam->N, in->B, cam->views);
+    SMIL_REQUIRE(smil_lbs_backward_ndc_supported(m, g->d_beta ? in->nB_used : 0, cam->views),
+                 "smil_lbs_backward_ndc: not available for this model / call (pose blend shapes, more than %d shape coefficients or %d views, "
+                 "or a mesh beyond 80 KB of LDS): use smil_project_backward + smil_lbs_backward", NDC_BWD_MAX_BETAS, NDC_BWD_MAX_VIEWS);
+    SMIL_REQUIRE(sv->verts && sv->joints && d_joints, "smil_lbs_backward_ndc: saved verts / joints and the d_joints buffer are required");
+    const NdcUpstream up = {cam, d_ndc, d_ndc_scale, d_yx_joints, d_joints, d_fov_img};
+    return lbs_backward_impl(m, in, sv, g, &up, (hipStream_t)stream_);
+}
+
+static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv, const SmilLbsGrads *g,
+                             const NdcUpstream *up, hipStream_t stream) {
     const int B = in->B, V = m->V, J = m->J;
     SMIL_REQUIRE(B > 0, "smil_lbs_backward: B=%d", B);
-    SMIL_REQUIRE(g->d_verts || g->d_joints, "smil_lbs_backward: no upstream gradient");
     SMIL_REQUIRE(g->d_A && g->d_Jrest && g->d_Rs, "smil_lbs_backward: scratch buffers missing");
     SMIL_REQUIRE(sv->v_shaped && sv->J_rest && sv->G && sv->A && sv->Rs, "smil_lbs_backward: saved forward tensors missing");
     const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
@@ -770,10 +1144,47 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
     // one block per frame: many frames -> smaller blocks (more of them resident, phases decoupled); a handful of frames -> the
     // widest block (the launch is one block's latency)
     const int few_frames = B < 64;
+    const int nBu_all = g->d_beta ? in->nB_used : 0;
+    float *dbeta_frame_all = nullptr, *dbeta_shared_all = nullptr;
+    if (g->d_beta && nBu_all > 0) {
+        // shared betas: every frame adds its term to the one (nB,) gradient (float atomics, like the rasteriser's vertex
+        // gradients); per-frame betas: one row per frame
+        if (in->shared_beta) {
+            dbeta_shared_all = g->d_beta;
+            if (!g->accumulate_shared_beta) SMIL_HIP(hipMemsetAsync(g->d_beta, 0, (size_t)nBu_all * sizeof(float), stream));
+        } else {
+            dbeta_frame_all = g->d_beta;
+        }
+    }
+    const float *d_joints_up = up ? up->d_joints : g->d_joints;
+    if (up) {
+        LbsBwdNdcArgs a;
+        a.cam = *up->cam;
+        a.verts = sv->verts; a.joints = sv->joints; a.A = sv->A; a.v_skin = v_skin;
+        a.d_ndc = up->d_ndc; a.d_ndc_scale = up->d_ndc_scale; a.d_yx = up->d_yx;
+        a.skin_idx = m->skin_idx; a.skin_w = m->skin_w;
+        a.bone_ptr = m->bone_ptr; a.bone_vid = m->bone_vid; a.bone_order = m->bone_order; a.bone_w = m->bone_w;
+        a.colptr = m->jreg_colptr; a.row = m->jreg_row; a.cval = m->jreg_cval; a.sd = m->shapedirs; a.vfirst = m->jreg_vfirst;
+        a.d_A = g->d_A; a.d_joints = up->d_joints; a.d_beta_frame = dbeta_frame_all; a.d_beta_shared = dbeta_shared_all;
+        a.d_trans = g->d_trans; a.d_fov_img = up->d_fov_img;
+        a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress;
+        a.trans_after = in->trans_after_joints ? 1 : 0;
+        const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views);
+        int dev = 0, cus = 0;
+        SMIL_HIP(hipGetDevice(&dev));
+        SMIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+        const int grid = std::min(B, std::max(1, cus) * per_cu);
+        if (nBu_all <= 3) hipLaunchKernelGGL(k_lbs_bwd_ndc<3>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
+        else if (nBu_all <= 6) hipLaunchKernelGGL(k_lbs_bwd_ndc<6>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL(k_lbs_bwd_ndc<NDC_BWD_MAX_BETAS>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
+        SMIL_LAUNCH_CHECK();
+    } else {
     hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(few_frames ? 1024 : SKIN_BWD_THREADS), (size_t)J * 3 * sizeof(float), stream, g->d_verts,
                        g->d_joints, v_skin, m->bone_ptr, m->bone_vid, m->bone_w, m->jreg_colptr, m->jreg_row,
                        m->jreg_cval, g->d_A, V, J, nS_skin, regress);
     SMIL_LAUNCH_CHECK();
+    }
     const float *d_posefeat = nullptr;
     if (m->posedirs && ((g->d_theta && !in->Rs_in) || (g->d_Rs_in && in->Rs_in))) {
         // gradient through v_posed -> vec(Rs[1:] - I): d_vposed, then the transposed product with posedirs;
@@ -800,7 +1211,11 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         ChainBwdArgs a;
         a.theta = in->Rs_in ? nullptr : in->theta; a.theta_mask = in->theta_mask; a.Rs = sv->Rs;
         a.logscale = in->logscale; a.btrans = in->btrans; a.J_rest = sv->J_rest; a.G = sv->G; a.d_A = g->d_A;
-        a.d_newJ = m->static_joints ? g->d_joints : nullptr;
+        a.d_newJ = m->static_joints ? d_joints_up : nullptr;
+        // (the fused vertex pass leaves the shape gradient through the rest joints to this kernel)
+        const bool js = up && !m->static_joints && nBu_all > 0;
+        a.jreg_shape = js ? m->jreg_shape : nullptr;
+        a.d_beta_frame = js ? dbeta_frame_all : nullptr; a.d_beta_shared = js ? dbeta_shared_all : nullptr; a.nB_used = nBu_all;
         a.d_posefeat = d_posefeat;
         a.parents = m->parents; a.depth = m->depth;
         a.d_Rs_out = in->Rs_in ? g->d_Rs_in : nullptr;
@@ -820,19 +1235,9 @@ extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, co
         int rc = smil_reduce_rows(dbt_frame, g->d_btrans, B, J * 3, stream);
         if (rc) return rc;
     }
-    if (g->d_beta || g->d_trans || g->d_del_v) {
-        const int nBu = g->d_beta ? in->nB_used : 0;
-        // shared betas: every frame's block adds its term to the one (nB,) gradient (float atomics, like the rasteriser's
-        // vertex gradients); per-frame betas: one row per frame
-        float *dbeta_frame = nullptr, *dbeta_shared = nullptr;
-        if (g->d_beta && nBu > 0) {
-            if (in->shared_beta) {
-                dbeta_shared = g->d_beta;
-                if (!g->accumulate_shared_beta) SMIL_HIP(hipMemsetAsync(g->d_beta, 0, (size_t)nBu * sizeof(float), stream));
-            } else {
-                dbeta_frame = g->d_beta;
-            }
-        }
+    if (!up && (g->d_beta || g->d_trans || g->d_del_v)) {
+        const int nBu = nBu_all;
+        float *dbeta_frame = dbeta_frame_all, *dbeta_shared = dbeta_shared_all;
         const int shape_threads = few_frames ? 1024 : SHAPE_BWD_THREADS;
         const size_t lds = ((size_t)J * 18 + (shape_threads / WAVE) * SHAPE_TERMS) * sizeof(float);
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(shape_threads), lds, stream, g->d_verts, g->d_joints,

@@ -110,6 +110,26 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
             }
     }
 
+    // J_regressor @ shapedirs[k] (nB,J,3) and the bones by falling list length
+    std::vector<float> jreg_shape((size_t)std::max(d->nB, 1) * J * 3, 0.f);
+    for (int k = 0; k < d->nB; ++k)
+        for (int j = 0; j < J; ++j)
+            for (int e = d->jreg_rowptr[j]; e < d->jreg_rowptr[j + 1]; ++e)
+                for (int c = 0; c < 3; ++c)
+                    jreg_shape[((size_t)k * J + j) * 3 + c] += d->jreg_val[e] * d->shapedirs[(size_t)k * 3 * V + 3 * d->jreg_col[e] + c];
+    std::vector<int2> vfirst(V);
+    for (int v = 0; v < V; ++v) {
+        const int n_ent = colptr[v + 1] - colptr[v];
+        SMIL_REQUIRE(n_ent < 32768, "smil_model_create: vertex %d has %d regressor entries", v, n_ent);
+        float w0 = n_ent ? cval[colptr[v]] : 0.f;
+        int wb;
+        std::memcpy(&wb, &w0, 4);
+        vfirst[v] = make_int2((n_ent ? crow[colptr[v]] : 0) | (n_ent << 16), wb);
+    }
+    std::vector<int> bone_order(J);
+    std::iota(bone_order.begin(), bone_order.end(), 0);
+    std::stable_sort(bone_order.begin(), bone_order.end(), [&](int a, int b) { return bone_cnt[a + 1] > bone_cnt[b + 1]; });
+
     SmilModel *m = new SmilModel();
     m->V = V; m->F = F; m->J = J; m->nB = d->nB;
     m->max_depth = max_depth;
@@ -135,6 +155,9 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
     UP(bone_ptr, bone_ptr.data(), J + 1);
     UP(bone_vid, bone_vid.data(), bone_nnz);
     UP(bone_w, bone_w.data(), bone_nnz);
+    UP(jreg_vfirst, vfirst.data(), V);
+    UP(jreg_shape, jreg_shape.data(), (size_t)std::max(d->nB, 1) * J * 3);
+    UP(bone_order, bone_order.data(), J);
     UP(J_static, d->static_joints ? d->J_static : (const float *)nullptr, 3 * J);
     if (d->posedirs) { UP(posedirs, d->posedirs, (size_t)9 * (J - 1) * 3 * V); }
 #undef UP

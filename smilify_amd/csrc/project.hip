@@ -8,31 +8,6 @@
 //   x_s = S/2 - (S/2) x_ndc ; y_s likewise ; the reference returns (y_s, x_s).
 #include "common.h"
 
-#define SMIL_ZNEAR 0.001f  // Renderer.DEFAULT_ZNEAR (p3d_renderer.py:24)
-
-struct CamParams {
-    float R[9];
-    float T[3];
-    float k00, k11, tanh_;  // tan(fov/2)
-};
-
-__device__ __forceinline__ CamParams load_camera(const SmilCameras &c, int n) {
-    CamParams p;
-    const float *R = c.R + (size_t)(n % c.nR) * 9;
-    const float *T = c.T + (size_t)(n % c.nT) * 3;
-    for (int i = 0; i < 9; ++i) p.R[i] = R[i];
-    for (int i = 0; i < 3; ++i) p.T[i] = T[i];
-    const float fov = c.fov[n % c.nFov];
-    const float asp = c.aspect ? c.aspect[n % c.nAspect] : 1.0f;
-    const float t = tanf((fov * 0.017453292519943295f) / 2.0f);
-    const float max_y = t * SMIL_ZNEAR;
-    const float max_x = max_y * asp;
-    p.k00 = 2.0f * SMIL_ZNEAR / (max_x - (-max_x));
-    p.k11 = 2.0f * SMIL_ZNEAR / (max_y - (-max_y));
-    p.tanh_ = t;
-    return p;
-}
-
 // One or two point sets (e.g. the vertices -> NDC for the rasteriser and the joints -> screen for the 2-D loss) per launch.
 struct ProjectSet {
     const float *pts;  // (frames,P,3)

@@ -186,12 +186,23 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     return out
 
 
+FUSED_LBS_BACKWARD = True  # the fit iteration takes smil_lbs_backward_ndc where the library supports the model (tests switch it off to compare)
+
+
+def lbs_backward_ndc_supported(model: DeviceModel, nB_used: int, views: int) -> bool:
+    """Whether ``lbs_backward(..., ndc_upstream=...)`` (one kernel from the image plane) handles this model and call."""
+    return bool(_lib.load().smil_lbs_backward_ndc_supported(model.handle, int(nB_used), int(views)))
+
+
 def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=True, need_theta=True,
                  need_logscale=True, need_btrans=True, need_trans=True, need_vshaped=False,
                  need_Rs=False, d_beta_accum: Optional[torch.Tensor] = None, out_logscale: Optional[torch.Tensor] = None,
-                 out_btrans: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
+                 out_btrans: Optional[torch.Tensor] = None, ndc_upstream: Optional[Dict] = None) -> Dict[str, Optional[torch.Tensor]]:
     """``d_beta_accum`` (shared betas only): the sum over frames is ADDED to this (nB,) tensor instead of a fresh one.
-    ``out_logscale`` / ``out_btrans`` (shared tables only): (J,3) buffers that receive those gradients (overwritten)."""
+    ``out_logscale`` / ``out_btrans`` (shared tables only): (J,3) buffers that receive those gradients (overwritten).
+    ``ndc_upstream`` = ``dict(cams=CameraSet, d_ndc=, d_ndc_scale=, d_yx=, d_fov_img=)`` instead of ``d_verts`` / ``d_joints``:
+    the gradients are taken on the image plane and projected back inside the skinning backward (``smil_lbs_backward_ndc``);
+    the result then carries ``d_joints`` (B,J,3)."""
     dev = model.device
     inp, fl = saved["_inputs"], saved["_flags"]
     B, J = fl["B"], model.J
@@ -236,6 +247,18 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
     for k, t in {**g, **scratch}.items():
         setattr(gs, k, None if t is None else t.data_ptr())
     gs.accumulate_shared_beta = int(accumulate_beta)
+    if ndc_upstream is not None:
+        if d_verts is not None or d_joints is not None or need_vshaped:
+            raise ValueError("ndc_upstream replaces d_verts / d_joints and has no del_v gradient")
+        up = ndc_upstream
+        cams = up["cams"]
+        g["d_joints"] = f(B, J, 3)
+        c = cams.struct(B * cams.views)
+        _lib.check(_lib.load().smil_lbs_backward_ndc(model.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(gs), ctypes.byref(c),
+                                                     _ptr(up.get("d_ndc")), _ptr(up.get("d_ndc_scale")), _ptr(up.get("d_yx")),
+                                                     _ptr(g["d_joints"]), _ptr(up.get("d_fov_img")), _stream()),
+                   "smil_lbs_backward_ndc")
+        return g
     _lib.check(_lib.load().smil_lbs_backward(model.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(gs), _stream()),
                "smil_lbs_backward")
     return g

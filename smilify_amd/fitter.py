@@ -345,7 +345,12 @@ class SMALFitter(nn.Module):
                 # (the vertex gradient stays as the tile kernel accumulated it: the projection backward decodes it while it reads)
                 loss_img, d_ndc, _, d_ndc_scale = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings,
                                                                              packed_out=True)
-            if both:
+            # image-plane gradients -> world space: inside the skinning backward (one kernel per frame, no (B,V,3) vertex
+            # gradient in memory) where the library offers it, else by the projection backward first
+            ndc_up = None
+            if engine.FUSED_LBS_BACKWARD and engine.lbs_backward_ndc_supported(dm, nB if self.betas.requires_grad else 0, views):
+                ndc_up = dict(cams=cams, d_ndc=d_ndc, d_ndc_scale=d_ndc_scale if d_ndc is not None else None, d_yx=d_yx, d_fov_img=d_fov_img)
+            elif both:
                 d_verts, d_joints = engine.project_backward_verts_and_joints(cams, lbs["verts"], d_ndc, lbs["joints"], d_yx, d_fov_img,
                                                                              d_ndc_scale=d_ndc_scale)
             elif w_j2d > 0:
@@ -359,7 +364,7 @@ class SMALFitter(nn.Module):
                                         need_logscale=self.log_beta_scales.requires_grad,
                                         need_btrans=self.betas_trans.requires_grad, need_trans=self.trans.requires_grad,
                                         d_beta_accum=d_betas, out_logscale=arena[o_ls:o_bt].view(J, 3) if n_ls else None,
-                                        out_btrans=arena[o_bt:n_shared].view(J, 3) if n_bt else None)
+                                        out_btrans=arena[o_bt:n_shared].view(J, 3) if n_bt else None, ndc_upstream=ndc_up)
         if g_lbs is not None and g_lbs["d_theta"] is not None:
             d_pose = g_lbs["d_theta"]
             d_trans = g_lbs["d_trans"] if g_lbs["d_trans"] is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)

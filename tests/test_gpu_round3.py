@@ -1,0 +1,130 @@
+"""GPU tests of round 3 (``pytest -m gpu``): the skinning backward that takes its upstream gradients on the image plane
+(``smil_lbs_backward_ndc``: projection backward + skinning backward + shape backward in one kernel per frame) against the
+two-call route it replaces, which the other test files pin to the oracle and to vectors of the real reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol, what):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b).max() / scale
+    assert err < rtol, (what, err)
+
+
+@pytest.mark.parametrize("key,views,shared_beta,trans_after", [
+    ("stick", 1, True, True),            # the fit iteration's own call
+    ("stick", 3, True, True),
+    ("stick", 2, False, False),          # SMAL.__call__ semantics: joints regressed from the translated vertices, per-frame betas
+    ("synthetic", 4, True, True),
+    ("synthetic_static", 2, True, True),  # static joints: the joint gradient enters the chain, not the regressor
+    ("synthetic_static", 1, False, False),
+])
+def test_backward_from_the_image_plane_equals_projection_backward_then_skinning_backward(key, views, shared_beta, trans_after, tables):
+    from smilify_amd import cameras as cam_mod
+    from smilify_amd import engine as eng
+
+    t = tables(key)
+    dm = eng.DeviceModel(t, DEV)
+    B, S = 37, 64
+    J, V, nB = dm.J, dm.V, dm.nB
+    g = torch.Generator().manual_seed(5)
+    beta = (0.4 * torch.randn(nB, generator=g) if shared_beta else 0.4 * torch.randn(B, nB, generator=g)).to(DEV)
+    theta = (0.25 * torch.randn(B, J, 3, generator=g)).to(DEV)
+    trans = (0.1 * torch.randn(B, 3, generator=g)).to(DEV)
+    ls = (0.05 * torch.randn(J, 3, generator=g)).to(DEV)
+    bt = (0.02 * torch.randn(J, 3, generator=g)).to(DEV)
+    lbs = eng.lbs_forward(dm, beta, theta, trans=trans, logscale=ls, btrans=bt, shared_beta=shared_beta, logscale_shared=True,
+                          btrans_shared=True, trans_after_joints=trans_after)
+    R, T = cam_mod.look_at_view_transform(3.0, 10.0, np.linspace(0, 300, views), device=DEV)
+    fov = torch.full((views,), 55.0, device=DEV)
+    cams = eng.CameraSet(R.contiguous(), T.contiguous(), fov, None, views, S)
+    N = B * views
+    d_ndc = (1e-3 * torch.randn(N, V, 2, generator=g)).to(DEV)
+    d_yx = (1e-2 * torch.randn(N, J, 2, generator=g)).to(DEV)
+    assert eng.lbs_backward_ndc_supported(dm, nB, views)
+
+    def route(fused, with_ndc=True, with_yx=True):
+        dn = d_ndc if with_ndc else None
+        dy = d_yx if with_yx else None
+        fov_img = torch.zeros(N, device=DEV)
+        if fused:
+            out = eng.lbs_backward(dm, lbs, None, None, ndc_upstream=dict(cams=cams, d_ndc=dn, d_yx=dy, d_fov_img=fov_img))
+        else:
+            if with_ndc and with_yx:
+                dv, dj = eng.project_backward_verts_and_joints(cams, lbs["verts"], dn, lbs["joints"], dy, fov_img)
+            elif with_ndc:
+                (dv, _), dj = eng.project_backward(cams, lbs["verts"], d_ndc=dn, d_fov_img=fov_img), None
+            else:
+                dv, (dj, _) = None, eng.project_backward(cams, lbs["joints"], d_yx=dy, d_fov_img=fov_img)
+            out = eng.lbs_backward(dm, lbs, dv, dj)
+            out["d_joints"] = dj
+        out["fov_img"] = fov_img
+        return out
+
+    for with_ndc, with_yx in ((True, True), (True, False), (False, True)):
+        a, b = route(True, with_ndc, with_yx), route(False, with_ndc, with_yx)
+        for k in ("d_beta", "d_theta", "d_trans", "d_logscale", "d_btrans", "fov_img"):
+            assert a[k] is not None and b[k] is not None, k
+            _close(a[k], b[k], 2e-5, (k, with_ndc, with_yx))
+        if with_yx:
+            _close(a["d_joints"], b["d_joints"], 1e-6, "d_joints")
+
+
+def test_backward_from_the_image_plane_decodes_packed_rows_and_declines_what_it_cannot_hold(tables):
+    """The vertex gradient arrives as the fused rasteriser leaves it (packed 64-bit fixed point with per-image factors); a
+    mesh whose per-frame gradient does not fit the workgroup's LDS is declined, and the fit iteration then takes the two-call route."""
+    from smilify_amd import engine as eng
+    from smilify_amd import synthetic
+
+    t = tables("stick")
+    N, S = 80, 96
+    f = synthetic.make_problem(t, N, 1, S, DEV, seed=4, window=N)
+    f._refresh_targets()
+    dm = f.device_model
+    lbs = eng.lbs_forward(dm, f.betas.detach(), f._pose, trans=f.trans.detach().contiguous(), shared_beta=True, trans_after_joints=True)
+    cam = f.renderer.cameras
+    cams = eng.CameraSet(cam.R.contiguous(), cam.T.contiguous(), f.fov.detach(), None, 1, S)
+    ndc, _ = eng.project(cams, lbs["verts"], want_yx=False)
+    scale = torch.full((N,), 3.0 / (S * S), device=DEV)
+    scale[7] = 0.0
+    _, dn_p, _, sc_p = eng.silhouette_l1_fused(dm, ndc, S, f._sil_dev, f._sil_sum, scale, packed_out=True)
+    assert float(sc_p.max()) > 0.0
+    fov_a, fov_b = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    a = eng.lbs_backward(dm, lbs, None, None, ndc_upstream=dict(cams=cams, d_ndc=dn_p, d_ndc_scale=sc_p, d_fov_img=fov_a))
+    dv, _ = eng.project_backward(cams, lbs["verts"], d_ndc=dn_p, d_fov_img=fov_b, d_ndc_scale=sc_p)
+    b = eng.lbs_backward(dm, lbs, dv, None)
+    for k in ("d_beta", "d_theta", "d_trans"):
+        _close(a[k], b[k], 2e-5, k)
+    _close(fov_a, fov_b, 2e-5, "fov")
+    mouse = eng.DeviceModel(tables("mouse"), DEV)
+    assert not eng.lbs_backward_ndc_supported(mouse, mouse.nB, 1)  # 11 263 vertices x 12 bytes
+
+
+@pytest.mark.parametrize("views", [1, 3])
+def test_fit_iteration_is_the_same_through_either_backward(views, tables):
+    from smilify_amd import engine as eng
+    from smilify_amd import synthetic
+
+    t = tables("stick")
+    outs = []
+    for fused in (True, False):
+        eng.FUSED_LBS_BACKWARD = fused
+        try:
+            f = synthetic.make_problem(t, 24, views, 64, DEV, seed=9, window=8)
+            objs, grads = f._loss_and_grads(None, synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=8)
+        finally:
+            eng.FUSED_LBS_BACKWARD = True
+        outs.append((objs, grads))
+    (oa, ga), (ob, gb) = outs
+    _close(oa, ob, 1e-6, "objs")
+    assert set(ga) == set(gb)
+    for k in ga:
+        if ga[k] is None:
+            assert gb[k] is None
+            continue
+        _close(ga[k], gb[k], 3e-5, k)

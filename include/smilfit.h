@@ -168,6 +168,14 @@ int smil_project_backward(const SmilCameras *cam, const float *pts, int32_t P, c
                           void *stream);
 int smil_fov_reduce(const SmilCameras *cam, const float *d_fov_img, float *d_fov, void *stream);
 
+/* smil_lbs_forward followed by the projection of its vertices and joints through `cam` (N = in->B * cam->views images):
+ * ndc (N,V,3) as smil_project(verts) and yx (N,J,2) as smil_project(joints); either may be NULL.  Replaces SMAL.__call__
+ * + Renderer's two projections of one fit iteration (fitter.py:270-290, p3d_renderer.py:137-146).  Where the frame's vertices
+ * fit a workgroup's LDS (3 V floats <= 64 KB) skinning, joint regression and both projections are ONE kernel per frame and
+ * `verts` is written once and not read back; otherwise the separate kernels run.  Outputs are those of the separate calls. */
+int smil_lbs_forward_project(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, const SmilCameras *cam,
+                             float *ndc, float *yx, void *stream);
+
 /* smil_lbs_backward taking its upstream gradients on the IMAGE PLANE, as the fit iteration has them: d_ndc (N,V,2) on the
  * projected vertices (rows may be the packed fixed point smil_silhouette_l1_fused leaves, with d_ndc_scale (N,) as in
  * smil_project_backward) and d_yx_joints (N,J,2) on the projected joints (y, x) in pixels; either may be NULL.  One kernel per

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SMILFIT_LIB") or os.path.join(_HERE, "lib", "libsmilf
 
 EXPORTS = [
     "smil_model_create", "smil_model_destroy", "smil_model_dims", "smil_last_error", "smil_version",
-    "smil_lbs_forward", "smil_lbs_backward", "smil_lbs_backward_ndc", "smil_lbs_backward_ndc_supported", "smil_project", "smil_project2", "smil_project_backward", "smil_project_backward2",
+    "smil_lbs_forward", "smil_lbs_forward_project", "smil_lbs_backward", "smil_lbs_backward_ndc", "smil_lbs_backward_ndc_supported", "smil_project", "smil_project2", "smil_project_backward", "smil_project_backward2",
     "smil_fov_reduce", "smil_fit_epilogue",
     "smil_raster_workspace_bytes", "smil_raster_stats", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
@@ -101,6 +101,7 @@ def load():
     lib.smil_model_destroy.restype = None
     lib.smil_model_dims.argtypes = [c_void_p, POINTER(c_int32)]
     lib.smil_lbs_forward.argtypes = [c_void_p, POINTER(LbsInputs), POINTER(LbsOutputs), c_void_p]
+    lib.smil_lbs_forward_project.argtypes = [c_void_p, POINTER(LbsInputs), POINTER(LbsOutputs), POINTER(Cameras), c_void_p, c_void_p, c_void_p]
     lib.smil_lbs_backward.argtypes = [c_void_p, POINTER(LbsInputs), POINTER(LbsOutputs), POINTER(LbsGrads), c_void_p]
     lib.smil_lbs_backward_ndc.argtypes = [c_void_p, POINTER(LbsInputs), POINTER(LbsOutputs), POINTER(LbsGrads), POINTER(Cameras),
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

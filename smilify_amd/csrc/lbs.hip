@@ -354,9 +354,190 @@ __global__ void __launch_bounds__(1024) k_regress_joints(const int *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// skinning + joint regression + projection of one frame in one workgroup: the posed vertices are kept in LDS for the joint
+// regressor (a gather) and projected through the frame's cameras as they are produced, so `verts` is written once and never
+// read back by the forward pass (k_skin_fwd + k_regress_joints + k_project read it twice).  Same arithmetic, in the same
+// order, as those three kernels: the outputs are bit-identical.
+// ---------------------------------------------------------------------------------------------
+#define FWD_FUSED_THREADS 512
+#define FWD_FUSED_MAX_VIEWS 32
+#ifndef FWD_UNR
+#define FWD_UNR 3
+#endif
+#ifndef FWD_MIN_WAVES
+#define FWD_MIN_WAVES 4
+#endif
+
+struct SkinProjectArgs {
+    SmilCameras cam;
+    const float *A, *v_skin, *trans, *trans_after;   // (B,J,12), (nS,V,3), (B,3) or NULL, = trans when it is added after the regression
+    const uint32_t *skin_idx;
+    const float4 *skin_w;
+    const int *rowptr, *col;
+    const float *val;
+    float *verts, *joints, *ndc, *yx;   // (B,V,3), (B,J,3), (N,V,3) or NULL, (N,J,2) or NULL
+    int B, V, J, nS, regress;           // regress 0: `joints` already holds the frame's joints (static joints, written by k_pose_fwd)
+    int nnz_lds;                        // regressor entries staged in LDS (all of them, or 0: read from memory)
+};
+
+__global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_project_fwd(SkinProjectArgs a) {
+    extern __shared__ float smem[];
+    const int V = a.V, J = a.J, views = a.cam.views;
+    constexpr int NT = FWD_FUSED_THREADS, NW = NT / WAVE;
+    float *vL = smem;                              // (V,3) posed vertices of the frame
+    float *sA = smem + ((3 * V + 3) & ~3);         // (J,12)
+    float *sCam = sA + 12 * J;                     // (views,16)
+    // the joint regressor (CSR) is staged once per workgroup when it fits: a joint is then LDS reads only (from memory every joint
+    // is a chain of two round trips, seven joints deep per wave - measured: 126 -> see profiles/r3_small_kernels.md)
+    int *sRow = reinterpret_cast<int *>(sCam + 16 * views);  // (J+1)
+    int *sCol = sRow + J + 1;                                 // (nnz)
+    float *sVal = reinterpret_cast<float *>(sCol + a.nnz_lds);
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const float hS = 0.5f * (float)a.cam.S;
+    const bool reg_lds = a.regress && a.nnz_lds > 0;
+    if (reg_lds) {
+        for (int i = tid; i <= J; i += NT) sRow[i] = a.rowptr[i];
+        for (int i = tid; i < a.nnz_lds; i += NT) { sCol[i] = a.col[i]; sVal[i] = a.val[i]; }
+    }
+    const int *const rowp = reg_lds ? sRow : a.rowptr, *const colp = reg_lds ? sCol : a.col;
+    const float *const valp = reg_lds ? sVal : a.val;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        for (int i = tid; i < 12 * J; i += NT) sA[i] = a.A[(size_t)b * J * 12 + i];
+        if (tid < views) {
+            const CamParams cp = load_camera(a.cam, b * views + tid);
+            float *o = sCam + 16 * tid;
+            for (int i = 0; i < 9; ++i) o[i] = cp.R[i];
+            for (int i = 0; i < 3; ++i) o[9 + i] = cp.T[i];
+            o[12] = cp.k00; o[13] = cp.k11;
+        }
+        __syncthreads();
+        const float *vpb = a.v_skin + (size_t)(a.nS == 1 ? 0 : b) * V * 3;
+        const float tx = a.trans ? a.trans[3 * b] : 0.f, ty = a.trans ? a.trans[3 * b + 1] : 0.f, tz = a.trans ? a.trans[3 * b + 2] : 0.f;
+        for (int v0 = tid; v0 < V; v0 += FWD_UNR * NT) {
+            uint32_t ids[FWD_UNR];
+            float4 w4[FWD_UNR];
+            float P[FWD_UNR][3];
+#pragma unroll
+            for (int u = 0; u < FWD_UNR; ++u) {
+                const int v = min(v0 + u * NT, V - 1);
+                ids[u] = a.skin_idx[v];
+                w4[u] = a.skin_w[v];
+                P[u][0] = vpb[3 * v]; P[u][1] = vpb[3 * v + 1]; P[u][2] = vpb[3 * v + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < FWD_UNR; ++u) {
+                const int v = v0 + u * NT;
+                if (v >= V) continue;
+                const float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+                float T[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < SMIL_MAX_BONES; ++k) {
+                    if (w[k] == 0.f) continue;
+                    const float4 *Ak = reinterpret_cast<const float4 *>(sA) + 3 * ((ids[u] >> (8 * k)) & 0xFF);  // (three 16-byte LDS reads per bone)
+#pragma unroll
+                    for (int m_ = 0; m_ < 3; ++m_) {
+                        const float4 r = Ak[m_];
+                        T[4 * m_] += w[k] * r.x; T[4 * m_ + 1] += w[k] * r.y; T[4 * m_ + 2] += w[k] * r.z; T[4 * m_ + 3] += w[k] * r.w;
+                    }
+                }
+                const float x = P[u][0], y = P[u][1], z = P[u][2];
+                float ox = T[0] * x + T[1] * y + T[2] * z + T[3];
+                float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
+                float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
+                if (a.trans) { ox += tx; oy += ty; oz += tz; }
+                vL[3 * v] = ox; vL[3 * v + 1] = oy; vL[3 * v + 2] = oz;
+#ifndef FWD_ABL_NO_VERTS
+                float *o = a.verts + ((size_t)b * V + v) * 3;
+                o[0] = ox; o[1] = oy; o[2] = oz;
+#endif
+#ifdef FWD_ABL_NO_NDC
+                if (a.ndc && ox == 123.456f)
+#else
+                if (a.ndc)
+#endif
+                    for (int view = 0; view < views; ++view) {
+                        const float *cp = sCam + 16 * view;
+                        const float vx = ox * cp[0] + oy * cp[3] + oz * cp[6] + cp[9];
+                        const float vy = ox * cp[1] + oy * cp[4] + oz * cp[7] + cp[10];
+                        const float vz = ox * cp[2] + oy * cp[5] + oz * cp[8] + cp[11];
+                        float *q = a.ndc + ((size_t)(b * views + view) * V + v) * 3;
+                        q[0] = vx * cp[12] / vz; q[1] = vy * cp[13] / vz; q[2] = vz;
+                    }
+            }
+        }
+        __syncthreads();  // the frame's vertices are in LDS
+        // joints: one wave per joint, lanes over the non-zeros of its regressor row (k_regress_joints), then through the cameras
+        const float t0 = a.trans_after ? a.trans_after[3 * b] : 0.f, t1 = a.trans_after ? a.trans_after[3 * b + 1] : 0.f,
+                    t2 = a.trans_after ? a.trans_after[3 * b + 2] : 0.f;
+        // joints: sixteen lanes per joint (a regressor row holds ~30 non-zeros), four joints per wave at a time; the sum inside
+        // the 16-lane row is four DPP adds.  Then the joint goes through the cameras (lane = view, sixteen at a time).
+#ifdef FWD_ABL_NO_JOINTS
+        for (int j0_ = 0; j0_ < 0; j0_ += 4 * NW) {
+#else
+        for (int j0_ = 0; j0_ < J; j0_ += 4 * NW) {
+#endif
+            const int j = j0_ + 4 * wid + (lane >> 4), sub = lane & 15;
+            const bool live = j < J;
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            if (a.regress) {
+                if (live)
+                    for (int e = rowp[j] + sub; e < rowp[j + 1]; e += 16) {
+                        const float w = valp[e];
+                        const float *p = vL + 3 * colp[e];
+                        q0 += (p[0] - t0) * w; q1 += (p[1] - t1) * w; q2 += (p[2] - t2) * w;
+                    }
+                q0 = row_sum16(q0) + t0; q1 = row_sum16(q1) + t1; q2 = row_sum16(q2) + t2;
+                if (live && sub == 0) { float *o = a.joints + ((size_t)b * J + j) * 3; o[0] = q0; o[1] = q1; o[2] = q2; }
+            } else if (live) {
+                const float *o = a.joints + ((size_t)b * J + j) * 3;
+                q0 = o[0]; q1 = o[1]; q2 = o[2];
+            }
+            if (a.yx && live)
+                for (int view = sub; view < views; view += 16) {
+                    const float *cp = sCam + 16 * view;
+                    const float vx = q0 * cp[0] + q1 * cp[3] + q2 * cp[6] + cp[9];
+                    const float vy = q0 * cp[1] + q1 * cp[4] + q2 * cp[7] + cp[10];
+                    const float vz = q0 * cp[2] + q1 * cp[5] + q2 * cp[8] + cp[11];
+                    const float xn = vx * cp[12] / vz, yn = vy * cp[13] / vz;
+                    float *q = a.yx + ((size_t)(b * views + view) * J + j) * 2;
+                    q[0] = hS - hS * yn; q[1] = hS - hS * xn;
+                }
+        }
+        __syncthreads();  // the next frame overwrites vL, sA, sCam
+    }
+}
+
+#define FWD_REG_LDS_MAX 4096  // regressor non-zeros staged in LDS (32 KB)
+static int fwd_fused_nnz_lds(const SmilModel *m) { return (!m->static_joints && m->jreg_nnz <= FWD_REG_LDS_MAX) ? m->jreg_nnz : 0; }
+static size_t fwd_fused_lds_bytes(const SmilModel *m, int views) {
+    return ((size_t)3 * m->V + 4 + 12 * m->J + 16 * views + m->J + 1 + 2 * fwd_fused_nnz_lds(m)) * sizeof(float);
+}
+
+static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, const SmilCameras *cam, float *ndc,
+                            float *yx, hipStream_t stream);
+
 extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, void *stream_) {
+    return lbs_forward_impl(m, in, out, nullptr, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int smil_project2(const SmilCameras *cam, const float *pts_a, int32_t Pa, float *ndc_a, float *yx_a, const float *pts_b,
+                             int32_t Pb, float *ndc_b, float *yx_b, void *stream);
+
+extern "C" int smil_lbs_forward_project(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, const SmilCameras *cam,
+                                        float *ndc, float *yx, void *stream_) {
+    SMIL_REQUIRE(cam && (ndc || yx), "smil_lbs_forward_project: cameras and at least one of ndc / yx are required");
+    SMIL_REQUIRE(in && cam->N > 0 && cam->views > 0 && cam->N == in->B * cam->views, "smil_lbs_forward_project: %d images for %d frames x %d views",
+                 cam->N, in ? in->B : 0, cam->views);
+    return lbs_forward_impl(m, in, out, cam, ndc, yx, (hipStream_t)stream_);
+}
+
+static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, const SmilCameras *cam, float *ndc,
+                            float *yx, hipStream_t stream) {
     SMIL_REQUIRE(m && in && out, "smil_lbs_forward: null argument");
-    hipStream_t stream = (hipStream_t)stream_;
     const int B = in->B, V = m->V, J = m->J;
     SMIL_REQUIRE(B > 0, "smil_lbs_forward: B=%d", B);
     SMIL_REQUIRE(in->nB_used >= 0 && in->nB_used <= m->nB, "smil_lbs_forward: nB_used=%d but the model has %d betas",
@@ -404,6 +585,26 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
         v_skin = out->v_posed;
         nS_skin = B;
     }
+    const float *trans_after = (in->trans_after_joints && in->trans) ? in->trans : nullptr;
+    if (cam && cam->views <= FWD_FUSED_MAX_VIEWS && fwd_fused_lds_bytes(m, cam->views) <= 80 * 1024) {
+        // skinning, joint regression and both projections in one kernel per frame (the frame's vertices stay in LDS)
+        SkinProjectArgs a;
+        a.cam = *cam;
+        a.A = out->A; a.v_skin = v_skin; a.trans = in->trans; a.trans_after = trans_after;
+        a.skin_idx = m->skin_idx; a.skin_w = m->skin_w;
+        a.rowptr = m->jreg_rowptr; a.col = m->jreg_col; a.val = m->jreg_val;
+        a.verts = out->verts; a.joints = out->joints; a.ndc = ndc; a.yx = yx;
+        a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.regress = m->static_joints ? 0 : 1;
+        a.nnz_lds = fwd_fused_nnz_lds(m);
+        const size_t lds = fwd_fused_lds_bytes(m, cam->views);
+        int dev = 0, cus = 0;
+        SMIL_HIP(hipGetDevice(&dev));
+        SMIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int per_cu = std::max(1, std::min(FWD_MIN_WAVES / 2, (int)((160 * 1024) / lds)));
+        hipLaunchKernelGGL(k_skin_project_fwd, dim3(std::min(B, std::max(1, cus) * per_cu)), dim3(FWD_FUSED_THREADS), lds, stream, a);
+        SMIL_LAUNCH_CHECK();
+        return SMIL_OK;
+    }
     {
         dim3 grid(B, ceil_div(V, 256));
         hipLaunchKernelGGL(k_skin_fwd, grid, dim3(256), (size_t)J * 12 * sizeof(float), stream, out->A, v_skin,
@@ -412,8 +613,13 @@ extern "C" int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, con
     }
     if (!m->static_joints) {
         hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(1024), 0, stream, m->jreg_rowptr, m->jreg_col, m->jreg_val,
-                           out->verts, (in->trans_after_joints && in->trans) ? in->trans : nullptr, out->joints, V, J);
+                           out->verts, trans_after, out->joints, V, J);
         SMIL_LAUNCH_CHECK();
+    }
+    if (cam) {  // (a mesh or a camera rig beyond the fused kernel's LDS: the projection as its own launch)
+        if (ndc && yx) return smil_project2(cam, out->verts, V, ndc, nullptr, out->joints, J, nullptr, yx, stream);
+        if (ndc) return smil_project(cam, out->verts, V, ndc, nullptr, stream);
+        return smil_project(cam, out->joints, J, nullptr, yx, stream);
     }
     return SMIL_OK;
 }

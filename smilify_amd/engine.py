@@ -154,8 +154,12 @@ def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL) -> _lib.Ra
 # ----------------------------------------------------------------------------------------------
 def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btrans=None, del_v=None,
                 v_template=None, Rs_in=None, shared_beta=False, logscale_shared=False, btrans_shared=False,
-                propagate_scaling=False, allow_limb_scaling=True, trans_after_joints=False, theta_mask=None) -> Dict[str, torch.Tensor]:
-    """``theta_mask`` (J,3): the kernels use ``theta * mask`` without a masked copy being made (SMALFitter's rotation masks)."""
+                propagate_scaling=False, allow_limb_scaling=True, trans_after_joints=False, theta_mask=None,
+                project: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
+    """``theta_mask`` (J,3): the kernels use ``theta * mask`` without a masked copy being made (SMALFitter's rotation masks).
+    ``project`` = ``dict(cams=CameraSet, ndc=bool, yx=bool)``: the vertices / joints are also projected through the cameras
+    (``smil_lbs_forward_project``: one kernel per frame with skinning and joint regression); the result carries ``ndc`` (N,V,3)
+    and / or ``yx`` (N,J,2)."""
     dev = model.device
     B = int((theta if theta is not None else Rs_in).shape[0])
     J, V = model.J, model.V
@@ -178,7 +182,21 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     o = _lib.LbsOutputs()
     for k, t in out.items():
         setattr(o, k, t.data_ptr())
-    _lib.check(_lib.load().smil_lbs_forward(model.handle, ctypes.byref(i), ctypes.byref(o), _stream()), "smil_lbs_forward")
+    ndc = yx = None
+    if project is not None:
+        cams = project["cams"]
+        N = B * cams.views
+        ndc = f(N, V, 3) if project.get("ndc", True) else None
+        yx = f(N, J, 2) if project.get("yx", True) else None
+        c = cams.struct(N)
+        _lib.check(_lib.load().smil_lbs_forward_project(model.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(c), _ptr(ndc), _ptr(yx), _stream()),
+                   "smil_lbs_forward_project")
+    else:
+        _lib.check(_lib.load().smil_lbs_forward(model.handle, ctypes.byref(i), ctypes.byref(o), _stream()), "smil_lbs_forward")
+    if ndc is not None:
+        out["ndc"] = ndc
+    if yx is not None:
+        out["yx"] = yx
     out["_inputs"] = inp
     out["_flags"] = dict(B=B, shared_beta=shared_beta, nB_used=nB_used, logscale_shared=logscale_shared,
                          btrans_shared=btrans_shared, propagate_scaling=propagate_scaling,
@@ -186,6 +204,7 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     return out
 
 
+FUSED_LBS_FORWARD = True   # the fit iteration projects inside the skinning kernel (smil_lbs_forward_project)
 FUSED_LBS_BACKWARD = True  # the fit iteration takes smil_lbs_backward_ndc where the library supports the model (tests switch it off to compare)
 
 

@@ -322,10 +322,13 @@ class SMALFitter(nn.Module):
             # the rotation masks are applied inside the pose kernels (theta_mask): no masked copy of the pose
             lbs = engine.lbs_forward(dm, betas, pose, trans=trans, logscale=ls, btrans=bt, shared_beta=True,
                                      logscale_shared=ls_shared, btrans_shared=bt_shared, propagate_scaling=self.propagate_scaling,
-                                     allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True, theta_mask=mask)
+                                     allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True, theta_mask=mask,
+                                     project=dict(cams=cams, ndc=w_reproj > 0, yx=w_j2d > 0) if engine.FUSED_LBS_FORWARD else None)
             both = w_j2d > 0 and w_reproj > 0
             ndc = yx = d_yx = d_ndc = d_verts = d_joints = None
-            if both:  # vertices -> NDC and joints -> pixels in one launch
+            if engine.FUSED_LBS_FORWARD:  # projected by the skinning kernel (vertices -> NDC, joints -> pixels)
+                ndc, yx = lbs.get("ndc"), lbs.get("yx")
+            elif both:  # vertices -> NDC and joints -> pixels in one launch
                 ndc, yx = engine.project_verts_and_joints(cams, lbs["verts"], lbs["joints"])
             elif w_j2d > 0:
                 _, yx = engine.project(cams, lbs["joints"], want_ndc=False)

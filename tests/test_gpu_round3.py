@@ -105,20 +105,51 @@ def test_backward_from_the_image_plane_decodes_packed_rows_and_declines_what_it_
     assert not eng.lbs_backward_ndc_supported(mouse, mouse.nB, 1)  # 11 263 vertices x 12 bytes
 
 
+@pytest.mark.parametrize("key,views,trans_after", [("stick", 1, True), ("stick", 3, False), ("synthetic", 5, True), ("synthetic_static", 2, True),
+                                                   ("synthetic_static", 2, False), ("mouse", 2, True)])
+def test_forward_with_projection_equals_forward_then_projection(key, views, trans_after, tables):
+    """``smil_lbs_forward_project``: skinning + joint regression + both projections in one kernel per frame (the mouse does not
+    fit its LDS and takes the separate kernels behind the same entry point)."""
+    from smilify_amd import cameras as cam_mod
+    from smilify_amd import engine as eng
+
+    t = tables(key)
+    dm = eng.DeviceModel(t, DEV)
+    B, S, J, nB = 21, 96, dm.J, dm.nB
+    g = torch.Generator().manual_seed(8)
+    beta = (0.4 * torch.randn(nB, generator=g)).to(DEV)
+    theta = (0.25 * torch.randn(B, J, 3, generator=g)).to(DEV)
+    trans = (0.1 * torch.randn(B, 3, generator=g)).to(DEV)
+    R, T = cam_mod.look_at_view_transform(3.0, 10.0, np.linspace(0, 300, views), device=DEV)
+    cams = eng.CameraSet(R.contiguous(), T.contiguous(), torch.full((views,), 50.0, device=DEV), None, views, S)
+    kw = dict(trans=trans, shared_beta=True, trans_after_joints=trans_after)
+    ref = eng.lbs_forward(dm, beta, theta, **kw)
+    ndc_ref, yx_ref = eng.project_verts_and_joints(cams, ref["verts"], ref["joints"])
+    for want in (dict(ndc=True, yx=True), dict(ndc=True, yx=False), dict(ndc=False, yx=True)):
+        got = eng.lbs_forward(dm, beta, theta, project=dict(cams=cams, **want), **kw)
+        for k in ("verts", "joints", "A", "new_J"):
+            _close(got[k], ref[k], 1e-6, k)
+        assert ("ndc" in got) == want["ndc"] and ("yx" in got) == want["yx"]
+        if want["ndc"]:
+            _close(got["ndc"], ndc_ref, 1e-6, "ndc")
+        if want["yx"]:
+            _close(got["yx"], yx_ref, 1e-6, "yx")
+
+
 @pytest.mark.parametrize("views", [1, 3])
-def test_fit_iteration_is_the_same_through_either_backward(views, tables):
+def test_fit_iteration_is_the_same_through_either_route(views, tables):
     from smilify_amd import engine as eng
     from smilify_amd import synthetic
 
     t = tables("stick")
     outs = []
     for fused in (True, False):
-        eng.FUSED_LBS_BACKWARD = fused
+        eng.FUSED_LBS_BACKWARD = eng.FUSED_LBS_FORWARD = fused
         try:
             f = synthetic.make_problem(t, 24, views, 64, DEV, seed=9, window=8)
             objs, grads = f._loss_and_grads(None, synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=8)
         finally:
-            eng.FUSED_LBS_BACKWARD = True
+            eng.FUSED_LBS_BACKWARD = eng.FUSED_LBS_FORWARD = True
         outs.append((objs, grads))
     (oa, ga), (ob, gb) = outs
     _close(oa, ob, 1e-6, "objs")

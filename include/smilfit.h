@@ -117,6 +117,9 @@ typedef struct {
                               matrices (Rs_in; smal_torch.py:288-289) */
     int32_t accumulate_shared_beta; /* shared_beta only: ADD the sum over frames to d_beta (caller zeroes it or holds
                               other terms there) instead of overwriting it */
+    const float *up_Rs;       /* (B,J,3,3) or NULL: upstream gradient on the rotation matrices the forward returned
+                              (SMAL.__call__ hands Rs to its caller, smal_torch.py:367-370); flows to d_theta / d_Rs_in */
+    const float *up_v_shaped; /* (nS,V,3) or NULL: upstream gradient on the returned v_shaped; flows to d_beta and d_del_v */
 } SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
                               logscale_shared, btrans_shared) receive the sum over frames */
 

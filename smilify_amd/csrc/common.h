@@ -9,6 +9,7 @@
 #include "smilfit.h"
 
 #define WAVE 64
+#define BONE_WAVES 8  // waves of the workgroup that walks a frame's bone lists (k_lbs_bwd_ndc: 512 threads)
 
 void smil_set_error(const char *fmt, ...);
 
@@ -65,7 +66,9 @@ struct SmilModel {
     float *bone_w = nullptr;
     float *J_static = nullptr;    // (J,3)
     float *jreg_shape = nullptr;  // (nB,J,3) = J_regressor @ shapedirs[k]: d beta through the rest joints without a pass over the vertices
-    int *bone_order = nullptr;    // (J) bones by falling vertex count (balanced dealing of the bone lists to waves)
+    int *bone_order = nullptr;    // (bone_slots) the bone lists dealt to BONE_WAVES waves, longest processing time first: slot w + k BONE_WAVES
+                                  // is wave w's k-th bone, -1 behind its last
+    int bone_slots = 0;
     float *posedirs = nullptr;    // (9(J-1),3V) or null
     std::vector<void *> allocations;
 };

@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(1024) k_skin_bwd_transforms(
 struct ChainBwdArgs {
     const float *theta, *theta_mask, *Rs, *logscale, *btrans, *J_rest, *G, *d_A, *d_newJ;
     const float *d_posefeat;  // (B,9(J-1)) gradient on vec(Rs[1:] - I) from the pose blend shapes, or NULL
+    const float *d_Rs_up;     // (B,J,9) upstream gradient on the rotation matrices SMAL.__call__ returned, or NULL
     const int *parents, *depth;
     float *d_theta, *d_logscale, *d_btrans, *d_Jrest;
     float *d_Rs_out;          // (B,J,9) gradient on the rotation matrices themselves (matrix-valued theta), or NULL
@@ -810,6 +811,8 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                 }
                 if (a.d_posefeat && j > 0)
                     for (int i = 0; i < 9; ++i) dR[i] += a.d_posefeat[fb * 9 * (J - 1) + (size_t)(j - 1) * 9 + i];
+                if (a.d_Rs_up)
+                    for (int i = 0; i < 9; ++i) dR[i] += a.d_Rs_up[o * 9 + i];
                 if (a.d_Rs_out)
                     for (int i = 0; i < 9; ++i) a.d_Rs_out[o * 9 + i] = dR[i];
                 if (a.d_theta && a.theta) {
@@ -872,7 +875,8 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
     const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_beta_shared, float *__restrict__ d_trans,
-    float *__restrict__ d_vshaped, int V, int J, int nB_used, int regress, int trans_after) {
+    float *__restrict__ d_vshaped, int V, int J, int nB_used, int regress, int trans_after,
+    const float *__restrict__ up_vshaped_all, int up_rows /* upstream gradient on the returned v_shaped (up_rows = 1 or B rows), or NULL */) {
     extern __shared__ float smem[];
     float *sA = smem;            // (J,12)
     float *sDJ = sA + J * 12;    // (J,3) upstream on posed joints
@@ -888,6 +892,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     }
     __syncthreads();
     const float *dvb = d_verts ? d_verts + (size_t)b * V * 3 : nullptr;
+    const float *up_vshaped = !up_vshaped_all ? nullptr : (up_rows == 1 ? (b == 0 ? up_vshaped_all : nullptr) : up_vshaped_all + (size_t)b * V * 3);
     const int V3 = 3 * V;
     for (int k0 = 0; k0 < (nB_used > 0 ? nB_used : 1); k0 += BETA_CHUNK) {
         float bsum[BETA_CHUNK];
@@ -924,6 +929,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
                     dvp[0] += wv * dr[0]; dvp[1] += wv * dr[1]; dvp[2] += wv * dr[2];
                 }
             }
+            if (up_vshaped) { dvp[0] += up_vshaped[3 * v]; dvp[1] += up_vshaped[3 * v + 1]; dvp[2] += up_vshaped[3 * v + 2]; }
             if (d_vshaped && k0 == 0) {  // = gradient on del_v: v_shaped = v_template + blend + del_v
                 float *o = d_vshaped + ((size_t)b * V + v) * 3;
                 o[0] = dvp[0]; o[1] = dvp[1]; o[2] = dvp[2];
@@ -997,7 +1003,7 @@ struct LbsBwdNdcArgs {
     const int2 *vfirst;
     const float *cval, *sd;
     float *d_A, *d_joints, *d_beta_frame, *d_beta_shared, *d_trans, *d_fov_img;
-    int B, V, J, nS, nB_used, regress, trans_after;
+    int B, V, J, nS, nB_used, regress, trans_after, bone_slots;
 };
 
 __device__ __forceinline__ void project_point_bwd(const float *cp /* 15 floats: R, T, k00, k11, - */, float x, float y, float z,
@@ -1034,12 +1040,14 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
     float *sCam = sDJ + 3 * J;          // (views,16)
     float *sFov = sCam + 16 * views;    // (views) raw fov sums of the frame's images
     float *red = sFov + views;          // (NW,12)
-    int *sBone = reinterpret_cast<int *>(red + NW * 12);  // (J,3) {first entry, end, bone} in the order the waves take them
+    int *sBone = reinterpret_cast<int *>(red + NW * 12);  // (bone_slots,3) {first entry, end, bone} in the order the waves take them
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const float h = 0.5f * (float)a.cam.S;
-    for (int o = tid; o < J; o += NT) {
+    static_assert(NW == BONE_WAVES, "the model's bone schedule is dealt to this many waves");
+    const int n_slots = a.bone_slots;
+    for (int o = tid; o < n_slots; o += NT) {
         const int j = a.bone_order[o];
-        sBone[3 * o] = a.bone_ptr[j]; sBone[3 * o + 1] = a.bone_ptr[j + 1]; sBone[3 * o + 2] = j;
+        sBone[3 * o] = j >= 0 ? a.bone_ptr[j] : 0; sBone[3 * o + 1] = j >= 0 ? a.bone_ptr[j + 1] : 0; sBone[3 * o + 2] = j;
     }
     if (a.nS == 1)  // one set of rest vertices for every frame: staged once (each thread its own vertices; phase 3 is behind a barrier)
         for (int v = tid; v < V; v += NT) { vpL[3 * v] = a.v_skin[3 * v]; vpL[3 * v + 1] = a.v_skin[3 * v + 1]; vpL[3 * v + 2] = a.v_skin[3 * v + 2]; }
@@ -1223,19 +1231,19 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
         // entries of the NEXT 64-entry segment (of this bone or of the wave's next one) are requested before this segment's
         // gathers: those come from LDS, so the list is the only memory round trip and it is hidden ----
 #ifdef NDC_ABL_NO_BONES  // (timing experiment, garbage results)
-        int o = J;
+        int o = n_slots;
 #else
-        int o = wid;
+        int o = sBone[3 * wid + 2] >= 0 ? wid : n_slots;  // (a wave's bones are its first slots)
 #endif
         int e0 = 0, e1 = 0;
-        if (o < J) { e0 = sBone[3 * o]; e1 = sBone[3 * o + 1]; }
+        if (o < n_slots) { e0 = sBone[3 * o]; e1 = sBone[3 * o + 1]; }
         int vid_n = 0;
         float w_n = 0.f;
-        if (o < J && e0 + lane < e1) { vid_n = a.bone_vid[e0 + lane]; w_n = a.bone_w[e0 + lane]; }
+        if (o < n_slots && e0 + lane < e1) { vid_n = a.bone_vid[e0 + lane]; w_n = a.bone_w[e0 + lane]; }
         float acc[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-        while (o < J) {  // (wave-uniform)
+        while (o < n_slots) {  // (wave-uniform)
             const int vid = vid_n;
             const float w = w_n;  // (0 beyond the end of the list)
             // where the next segment starts
@@ -1245,10 +1253,11 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
             if (bone_done) {
                 o_nx = o + NW;
                 e0_nx = e1_nx = 0;
-                if (o_nx < J) { e0_nx = sBone[3 * o_nx]; e1_nx = sBone[3 * o_nx + 1]; }
+                if (o_nx < n_slots && sBone[3 * o_nx + 2] < 0) o_nx = n_slots;  // behind the wave's last bone
+                if (o_nx < n_slots) { e0_nx = sBone[3 * o_nx]; e1_nx = sBone[3 * o_nx + 1]; }
             }
             vid_n = 0; w_n = 0.f;
-            if (o_nx < J && e0_nx + lane < e1_nx) { vid_n = a.bone_vid[e0_nx + lane]; w_n = a.bone_w[e0_nx + lane]; }
+            if (o_nx < n_slots && e0_nx + lane < e1_nx) { vid_n = a.bone_vid[e0_nx + lane]; w_n = a.bone_w[e0_nx + lane]; }
             {
                 const float x = vpL[3 * vid], y = vpL[3 * vid + 1], z = vpL[3 * vid + 2];
 #pragma unroll
@@ -1300,7 +1309,7 @@ struct NdcUpstream {
 };
 
 static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views) {
-    return ((size_t)6 * m->V + 4 + 18 * m->J + 17 * views + (NDC_BWD_THREADS / WAVE) * 12) * sizeof(float);
+    return ((size_t)6 * m->V + 4 + 15 * m->J + 3 * m->bone_slots + 17 * views + (NDC_BWD_THREADS / WAVE) * 12) * sizeof(float);
 }
 
 extern "C" int smil_lbs_backward_ndc_supported(const SmilModel *m, int32_t nB_used, int32_t views) {
@@ -1314,7 +1323,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
 extern "C" int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv,
                                  const SmilLbsGrads *g, void *stream_) {
     SMIL_REQUIRE(m && in && sv && g, "smil_lbs_backward: null argument");
-    SMIL_REQUIRE(g->d_verts || g->d_joints, "smil_lbs_backward: no upstream gradient");
+    SMIL_REQUIRE(g->d_verts || g->d_joints || g->up_Rs || g->up_v_shaped, "smil_lbs_backward: no upstream gradient");
     return lbs_backward_impl(m, in, sv, g, nullptr, (hipStream_t)stream_);
 }
 
@@ -1323,7 +1332,8 @@ extern "C" int smil_lbs_backward_ndc(const SmilModel *m, const SmilLbsInputs *in
                                      float *d_joints, float *d_fov_img, void *stream_) {
     SMIL_REQUIRE(m && in && sv && g && cam, "smil_lbs_backward_ndc: null argument");
     SMIL_REQUIRE(d_ndc || d_yx_joints, "smil_lbs_backward_ndc: no upstream gradient");
-    SMIL_REQUIRE(!g->d_verts && !g->d_joints && !g->d_del_v, "smil_lbs_backward_ndc: d_verts / d_joints / d_del_v belong to smil_lbs_backward");
+    SMIL_REQUIRE(!g->d_verts && !g->d_joints && !g->d_del_v && !g->up_v_shaped,
+                 "smil_lbs_backward_ndc: d_verts / d_joints / d_del_v / up_v_shaped belong to smil_lbs_backward");
     SMIL_REQUIRE(cam->N > 0 && cam->views > 0 && cam->N == in->B * cam->views, "smil_lbs_backward_ndc: %d images for %d frames x %d views",
                  cam->N, in->B, cam->views);
     SMIL_REQUIRE(smil_lbs_backward_ndc_supported(m, g->d_beta ? in->nB_used : 0, cam->views),
@@ -1373,7 +1383,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.colptr = m->jreg_colptr; a.row = m->jreg_row; a.cval = m->jreg_cval; a.sd = m->shapedirs; a.vfirst = m->jreg_vfirst;
         a.d_A = g->d_A; a.d_joints = up->d_joints; a.d_beta_frame = dbeta_frame_all; a.d_beta_shared = dbeta_shared_all;
         a.d_trans = g->d_trans; a.d_fov_img = up->d_fov_img;
-        a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress;
+        a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress; a.bone_slots = m->bone_slots;
         a.trans_after = in->trans_after_joints ? 1 : 0;
         const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views);
         int dev = 0, cus = 0;
@@ -1423,6 +1433,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.jreg_shape = js ? m->jreg_shape : nullptr;
         a.d_beta_frame = js ? dbeta_frame_all : nullptr; a.d_beta_shared = js ? dbeta_shared_all : nullptr; a.nB_used = nBu_all;
         a.d_posefeat = d_posefeat;
+        a.d_Rs_up = g->up_Rs;
         a.parents = m->parents; a.depth = m->depth;
         a.d_Rs_out = in->Rs_in ? g->d_Rs_in : nullptr;
         a.d_theta = g->d_theta; a.d_logscale = dls_frame; a.d_btrans = dbt_frame; a.d_Jrest = g->d_Jrest;
@@ -1449,7 +1460,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(shape_threads), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
                            m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, dbeta_shared, g->d_trans, g->d_del_v, V, J, nBu, regress,
-                           in->trans_after_joints ? 1 : 0);
+                           in->trans_after_joints ? 1 : 0, g->up_v_shaped, nS);
         SMIL_LAUNCH_CHECK();
     }
     return SMIL_OK;

@@ -126,9 +126,26 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
         std::memcpy(&wb, &w0, 4);
         vfirst[v] = make_int2((n_ent ? crow[colptr[v]] : 0) | (n_ent << 16), wb);
     }
-    std::vector<int> bone_order(J);
-    std::iota(bone_order.begin(), bone_order.end(), 0);
-    std::stable_sort(bone_order.begin(), bone_order.end(), [&](int a, int b) { return bone_cnt[a + 1] > bone_cnt[b + 1]; });
+    // the bone lists dealt to BONE_WAVES waves: longest first, each to the wave with the least work so far (work = 64-entry
+    // segments + one for the reduction at the end of a bone)
+    std::vector<int> by_len(J);
+    std::iota(by_len.begin(), by_len.end(), 0);
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return bone_cnt[a + 1] > bone_cnt[b + 1]; });
+    std::vector<std::vector<int>> per_wave(BONE_WAVES);
+    {
+        std::vector<int> load(BONE_WAVES, 0);
+        for (int j : by_len) {
+            const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            per_wave[w].push_back(j);
+            load[w] += (bone_cnt[j + 1] + WAVE - 1) / WAVE + 1;
+        }
+    }
+    size_t deepest = 0;
+    for (const auto &l : per_wave) deepest = std::max(deepest, l.size());
+    const int bone_slots = BONE_WAVES * (int)deepest;
+    std::vector<int> bone_order(std::max(bone_slots, 1), -1);
+    for (int w = 0; w < BONE_WAVES; ++w)
+        for (size_t k = 0; k < per_wave[w].size(); ++k) bone_order[w + k * BONE_WAVES] = per_wave[w][k];
 
     SmilModel *m = new SmilModel();
     m->V = V; m->F = F; m->J = J; m->nB = d->nB;
@@ -157,7 +174,8 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
     UP(bone_w, bone_w.data(), bone_nnz);
     UP(jreg_vfirst, vfirst.data(), V);
     UP(jreg_shape, jreg_shape.data(), (size_t)std::max(d->nB, 1) * J * 3);
-    UP(bone_order, bone_order.data(), J);
+    UP(bone_order, bone_order.data(), bone_slots);
+    m->bone_slots = bone_slots;
     UP(J_static, d->static_joints ? d->J_static : (const float *)nullptr, 3 * J);
     if (d->posedirs) { UP(posedirs, d->posedirs, (size_t)9 * (J - 1) * 3 * V); }
 #undef UP

@@ -216,12 +216,14 @@ def lbs_backward_ndc_supported(model: DeviceModel, nB_used: int, views: int) -> 
 def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=True, need_theta=True,
                  need_logscale=True, need_btrans=True, need_trans=True, need_vshaped=False,
                  need_Rs=False, d_beta_accum: Optional[torch.Tensor] = None, out_logscale: Optional[torch.Tensor] = None,
-                 out_btrans: Optional[torch.Tensor] = None, ndc_upstream: Optional[Dict] = None) -> Dict[str, Optional[torch.Tensor]]:
+                 out_btrans: Optional[torch.Tensor] = None, ndc_upstream: Optional[Dict] = None, up_Rs: Optional[torch.Tensor] = None,
+                 up_v_shaped: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
     """``d_beta_accum`` (shared betas only): the sum over frames is ADDED to this (nB,) tensor instead of a fresh one.
     ``out_logscale`` / ``out_btrans`` (shared tables only): (J,3) buffers that receive those gradients (overwritten).
     ``ndc_upstream`` = ``dict(cams=CameraSet, d_ndc=, d_ndc_scale=, d_yx=, d_fov_img=)`` instead of ``d_verts`` / ``d_joints``:
     the gradients are taken on the image plane and projected back inside the skinning backward (``smil_lbs_backward_ndc``);
-    the result then carries ``d_joints`` (B,J,3)."""
+    the result then carries ``d_joints`` (B,J,3).
+    ``up_Rs`` (B,J,3,3) / ``up_v_shaped`` (nS,V,3): upstream gradients on the returned rotation matrices / shaped vertices."""
     dev = model.device
     inp, fl = saved["_inputs"], saved["_flags"]
     B, J = fl["B"], model.J
@@ -266,6 +268,8 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
     for k, t in {**g, **scratch}.items():
         setattr(gs, k, None if t is None else t.data_ptr())
     gs.accumulate_shared_beta = int(accumulate_beta)
+    gs.up_Rs = None if up_Rs is None else up_Rs.data_ptr()
+    gs.up_v_shaped = None if up_v_shaped is None else up_v_shaped.data_ptr()
     if ndc_upstream is not None:
         if d_verts is not None or d_joints is not None or need_vshaped:
             raise ValueError("ndc_upstream replaces d_verts / d_joints and has no del_v gradient")

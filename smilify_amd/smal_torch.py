@@ -7,7 +7,7 @@ Differences that are deliberate and documented:
 * dense ``weights`` / ``J_regressor`` / ``posedirs`` attributes exist for callers that read them, but the
   kernels use the compact tables of ``model_io``;
 * gradients flow to ``beta, theta (axis-angle or (B,J,3,3) matrices), trans, del_v, betas_logscale, betas_trans,
-  v_template`` through ``verts`` and ``joints``; ``Rs`` and ``v_shaped`` are returned without gradient;
+  v_template`` through all four returned tensors (``verts``, ``joints``, ``Rs``, ``v_shaped``; reference :367-370);
 * inputs with a leading dimension of 1 are broadcast over the batch like the torch expressions of the reference do;
   any other shape mismatch raises instead of reading past a buffer;
 * pose blend shapes (legacy SMAL ``posedirs``) are applied when the model has a non-zero table; every SMIL
@@ -29,6 +29,7 @@ class _LbsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dm, flags, beta, theta, trans, logscale, btrans, del_v, v_template):
         dev = dm.device
+        ctx.set_materialize_grads(False)  # a returned tensor the caller's loss does not touch arrives as None, not as zeros
         c = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         theta_c = c(theta)
         rot_in = theta_c is not None and theta_c.dim() == 4
@@ -42,19 +43,20 @@ class _LbsFunction(torch.autograd.Function):
         ctx.rot_in = rot_in
         ctx.shared = (flags["logscale_shared"], flags["btrans_shared"])
         v_shaped = out["v_shaped"]
-        ctx.mark_non_differentiable(out["Rs"], v_shaped, out["new_J"])
+        ctx.mark_non_differentiable(out["new_J"])
         return out["verts"], out["joints"], out["Rs"], v_shaped, out["new_J"]
 
     @staticmethod
-    def backward(ctx, d_verts, d_joints, _dRs, _dvs, _dnj):
+    def backward(ctx, d_verts, d_joints, d_Rs, d_vs, _dnj):
         need = ctx.needs_input_grad  # (dm, flags, beta, theta, trans, logscale, btrans, del_v, v_template)
-        dv = None if d_verts is None else d_verts.contiguous()
-        dj = None if d_joints is None else d_joints.contiguous()
-        if dv is None and dj is None:
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        dv, dj, dR, dvs = cont(d_verts), cont(d_joints), cont(d_Rs), cont(d_vs)
+        if dv is None and dj is None and dR is None and dvs is None:
             return (None,) * 9
         g = engine.lbs_backward(ctx.dm, ctx.saved, dv, dj, need_beta=need[2] and ctx.has[0], need_theta=need[3] and ctx.has[1],
                                 need_logscale=need[5] and ctx.has[3], need_btrans=need[6] and ctx.has[4],
-                                need_trans=need[4] and ctx.has[2], need_vshaped=need[7] or need[8], need_Rs=need[3] and ctx.rot_in)
+                                need_trans=need[4] and ctx.has[2], need_vshaped=need[7] or need[8], need_Rs=need[3] and ctx.rot_in,
+                                up_Rs=dR, up_v_shaped=dvs)
         d_theta = g["d_Rs_in"] if ctx.rot_in else g["d_theta"]
         d_ls = g["d_logscale"] if g["d_logscale"] is None or not ctx.shared[0] else g["d_logscale"][None]
         d_bt = g["d_btrans"] if g["d_btrans"] is None or not ctx.shared[1] else g["d_btrans"][None]

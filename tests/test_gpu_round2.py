@@ -30,8 +30,8 @@ def test_smal_del_v_rotation_matrices_and_broadcast_inputs_match_reference(key, 
                                          betas_trans=leaf["bt"])
     np.testing.assert_allclose(verts.detach().cpu().numpy(), g["verts"], rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(joints.detach().cpu().numpy(), g["joints"], rtol=1e-4, atol=5e-6)
-    np.testing.assert_allclose(v_shaped.cpu().numpy(), g["v_shaped"], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(Rs_o.cpu().numpy(), g["Rs"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(v_shaped.detach().cpu().numpy(), g["v_shaped"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(Rs_o.detach().cpu().numpy(), g["Rs"], rtol=0, atol=1e-7)
     loss = (verts * vertex_probe(verts.shape, 2).to(DEV)).sum() + (joints * vertex_probe(joints.shape, 3).to(DEV)).sum()
     assert abs(loss.item() - float(g["loss"])) <= 2e-4 * abs(float(g["loss"])) + 1e-4
     loss.backward()

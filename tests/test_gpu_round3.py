@@ -159,3 +159,47 @@ def test_fit_iteration_is_the_same_through_either_route(views, tables):
             assert gb[k] is None
             continue
         _close(ga[k], gb[k], 3e-5, k)
+
+
+@pytest.mark.parametrize("key,matrices", [("stick", False), ("synthetic", True), ("synthetic_static", False)])
+def test_gradients_flow_through_all_four_tensors_smal_returns(key, matrices, tables):
+    """SMAL.__call__ hands (verts, joints, Rs, v_shaped) to its caller (reference smal_torch.py:367-370) and torch would
+    differentiate through every one of them: a loss on Rs and v_shaped alone, and one on all four, against the oracle's autograd."""
+    from conftest import oracle_model, vertex_probe
+    from oracle import lbs_ref
+    from smilify_amd.smal_torch import SMAL
+
+    t = tables(key)
+    smal = SMAL(DEV, tables=t)
+    m = oracle_model(t)
+    B, J, nB, V = 5, t.J, t.nB, t.V
+    g = torch.Generator().manual_seed(11)
+    host = dict(beta=0.4 * torch.randn(B, nB, generator=g), theta=0.3 * torch.randn(B, J, 3, generator=g),
+                trans=0.1 * torch.randn(B, 3, generator=g), del_v=0.01 * torch.randn(B, V, 3, generator=g))
+    if matrices:
+        host["theta"] = lbs_ref.rodrigues(host["theta"].reshape(-1, 3)).view(B, J, 3, 3)
+    pR, pS = vertex_probe((B, J, 3, 3), 2), vertex_probe((B, V, 3), 3)
+    pV, pJ = vertex_probe((B, V, 3), 0), vertex_probe((B, J, 3), 1)
+    for which in ("rs_vs", "all"):
+        ref_leaves = {k: v.clone().requires_grad_() for k, v in host.items()}
+        o = lbs_ref.smal_forward(m, ref_leaves["beta"], ref_leaves["theta"], trans=ref_leaves["trans"], del_v=ref_leaves["del_v"])
+        loss = (o["Rs"] * pR).sum() + (o["v_shaped"] * pS).sum()
+        if which == "all":
+            loss = loss + (o["verts"] * pV).sum() + (o["joints"] * pJ).sum()
+        loss.backward()
+        leaves = {k: v.clone().to(DEV).requires_grad_() for k, v in host.items()}
+        verts, joints, Rs, v_shaped = smal(leaves["beta"], leaves["theta"], trans=leaves["trans"], del_v=leaves["del_v"])
+        np.testing.assert_allclose(Rs.detach().cpu().numpy(), o["Rs"].detach().numpy(), atol=2e-6)
+        np.testing.assert_allclose(v_shaped.detach().cpu().numpy(), o["v_shaped"].detach().numpy(), atol=2e-6)
+        loss = (Rs * pR.to(DEV)).sum() + (v_shaped * pS.to(DEV)).sum()
+        if which == "all":
+            loss = loss + (verts * pV.to(DEV)).sum() + (joints * pJ.to(DEV)).sum()
+        loss.backward()
+        for k in host:
+            ref = ref_leaves[k].grad
+            got = leaves[k].grad
+            if which == "rs_vs" and k == "trans":
+                assert got is None or float(got.abs().max()) == 0.0  # neither tensor depends on the translation
+                continue
+            assert got is not None, (which, k)
+            _close(got, ref, 3e-4, (which, k))

@@ -6,6 +6,7 @@ path is a HIP kernel inside ``libsmilfit.so``.  All functions launch on ``torch.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -204,8 +205,9 @@ def lbs_forward(model: DeviceModel, beta, theta, trans=None, logscale=None, btra
     return out
 
 
-FUSED_LBS_FORWARD = True   # the fit iteration projects inside the skinning kernel (smil_lbs_forward_project)
-FUSED_LBS_BACKWARD = True  # the fit iteration takes smil_lbs_backward_ndc where the library supports the model (tests switch it off to compare)
+# SMILFIT_UNFUSED_LBS=1 (A/B measurements, tools/dbg/ab_lbs.sh): the fit iteration takes the separate projection / skinning kernels
+FUSED_LBS_FORWARD = os.environ.get("SMILFIT_UNFUSED_LBS") != "1"   # projection inside the skinning kernel (smil_lbs_forward_project)
+FUSED_LBS_BACKWARD = os.environ.get("SMILFIT_UNFUSED_LBS") != "1"  # the fit iteration takes smil_lbs_backward_ndc where the library supports the model (tests switch it off to compare)
 
 
 def lbs_backward_ndc_supported(model: DeviceModel, nB_used: int, views: int) -> bool:

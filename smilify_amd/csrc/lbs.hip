@@ -513,6 +513,19 @@ __global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_proje
 
 #define FWD_REG_LDS_MAX 4096  // regressor non-zeros staged in LDS (32 KB)
 static int fwd_fused_nnz_lds(const SmilModel *m) { return (!m->static_joints && m->jreg_nnz <= FWD_REG_LDS_MAX) ? m->jreg_nnz : 0; }
+// CUs of the current device (the grids of the per-frame persistent kernels); 0 if the query fails
+static int device_cu_count() {
+    static int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        cached = cus; cached_dev = dev;
+    }
+    return cached;
+}
+
 static size_t fwd_fused_lds_bytes(const SmilModel *m, int views) {
     return ((size_t)3 * m->V + 4 + 12 * m->J + 16 * views + m->J + 1 + 2 * fwd_fused_nnz_lds(m)) * sizeof(float);
 }
@@ -597,9 +610,7 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
         a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.regress = m->static_joints ? 0 : 1;
         a.nnz_lds = fwd_fused_nnz_lds(m);
         const size_t lds = fwd_fused_lds_bytes(m, cam->views);
-        int dev = 0, cus = 0;
-        SMIL_HIP(hipGetDevice(&dev));
-        SMIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int cus = device_cu_count();
         const int per_cu = std::max(1, std::min(FWD_MIN_WAVES / 2, (int)((160 * 1024) / lds)));
         hipLaunchKernelGGL(k_skin_project_fwd, dim3(std::min(B, std::max(1, cus) * per_cu)), dim3(FWD_FUSED_THREADS), lds, stream, a);
         SMIL_LAUNCH_CHECK();
@@ -1386,9 +1397,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress; a.bone_slots = m->bone_slots;
         a.trans_after = in->trans_after_joints ? 1 : 0;
         const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views);
-        int dev = 0, cus = 0;
-        SMIL_HIP(hipGetDevice(&dev));
-        SMIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int cus = device_cu_count();
         const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
         const int grid = std::min(B, std::max(1, cus) * per_cu);
         if (nBu_all <= 3) hipLaunchKernelGGL(k_lbs_bwd_ndc<3>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);

@@ -1571,10 +1571,18 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                         const int fch = ch * DCHUNK + h * WAVE + lane;
                         vi[h][0] = vi[h][1] = vi[h][2] = 0;
                         if (fch < list_total) {
+#ifdef ABL_P3CHAIN  // timing experiment (garbage results): no list -> face -> vertex chain, the coordinates are one round trip away
+                            const int f = fch % a.F;
+#else
                             const int f = (int)lst[fch];
+#endif
 #pragma unroll
                             for (int k = 0; k < 3; ++k) {
+#ifdef ABL_P3CHAIN
+                                vi[h][k] = (3 * f + k) % a.V;
+#else
                                 vi[h][k] = face_vertex(a.faces, xf_n, a.F, f, k);
+#endif
                                 const float *pv = vertex_ptr(vn, xv_n, a.V, vi[h][k]);
                                 fv[(h * WAVE + lane) * 3 + k] = make_float2(pv[0], pv[1]);
                             }

@@ -19,8 +19,11 @@ from smilify_amd import model_io  # noqa: E402
 DEV = "cuda:0"
 
 
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"  # up to 250 joints and 20 views
+
+
 def random_model(rng):
-    J = int(rng.integers(3, 121))
+    J = int(rng.integers(3, 251 if WIDE else 121))
     side = int(rng.integers(4, 41))
     while (J + 1) * side + 2 > 5000:
         side -= 1
@@ -73,7 +76,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     t = random_model(rng)
     dm = eng.DeviceModel(t, DEV)
     J, V, nB = dm.J, dm.V, dm.nB
-    B, views, S = int(rng.integers(1, 40)), int(rng.integers(1, 7)), 64
+    B, views, S = int(rng.integers(1, 40)), int(rng.integers(1, 21 if WIDE else 7)), 64
     shared_beta, trans_after = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     ls_shared, use_mask = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     g = torch.Generator().manual_seed(seed)

@@ -557,7 +557,13 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         const float2 zr = q.fzr[(size_t)n * FT + f];
         const Rec3 ent = {(uint32_t)f, __float_as_uint(zr.x), __float_as_uint(zr.y)};
         for (int ty = ty0; ty <= ty1; ++ty)
+#if defined(ABL_BIN_WRAP)      // timing experiments (garbage lists): every append lands in the image's first 12 KB ...
+            for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u) & 1023u) = ent;
+#elif defined(ABL_BIN_NOSTORE)  // ... only the cursor atomics
+            for (int tx = tx0; tx <= tx1; ++tx) if (atomicAdd(&tcur[ty * tiles_x + tx], 1u) == 0xFFFFFFFFu) at(lists, 0u) = ent;
+#else
             for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
+#endif
     }
 }
 

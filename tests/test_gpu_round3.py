@@ -203,3 +203,42 @@ def test_gradients_flow_through_all_four_tensors_smal_returns(key, matrices, tab
                 continue
             assert got is not None, (which, k)
             _close(got, ref, 3e-4, (which, k))
+
+
+def test_fused_entries_refuse_what_they_cannot_do(tables):
+    """Loud failures instead of wrong numbers: the image-plane backward on a mesh beyond its LDS, upstream gradients in both
+    forms at once, and a camera table that does not match the batch."""
+    from smilify_amd import cameras as cam_mod
+    from smilify_amd import engine as eng
+    from smilify_amd._lib import SmilError
+
+    t = tables("mouse")
+    dm = eng.DeviceModel(t, DEV)
+    B, S = 3, 32
+    g = torch.Generator().manual_seed(2)
+    beta = torch.zeros(dm.nB, device=DEV)
+    theta = (0.1 * torch.randn(B, dm.J, 3, generator=g)).to(DEV)
+    R, T = cam_mod.look_at_view_transform(4.0, 10.0, np.array([0.0]), device=DEV)
+    cams = eng.CameraSet(R.contiguous(), T.contiguous(), torch.full((1,), 50.0, device=DEV), None, 1, S)
+    lbs = eng.lbs_forward(dm, beta, theta, shared_beta=True)
+    d_ndc = torch.zeros(B, dm.V, 2, device=DEV)
+    with pytest.raises(SmilError, match="not available for this model"):
+        eng.lbs_backward(dm, lbs, None, None, ndc_upstream=dict(cams=cams, d_ndc=d_ndc))
+    small = eng.DeviceModel(tables("synthetic"), DEV)
+    th = (0.1 * torch.randn(B, small.J, 3, generator=g)).to(DEV)
+    lbs_s = eng.lbs_forward(small, torch.zeros(small.nB, device=DEV), th, shared_beta=True)
+    with pytest.raises(ValueError, match="ndc_upstream replaces"):
+        eng.lbs_backward(small, lbs_s, torch.zeros(B, small.V, 3, device=DEV), None, ndc_upstream=dict(cams=cams, d_ndc=torch.zeros(B, small.V, 2, device=DEV)))
+    two_views = eng.CameraSet(R.repeat(2, 1, 1).contiguous(), T.repeat(2, 1).contiguous(), torch.full((2,), 50.0, device=DEV), None, 2, S)
+    with pytest.raises(SmilError, match="images for"):
+        eng.lbs_backward(small, lbs_s, None, None, ndc_upstream=dict(cams=_Fixed(two_views, B), d_ndc=torch.zeros(B, small.V, 2, device=DEV)))
+
+
+class _Fixed:
+    """A camera set that claims ``n`` images whatever the caller computes (to reach the library's own check)."""
+
+    def __init__(self, cams, n):
+        self._c, self._n, self.views = cams, n, cams.views
+
+    def struct(self, _n):
+        return self._c.struct(self._n)

@@ -98,9 +98,11 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 // -DRASTER_EXPERIMENT: ablation knobs read from the environment by the host side (SMIL_STOP, SMIL_WRAP, SMIL_RESIDENT);
 // results are garbage under SMIL_WRAP / SMIL_STOP by design - timing experiments only, never in libsmilfit.so.
 #ifdef DBG_TIMERS
-#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0; unsigned long long tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub_last = tlast;
+#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0; unsigned long long tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub_last = tlast; unsigned long long tp3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp3_last = tlast;
 #define TSUB(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tsub[k] += now_ - tsub_last; tsub_last = now_; }  // finer marks, independent of TMARK
 #define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
+#define TP3_START { tp3_last = __builtin_readcyclecounter(); }
+#define TP3(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tp3[k] += now_ - tp3_last; tp3_last = now_; }  // inside pass 3 (dbg[48 + k])
 #ifdef DBG_STATS  // work counters: thousands of waves adding to the same few words - the launch runs several times longer, so the timers are read without them
 #define STAT(k, v) { const unsigned long long v_ = (unsigned long long)(v); /* (all lanes: v may hold a ballot) */ if (a.dbg && lane == 0) atomicAdd(&a.dbg[k], v_); }
 #else
@@ -108,11 +110,13 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #endif
 #define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
         atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); \
-        atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.dbg[32 + k_], tsub[k_]); }
+        atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); for (int k_ = 0; k_ < 8; ++k_) { atomicAdd(&a.dbg[32 + k_], tsub[k_]); atomicAdd(&a.dbg[48 + k_], tp3[k_]); } }
 #else
 #define TIMERS_INIT
 #define TSUB(k)
 #define TMARK(k)
+#define TP3_START
+#define TP3(k)
 #define STAT(k, v)
 #define TIMERS_FLUSH
 #endif
@@ -150,6 +154,11 @@ struct RasterCounters {
 };
 
 struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
+// Per list position of the current tile, left by pass 1 (which has them in registers) for pass 3: the face's projected vertices
+// and its vertex ids.  Pass 3 used to fetch them per group of 64 faces through the chain list -> face -> vertex: three dependent
+// memory round trips per group and 28 % of pass 3 (profiles/r4_pass3_timers.txt).
+struct alignas(8) TriXY { float x0, y0, x1, y1, x2, y2; };
+struct TriIds { int a, b, c; };
 
 // clip_faces (pytorch3d renderer/mesh/clip.py, as MeshRasterizer applies it with z_clip_value = znear / 2; the reference leaves that
 // default on, p3d_renderer.py:36-47): a face with one or two vertices nearer than z_clip is cut at the plane and its front part
@@ -209,7 +218,9 @@ struct RasterArgs {
     Rec3 *slist;             // the current tile's faces when it builds its list itself (ascending id; same entry layout) ...
     uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may
                              // truncate (the sort reads the depths it needs from slist instead of gathering them per face)
-    uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk
+    uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk from the 128th on (the others live in registers)
+    TriXY *sxy;              // (list_stride) projected vertices of the tile's faces by list position ...
+    TriIds *sid;             // ... and their vertex ids
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
     // pair records, 12 bytes each in ONE stream per workgroup (an append or a sweep step then touches one contiguous run of
     // memory instead of three): {depth bits, pixel | list position << 6 | inside << 22 | closest edge << 23, signed squared
@@ -659,6 +670,14 @@ __device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e)
     return single ? zv : pz;
 }
 
+// float -> nearest integer in ONE instruction (v_cvt_rpi_i32_f32 = floor(x + 0.5); __float2int_rn is v_rndne + v_cvt; the two differ
+// only on exact halves, which round up here)
+__device__ __forceinline__ int cvt_round(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ float face_prob(float sd, float inv_sigma_log2e) {
     // sigmoid(-dist / sigma) = 1 / (1 + 2^{dist log2(e) / sigma}); v_exp_f32 + v_rcp_f32 (1 ulp each), the two constant factors
     // of the exponent folded into one on the host
@@ -855,7 +874,8 @@ __device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const float *__restrict__ xv_n, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
-                                            int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2) {
+                                            int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2, TriXY *__restrict__ sxy_c,
+                                            TriIds *__restrict__ sid_c) {
     const int slot = lane & (DCHUNK - 1);
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
@@ -890,6 +910,8 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             r[5] = make_float4(e01x, e02x, e01y, e02y);
             r[6] = make_float4(rl01, rl02, e12x, e12y);
             r[7] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
+            sxy_c[slot] = TriXY{x0, y0, x1, y1, x2, y2};  // for pass 3 (fire and forget)
+            sid_c[slot] = TriIds{i0, i1, i2};
             const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
             b1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
@@ -1090,6 +1112,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
     Rec3 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
+    TriXY *const sxy = a.sxy + (size_t)blockIdx.x * a.list_stride;
+    TriIds *const sid = a.sid + (size_t)blockIdx.x * a.list_stride;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     Rec3 *const srec = a.srec + rec0, *const crec = a.crec + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
@@ -1222,6 +1246,20 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             unsigned long long open_px = __ballot(in_img && mine);
             int ox0 = sx0, ox1 = sx1, oy0 = sy0, oy1 = sy1;  // bounding box of the open pixels
             int chunks_done = 0;
+            // first record of every chunk (pass 3 walks the records group by group): lane c of `cst0` / `cst1` holds the start of chunk c /
+            // 64 + c - a register read in pass 3 instead of a memory round trip per group; chunks from 128 on (lists beyond 4096 faces)
+            // go through memory
+            uint32_t cst0 = 0u, cst1 = 0u;
+            auto set_chunk_start = [&](int c, uint32_t v) {  // (c, v wave-uniform)
+                if (c < WAVE) cst0 = lane == c ? v : cst0;
+                else if (c < 2 * WAVE) cst1 = lane == c - WAVE ? v : cst1;
+                else if (lane == 0) scfirst[c] = v;
+            };
+            auto chunk_start = [&](int c) -> uint32_t {
+                if (c < WAVE) return (uint32_t)__builtin_amdgcn_readlane((int)cst0, c);
+                if (c < 2 * WAVE) return (uint32_t)__builtin_amdgcn_readlane((int)cst1, c - WAVE);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)scfirst[c]);
+            };
             // The staging loads form a chain list entry -> vertex indices -> vertex coordinates.  The first two links are
             // fetched ahead: while chunk k is evaluated the indices of chunk k + 1 and the list entries of chunk k + 2 are in
             // flight (four registers), so a chunk starts with one memory round trip instead of three.
@@ -1255,8 +1293,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 const int i0 = ia, i1 = ib, i2 = ic;
                 ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + DCHUNK
                 f_nx = list_at(c0 + 2 * DCHUNK);
-                stage_faces(a, vn, xv_n, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2);
-                if (lane == 0) scfirst[c0 / DCHUNK] = (uint32_t)vbase;
+                stage_faces(a, vn, xv_n, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy + c0, sid + c0);
+                set_chunk_start(c0 / DCHUNK, (uint32_t)vbase);
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
 #ifdef RASTER_EXPERIMENT
@@ -1355,7 +1393,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 __syncthreads();
                 continue;
             }
-            if (lane == 0) scfirst[chunks_done] = (uint32_t)vbase;  // (chunks behind an early exit hold no records)
+            set_chunk_start(chunks_done, (uint32_t)vbase);  // (chunks behind an early exit hold no records)
             STAT(21, vbase) STAT(26, 1) STAT(27, list_total) STAT(28, chunks_done) STAT(29, (list_total + DCHUNK - 1) / DCHUNK) STAT(30, __popcll(open_px))
             __syncthreads();  // also: record stores of other lanes are visible from here on
             TMARK(1)
@@ -1476,6 +1514,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 // the compact records still in the stream (those of the last bucket examined) that made it: depth below the
                 // threshold, or at it up to the tie cut
                 lds.pgrad[lane] = make_float4(0.f, __uint_as_float(trunc ? pre : 0u), __int_as_float(tie_cut), 0.f);
+                const bool any_split_sel = __ballot(tie_cut != 0x7FFFFFFF) != 0ull;
                 __syncthreads();
                 for (int g0 = 0; g0 < n_cmp; g0 += DGROUP * WAVE) {
                     uint32_t kk[DGROUP], mt[DGROUP];
@@ -1493,10 +1532,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                         // a record AT the threshold depth of a pixel whose tie group straddles K is kept up to the cut in face id
                         // (rare: the id is fetched only then)
                         const bool in_range = g0 + u * WAVE + lane < n_cmp;
-                        const int cut = __float_as_int(pg.z);
-                        int fid = 0;
-                        if (in_range & (kk[u] == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[(mt[u] >> 6) & 0xFFFFu];
-                        const bool keep = in_range & ((kk[u] < zt_) | ((kk[u] == zt_) & (fid <= cut)));
+                        bool tie_ok = true;
+                        if (any_split_sel) {  // wave-uniform
+                            const int cut = __float_as_int(pg.z);
+                            int fid = 0;
+                            if (in_range & (kk[u] == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[(mt[u] >> 6) & 0xFFFFu];
+                            tie_ok = fid <= cut;
+                        }
+                        const bool keep = in_range & ((kk[u] < zt_) | ((kk[u] == zt_) & tie_ok));
                         if (keep & (lf[u] != 0.f)) atomicAdd(&lds.plog[mt[u] & 63u], (double)lf[u]);
                     }
                 }
@@ -1508,6 +1551,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             if (a.stop_after == 3) { p_lo += span; continue; }
 #endif
             STAT(22, n_cmp) STAT(23, __popcll(__ballot(trunc))) STAT(24, __popcll(__ballot(lds.plog[lane] != 0.0)))
+            STAT(40, any_trunc ? 1 : 0) STAT(41, may_truncate ? 1 : 0) STAT(42, any_trunc ? vbase : 0) STAT(43, may_truncate ? vbase : 0) STAT(44, __popcll(__ballot(tie_cut != 0x7FFFFFFF)))
             const float alpha = exp2f((float)lds.plog[lane]);
             TMARK(3)
 
@@ -1536,6 +1580,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
             const float coef = -g * alpha * a.inv_sigma;
             const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
+            const bool any_split = __ballot(tie_cut != 0x7FFFFFFF) != 0ull;  // a pixel whose tie group at the K-th depth is cut by face id
             TSUB(6)
             STAT(25, __popcll(__ballot(active)))
             if (MODE != MODE_FWD && __ballot(active) != 0ull) {
@@ -1553,49 +1598,30 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 // all sums - LDS, flush, memory-side atomics - are integer adds, exact in any order and any grouping of faces.
                 // (an image with cut faces stays on float atomics, see k_raster_setup)
                 const bool img_fixed = MODE == MODE_FUSED && a.packed && a.clip.xcount[n] == 0u;  // (wave-uniform)
-                float *const dnx = a.clip.xg + ((size_t)n * CLIP_VX - (size_t)a.V) * 2;  // gradient rows of the image's new vertices, indexed by vertex id
                 const float fx_scale = img_fixed ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma)
                                        : (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
                 const float fx_inv = fx_scale > 0.f ? 1.0f / fx_scale : 0.f;
                 lds.pgrad[lane] = make_float4(active ? coef * fx_scale : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
                 __syncthreads();
                 constexpr int GR = GCHUNK / DCHUNK;
+                static_assert(GCHUNK == WAVE, "pass 3: lane = face of the group");
                 const uint32_t copy_off = (uint32_t)(lane & (GCOPIES - 1)) * (GCHUNK * 3);
+                float *const xg_n = a.clip.xg + (size_t)n * CLIP_VX * 2;  // gradient rows of the image's new vertices (cut faces)
+                // the group's projected vertices, from which a record's edge parameter t is recomputed (4 bytes less written and
+                // read per record than storing it); the table lives where the selection histograms were
+                float2 *const fv = reinterpret_cast<float2 *>(lds.hist);  // [GCHUNK][3]
+                static_assert(GCHUNK * 3 * sizeof(float2) <= sizeof(lds.hist), "the vertex table of a group lives in the histogram area");
+                TP3_START
                 for (int ch = 0; ch < chunks_done; ch += GR) {
-                    const int i_beg = (int)scfirst[ch], i_end = (int)scfirst[min(ch + GR, chunks_done)];
+                    const int i_beg = (int)chunk_start(ch), i_end = (int)chunk_start(min(ch + GR, chunks_done));  // (registers: no memory round trip)
                     if (i_beg == i_end) continue;
-                    // vertex ids of this chunk's faces: requested now, used by the flush
-                    // vertex ids of this group's faces (lane = face, GCHUNK / WAVE faces per lane): requested now, used by the flush
-                    constexpr int FPL = GCHUNK / WAVE;
-                    int vi[FPL][3];
-                    // ... and their projected vertices, from which a record's edge parameter t is recomputed (4 bytes less
-                    // written and read per record than storing it); the table lives where the selection histograms were
-                    float2 *const fv = reinterpret_cast<float2 *>(lds.hist);  // [GCHUNK][3]
-                    static_assert(GCHUNK * 3 * sizeof(float2) <= sizeof(lds.hist), "the vertex table of a group lives in the histogram area");
-#pragma unroll
-                    for (int h = 0; h < FPL; ++h) {
-                        const int fch = ch * DCHUNK + h * WAVE + lane;
-                        vi[h][0] = vi[h][1] = vi[h][2] = 0;
-                        if (fch < list_total) {
-#ifdef ABL_P3CHAIN  // timing experiment (garbage results): no list -> face -> vertex chain, the coordinates are one round trip away
-                            const int f = fch % a.F;
-#else
-                            const int f = (int)lst[fch];
-#endif
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-#ifdef ABL_P3CHAIN
-                                vi[h][k] = (3 * f + k) % a.V;
-#else
-                                vi[h][k] = face_vertex(a.faces, xf_n, a.F, f, k);
-#endif
-                                const float *pv = vertex_ptr(vn, xv_n, a.V, vi[h][k]);
-                                fv[(h * WAVE + lane) * 3 + k] = make_float2(pv[0], pv[1]);
-                            }
-                        }
-                    }
-                    for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
-                    __syncthreads();
+                    TP3(0)
+                    // lane = face of the group: its projected vertices and vertex ids as pass 1 left them in the tile's table (one round
+                    // trip, requested together with the first records; the list -> face -> vertex chain they replace was three)
+                    const int fch = ch * DCHUNK + lane;
+                    const bool staged = fch < chunks_done * DCHUNK && fch < list_total;
+                    const TriXY txy = sxy[min(fch, list_total - 1)];
+                    const TriIds tid = sid[min(fch, list_total - 1)];
                     struct GRec { uint32_t z, mt; float sd; };
                     auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
 #pragma unroll
@@ -1605,87 +1631,99 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                             r[u].z = q.a; r[u].mt = q.b; r[u].sd = __uint_as_float(q.c);
                         }
                     };
+                    GRec ra[DGROUP], rb[DGROUP];
+                    load_recs(ra, i_beg);
+                    fv[lane * 3 + 0] = make_float2(txy.x0, txy.y0);
+                    fv[lane * 3 + 1] = make_float2(txy.x1, txy.y1);
+                    fv[lane * 3 + 2] = make_float2(txy.x2, txy.y2);
+                    TP3(1)
+                    for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
+                    lds_fence();
+                    TP3(2)
+                    // One row of records per lane and step, DGROUP rows per buffer.  Straight-line code: every lane computes its record's
+                    // contribution whether it is kept or not and only the two accumulator adds are predicated, so that the LDS gathers of
+                    // all rows of a buffer are in flight together (a branch per record kept each row's gathers behind the previous row's
+                    // conflicting atomics: one exposed LDS round trip per row).
                     auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {
-                        float4 pg[DGROUP];  // all LDS gathers first
+                        float4 pg[DGROUP];
+                        float2 pa[DGROUP], pb[DGROUP], pc[DGROUP];
+                        uint32_t oa[DGROUP], ob[DGROUP];
 #pragma unroll
-                        for (int u = 0; u < DGROUP; ++u) pg[u] = lds.pgrad[r[u].mt & 63u];
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const uint32_t mt = r[u].mt;
+                            const uint32_t f3 = ((mt >> 6) & (uint32_t)(GCHUNK - 1)) * 3u;  // (list position % GCHUNK) * 3
+                            const uint32_t edge = mt >> 23;
+                            oa[u] = f3 + (edge == 2u ? 1u : 0u); ob[u] = f3 + (edge == 0u ? 1u : 2u);  // end points of the closest edge
+                            pg[u] = lds.pgrad[mt & 63u];
+                            pa[u] = fv[oa[u]]; pb[u] = fv[ob[u]]; pc[u] = lds.pixt[mt & 63u];
+                        }
 #pragma unroll
                         for (int u = 0; u < DGROUP; ++u) {
                             const bool valid = g0 + u * WAVE + lane < i_end;
                             const uint32_t mt = r[u].mt;
-                            const int pos = (int)((mt >> 6) & 0xFFFFu);
                             const uint32_t zt_ = __float_as_uint(pg[u].y);
                             const bool inside = ((mt >> 22) & 1u) != 0u;
                             float gd = pg[u].x * face_prob(r[u].sd, a.inv_sigma_log2e);                 // scale * d L / d (signed dist)
                             gd = inside ? -gd : gd;                                               // ... / d (unsigned squared distance)
-                            const int cut = __float_as_int(pg[u].z);
-                            int fid = 0;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
-                            if (valid & (r[u].z == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[pos];
-                            const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & (fid <= cut)));
-                            const int edge = (int)(mt >> 23);
-                            const int va = edge == 2 ? 1 : 0, vb = edge == 0 ? 1 : 2;  // end points of the closest edge
+                            bool tie_ok = true;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
+                            if (any_split) {  // wave-uniform and rare: the fetch and the wait for it stay out of the common path
+                                const int cut = __float_as_int(pg[u].z);
+                                int fid = 0;
+                                if (valid & (r[u].z == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[(mt >> 6) & 0xFFFFu];
+                                tie_ok = fid <= cut;
+                            }
+                            const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & tie_ok));
                             // closest point of that edge: clamped projection of the pixel, as eval_pair computed it (t = 0 for a
                             // degenerate edge); r = closest point - pixel
-                            const float2 pa = fv[(pos % GCHUNK) * 3 + va], pb = fv[(pos % GCHUNK) * 3 + vb], pc = lds.pixt[mt & 63u];
-                            const float exx = pb.x - pa.x, eyy = pb.y - pa.y;
+                            const float exx = pb[u].x - pa[u].x, eyy = pb[u].y - pa[u].y;
                             const float l2 = exx * exx + eyy * eyy;
-                            const float t = __builtin_amdgcn_fmed3f((exx * (pc.x - pa.x) + eyy * (pc.y - pa.y)) * (l2 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l2)), 0.f, 1.f);
-                            const float rx = fmaf(t, exx, pa.x - pc.x), ry = fmaf(t, eyy, pa.y - pc.y);
+                            const float t = __builtin_amdgcn_fmed3f((exx * (pc[u].x - pa[u].x) + eyy * (pc[u].y - pa[u].y)) * (l2 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l2)), 0.f, 1.f);
+                            const float rx = fmaf(t, exx, pa[u].x - pc[u].x), ry = fmaf(t, eyy, pa[u].y - pc[u].y);
                             const float ex = 2.0f * rx * gd, ey = 2.0f * ry * gd;
                             const float bx = t * ex, by = t * ey;
-#ifdef RASTER_EXPERIMENT
-                            if (a.stop_after == 4) { if (keep && ex + ey + t == 123.456f) lds.gacc[0][0] = 1ull; continue; }  // no LDS atomics
-#endif
+                            // (x, y) -> x * 2^32 + y as 64-bit two's complement: a negative y borrows one from the high word
+                            auto pack = [](float x, float y) {
+                                const int qx = cvt_round(x), qy = cvt_round(y);
+                                return ((unsigned long long)(uint32_t)(qx + (qy >> 31)) << 32) | (unsigned long long)(uint32_t)qy;
+                            };
+                            const unsigned long long ga = pack(ex - bx, ey - by), gb = pack(bx, by);
                             if (keep) {
-                                // (x, y) -> x * 2^32 + y as 64-bit two's complement: a negative y borrows one from the high word
-                                auto pack = [](float x, float y) {
-                                    const int qx = __float2int_rn(x), qy = __float2int_rn(y);
-                                    return ((unsigned long long)(uint32_t)(qx + (qy >> 31)) << 32) | (unsigned long long)(uint32_t)qy;
-                                };
-                                unsigned long long *acc = &lds.gacc[0][0] + copy_off + (uint32_t)(pos % GCHUNK) * 3u;
-                                atomicAdd(acc + va, pack(ex - bx, ey - by));
-                                atomicAdd(acc + vb, pack(bx, by));
+                                unsigned long long *acc = &lds.gacc[0][0] + copy_off;
+                                atomicAdd(acc + oa[u], ga);
+                                atomicAdd(acc + ob[u], gb);
                             }
                         }
                     };
-                    {
-                        GRec ra[DGROUP], rb[DGROUP];
-                        load_recs(ra, i_beg);
-                        for (int g0 = i_beg; g0 < i_end; g0 += 2 * DGROUP * WAVE) {
-                            load_recs(rb, g0 + DGROUP * WAVE);
-                            grad_recs(ra, g0);
-                            load_recs(ra, g0 + 2 * DGROUP * WAVE);
-                            grad_recs(rb, g0 + DGROUP * WAVE);
-                        }
+                    for (int g0 = i_beg; g0 < i_end; g0 += 2 * DGROUP * WAVE) {
+                        load_recs(rb, g0 + DGROUP * WAVE);
+                        grad_recs(ra, g0);
+                        load_recs(ra, g0 + 2 * DGROUP * WAVE);
+                        grad_recs(rb, g0 + DGROUP * WAVE);
                     }
-                    __syncthreads();
-#pragma unroll
-                    for (int h = 0; h < FPL; ++h) {  // flush: sum the copies, unpack, one global atomic per touched vertex component
-                        if (ch * DCHUNK + h * WAVE + lane >= list_total) continue;
+                    TP3(3)
+                    lds_fence();
+                    TP3(4)
+                    if (staged) {  // flush: sum the copies, unpack, one global atomic per touched vertex component
+                        const int vi[3] = {tid.a, tid.b, tid.c};
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             unsigned long long tot = 0ull;
 #pragma unroll
-                            for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][(h * WAVE + lane) * 3 + k];
-                            const int qy = (int)(uint32_t)tot;
-                            const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
-#ifdef RASTER_EXPERIMENT
-                            if (a.stop_after == 5 && (qx | qy) != 0x12345678) continue;  // ablation: no global gradient atomics
-#endif
+                            for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][lane * 3 + k];
                             if (img_fixed) {  // wave-uniform: the sum is already in the image's scale
-                                if (tot != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[h][k], tot);
+                                if (tot != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[k], tot);
                                 continue;
                             }
-                            float *const row = vi[h][k] < a.V ? dn : dnx;  // (a vertex of a cut face's front part: its own table)
-                            if (qx != 0) atomicAdd(&row[2 * vi[h][k]], (float)qx * fx_inv);
-#ifdef RASTER_EXPERIMENT
-                            if (a.stop_after == 6) continue;  // ablation: half of the global gradient atomics
-#endif
-                            if (qy != 0) atomicAdd(&row[2 * vi[h][k] + 1], (float)qy * fx_inv);
+                            const int qy = (int)(uint32_t)tot;
+                            const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
+                            float *const row = vi[k] < a.V ? dn + 2 * vi[k] : xg_n + 2 * (vi[k] - a.V);  // (a vertex of a cut face's front part: its own table)
+                            if (qx != 0) atomicAdd(row, (float)qx * fx_inv);
+                            if (qy != 0) atomicAdd(row + 1, (float)qy * fx_inv);
                         }
                     }
                     lds_fence();  // the accumulators are read before the next group clears them; unlike __syncthreads() this does
                                   // not wait for the flush's global atomics to be acknowledged (a microsecond per group)
+                    TP3(5)
                 }
             }
             __syncthreads();
@@ -1734,10 +1772,11 @@ static int tile_grid(int N, int tiles_x) {
 }
 
 // per resident workgroup: F x {face id, nearest / farthest depth} in id order (tiles of images that are not binned), F face ids in walking order,
-// F / DCHUNK + 2 chunk starts, (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
+// F x {projected vertices (24 B), vertex ids (12 B)} by list position, F / DCHUNK + 2 chunk starts,
+// (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
 #define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
-    return (size_t)grid * (4 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+    return (size_t)grid * (13 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
 
@@ -1845,6 +1884,10 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
         ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
+        a.sxy = (TriXY *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(TriXY);
+        a.sid = (TriIds *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(TriIds);
         const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3);
         a.srec = (Rec3 *)ws; ws += stream;
         a.crec = (Rec3 *)ws;
@@ -1873,6 +1916,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         (void)hipMemcpy(h, dbg_dev, 512, hipMemcpyDeviceToHost);  // totals of the launches so far
         fprintf(stderr, "[dbg sub] other %.3e  item fetch %.3e  list bounds %.3e  sort %.3e  blend sweep %.3e  select %.3e  epilogue %.3e  pass3 %.3e\n",
                 (double)h[32], (double)h[33], (double)h[34], (double)h[35], (double)h[36], (double)h[37], (double)h[38], (double)h[39]);
+        fprintf(stderr, "[dbg pass3] chunk starts %.3e  vertex chain %.3e  zero + sync %.3e  record loop %.3e  sync %.3e  flush %.3e\n",
+                (double)h[48], (double)h[49], (double)h[50], (double)h[51], (double)h[52], (double)h[53]);
         fprintf(stderr, "[dbg timers] list %.3e  pass1 sweep %.3e  blend+select %.3e  pass1 staging %.3e  pass3 %.3e cycles (summed over waves); "
                 "first wave exit %.3e, last wave exit %.3e cycles after the first start\n",
                 (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)(h[6] - h[5]), (double)(h[7] - h[5]));
@@ -1882,6 +1927,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e; chunks walked %.4e of %.4e, pixels still open at the end %.4e\n",
                 (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25], (double)h[28], (double)h[29], (double)h[30]);
         fprintf(stderr, "[dbg stats] staged faces with a non-empty pixel box %.4e\n", (double)h[31]);
+        fprintf(stderr, "[dbg stats] (sub-)tiles with a truncated pixel %.4e (their records %.4e), that may truncate %.4e (records %.4e); pixels with a split tie group %.4e\n",
+                (double)h[40], (double)h[42], (double)h[41], (double)h[43], (double)h[44]);
         (void)hipMemset(dbg_dev, 0, 512);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         a.dbg = dbg_dev;

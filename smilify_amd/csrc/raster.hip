@@ -156,8 +156,7 @@ struct RasterCounters {
 struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
 // Per list position of the current tile, left by pass 1 (which has them in registers) for pass 3: the face's projected vertices
 // and its vertex ids.  Pass 3 used to fetch them per group of 64 faces through the chain list -> face -> vertex: three dependent
-// memory round trips per group and 28 % of pass 3 (profiles/r4_pass3_timers.txt).
-struct alignas(8) TriXY { float x0, y0, x1, y1, x2, y2; };
+// memory round trips per group and 28 % of pass 3 (profiles/r4_pass3_timers.txt).  Vertices as three float2 arrays, see stage_faces.
 struct TriIds { int a, b, c; };
 
 // clip_faces (pytorch3d renderer/mesh/clip.py, as MeshRasterizer applies it with z_clip_value = znear / 2; the reference leaves that
@@ -219,8 +218,8 @@ struct RasterArgs {
     uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may
                              // truncate (the sort reads the depths it needs from slist instead of gathering them per face)
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk from the 128th on (the others live in registers)
-    TriXY *sxy;              // (list_stride) projected vertices of the tile's faces by list position ...
-    TriIds *sid;             // ... and their vertex ids
+    float2 *sxy;             // (3, list_stride) projected vertices v0 / v1 / v2 of the tile's faces by list position ...
+    TriIds *sid;             // (list_stride) ... and their vertex ids
     // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
     // pair records, 12 bytes each in ONE stream per workgroup (an append or a sweep step then touches one contiguous run of
     // memory instead of three): {depth bits, pixel | list position << 6 | inside << 22 | closest edge << 23, signed squared
@@ -670,6 +669,79 @@ __device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e)
     return single ? zv : pz;
 }
 
+// Two horizontally adjacent pixels of one face per lane (round 4).  Everything a lane does per (face, pixel) pair that is not
+// arithmetic - finding its face and pixel, gathering the 32-float face record from LDS, the loop around it - is paid once per TWO pairs,
+// and the arithmetic itself packs over the two pixels (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, the face's constants as op_sel
+// splats): the two pixels share dy, and with it the y parts of every projection.  The per-pixel results are those of eval_pair /
+// pair_depth up to the rounding of a different (but equally valid) order of operations.
+// The face record as eight 16-byte rows read straight into registers.  (Reading it through a FaceRec in private memory let the
+// optimiser turn `w0 > 0 ? z0 : z1` into an INDEXED load from that private copy - which then lives in scratch memory, with a
+// scratch store and six scratch loads per sweep step.)
+struct FaceRows { float4 r0, r1, r2, r3, r4, r5, r6, r7; };
+__device__ __forceinline__ FaceRows load_face_rows(const float *rec) {
+    const float4 *r = reinterpret_cast<const float4 *>(rec);
+    return FaceRows{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
+}
+struct PairEval2 {
+    f32x2 w0, w1, w2;     // perspective-correct barycentric numerators, .x = left pixel (even column), .y = right pixel
+    f32x2 sd;             // signed squared distance
+    bool cand0, cand1, inside0, inside1;
+    uint32_t ebits0, ebits1;  // closest edge << 23 (record layout)
+};
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void eval_pair2(const FaceRows &q, float px0, float px1, float py, float dx0, float dx1, float dyp, float blur,
+                                           PairEval2 &e) {
+    const bool in_y = __builtin_amdgcn_fmed3f(py, q.r0.z, q.r0.w) == py;
+    const bool in0 = (__builtin_amdgcn_fmed3f(px0, q.r0.x, q.r0.y) == px0) & in_y, in1 = (__builtin_amdgcn_fmed3f(px1, q.r0.x, q.r0.y) == px1) & in_y;
+    const f32x2 DX = {dx0, dx1};
+    const f32x2 base01 = pk_fma((f32x2){q.r1.z, q.r1.w}, splat2(dyp), (f32x2){q.r2.x, q.r2.y});
+    const float base2 = fmaf(q.r2.w, dyp, q.r3.x);
+    e.w0 = pk_fma(splat2(q.r1.x), DX, splat2(base01.x));
+    e.w1 = pk_fma(splat2(q.r1.y), DX, splat2(base01.y));
+    e.w2 = pk_fma(splat2(q.r2.z), DX, splat2(base2));
+    e.inside0 = fminf(fminf(e.w0.x, e.w1.x), e.w2.x) > 0.f;   // (all three positive; the numerators are finite)
+    e.inside1 = fminf(fminf(e.w0.y, e.w1.y), e.w2.y) > 0.f;
+    // pixels relative to v0 and to v1; the y parts are the same for both pixels
+    const f32x2 QX0 = DX - splat2(q.r4.x), QX1 = DX - splat2(q.r4.y);
+    const f32x2 qy = splat2(dyp) - (f32x2){q.r4.z, q.r4.w};             // .x relative to v0, .y relative to v1
+    const f32x2 eyq0 = (f32x2){q.r5.z, q.r5.w} * splat2(qy.x);        // y parts of the projections on the edges leaving v0
+    const float eyq12 = q.r6.w * qy.y;
+    const f32x2 T01 = clamp01(pk_fma(splat2(q.r5.x), QX0, splat2(eyq0.x)) * splat2(q.r6.x));
+    const f32x2 T02 = clamp01(pk_fma(splat2(q.r5.y), QX0, splat2(eyq0.y)) * splat2(q.r6.y));
+    const f32x2 T12 = clamp01(pk_fma(splat2(q.r6.z), QX1, splat2(eyq12)) * splat2(q.r7.x));
+    const f32x2 RX01 = pk_fma(T01, splat2(q.r5.x), -QX0), RY01 = pk_fma(T01, splat2(q.r5.z), -splat2(qy.x));
+    const f32x2 RX02 = pk_fma(T02, splat2(q.r5.y), -QX0), RY02 = pk_fma(T02, splat2(q.r5.w), -splat2(qy.x));
+    const f32x2 RX12 = pk_fma(T12, splat2(q.r6.z), -QX1), RY12 = pk_fma(T12, splat2(q.r6.w), -splat2(qy.y));
+    const f32x2 D01 = pk_fma(RX01, RX01, RY01 * RY01), D02 = pk_fma(RX02, RX02, RY02 * RY02), D12 = pk_fma(RX12, RX12, RY12 * RY12);
+    const float dist0 = fminf(fminf(D01.x, D02.x), D12.x), dist1 = fminf(fminf(D01.y, D02.y), D12.y);
+    e.cand0 = in0 && (e.inside0 || dist0 < blur);
+    e.cand1 = in1 && (e.inside1 || dist1 < blur);
+    e.sd = (f32x2){e.inside0 ? -dist0 : dist0, e.inside1 ? -dist1 : dist1};
+    // closest edge in the reference's order e01, e02, e12 with <= ties: the first whose distance IS the minimum
+    e.ebits0 = D01.x == dist0 ? 0u : (D02.x == dist0 ? 1u << 23 : 2u << 23);
+    e.ebits1 = D01.y == dist1 ? 0u : (D02.y == dist1 ? 1u << 23 : 2u << 23);
+}
+// depths of both pixels (see pair_depth)
+__device__ __forceinline__ f32x2 pair_depth2(const FaceRows &q, const PairEval2 &e) {
+    // (the vertex depths as opaque scalars: selecting among the ELEMENTS of a row makes the optimiser index the row dynamically,
+    // through scratch memory)
+    float z0 = q.r3.y, z1 = q.r3.z, z2 = q.r3.w;
+    asm("" : "+v"(z0), "+v"(z1), "+v"(z2));
+    const f32x2 den3 = e.w0 + e.w1 + e.w2;
+    const f32x2 den = {fmaxf(den3.x, K_EPS), fmaxf(den3.y, K_EPS)};
+    const f32x2 m0 = {vmax_raw(e.w0.x, 0.f), vmax_raw(e.w0.y, 0.f)}, m1 = {vmax_raw(e.w1.x, 0.f), vmax_raw(e.w1.y, 0.f)},
+                m2 = {vmax_raw(e.w2.x, 0.f), vmax_raw(e.w2.y, 0.f)};
+    const f32x2 msum = m0 + m1 + m2, floor_ = splat2(1e-5f) * den;
+    const f32x2 cs = {fmaxf(msum.x, floor_.x), fmaxf(msum.y, floor_.y)};
+    const f32x2 rc = {__builtin_amdgcn_rcpf(cs.x), __builtin_amdgcn_rcpf(cs.y)};
+    const f32x2 pz = pk_fma(splat2(z0), m0 * rc, splat2(z1) * (m1 * rc)) + splat2(z2) * (m2 * rc);
+    // one survivor <=> the sum of the clipped weights equals their maximum (and was not lifted by the 1e-5 floor)
+    const float mx0 = fmaxf(fmaxf(m0.x, m1.x), m2.x), mx1 = fmaxf(fmaxf(m0.y, m1.y), m2.y);
+    const bool single0 = (msum.x == mx0) && (mx0 >= cs.x), single1 = (msum.y == mx1) && (mx1 >= cs.y);
+    const float zv0 = m0.x > 0.f ? z0 : (m1.x > 0.f ? z1 : z2), zv1 = m0.y > 0.f ? z0 : (m1.y > 0.f ? z1 : z2);
+    return (f32x2){single0 ? zv0 : pz.x, single1 ? zv1 : pz.y};
+}
+
 // float -> nearest integer in ONE instruction (v_cvt_rpi_i32_f32 = floor(x + 0.5); __float2int_rn is v_rndne + v_cvt; the two differ
 // only on exact halves, which round up here)
 __device__ __forceinline__ int cvt_round(float x) {
@@ -874,8 +946,8 @@ __device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const float *__restrict__ xv_n, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
-                                            int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2, TriXY *__restrict__ sxy_c,
-                                            TriIds *__restrict__ sid_c) {
+                                            int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2, float2 *__restrict__ sxy,
+                                            TriIds *__restrict__ sid, int c0, int list_stride) {
     const int slot = lane & (DCHUNK - 1);
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
@@ -885,7 +957,12 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
         const float x1 = p1[0], y1 = p1[1], z1 = p1[2];
         const float x2 = p2[0], y2 = p2[1], z2 = p2[2];
         float4 *r = reinterpret_cast<float4 *>(rec + slot * FSTR);
+        // The tile's vertex table for pass 3: three arrays of float2 (v0, v1, v2 by list position) and the vertex ids, so that every
+        // store instruction writes whole runs of bytes (one 24-byte structure per face, stored as 16 + 8 bytes, cost 0.45 ms per
+        // cfg2b launch in partial-line writes; this form 0.1): v0 from the low lanes and v1 from the high lanes in one instruction
+        at(sxy, (uint32_t)((hi ? list_stride : 0) + c0 + slot)) = hi ? make_float2(x1, y1) : make_float2(x0, y0);
         if (!hi) {
+            at(sid, (uint32_t)(c0 + slot)) = TriIds{i0, i1, i2};
             // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
             const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
             // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
@@ -910,8 +987,7 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             r[5] = make_float4(e01x, e02x, e01y, e02y);
             r[6] = make_float4(rl01, rl02, e12x, e12y);
             r[7] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
-            sxy_c[slot] = TriXY{x0, y0, x1, y1, x2, y2};  // for pass 3 (fire and forget)
-            sid_c[slot] = TriIds{i0, i1, i2};
+            at(sxy, (uint32_t)(2 * list_stride + c0 + slot)) = make_float2(x2, y2);  // (the table, see above)
             const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
             b1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
@@ -939,13 +1015,14 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
         }
     }
     if (!hi && slot < m && bx0 <= bx1 && b0 <= b1) {
-        const int bw = bx1 - bx0 + 1;
+        // the box in PIXEL PAIRS (columns 2c, 2c + 1 of one row; pair index = pixel index / 2): a lane of the sweep evaluates one
+        const int cp0 = bx0 >> 1, bw = (bx1 >> 1) - cp0 + 1;   // 1 ... 4 pairs per row
         cf = bw * (b1 - b0 + 1);
-        // what a pair needs to find its pixel: pair r of the box sits in box row r / bw, computed as (r * inv) >> 16 with
-        // inv = floor(65536 / bw) + 1 (exact for r < 64, bw <= 8; the reciprocal is exact for 1, 2, 4, 8 and 0.003 away from
-        // an integer at worst otherwise), and its pixel is first + r + (r / bw) * (8 - bw)
+        // what a lane needs to find its pixel pair: lane r of the box sits in box row r / bw, computed as (r * inv) >> 16 with
+        // inv = floor(65536 / bw) + 1 (exact for r < 32, bw <= 4: the reciprocal is exact for 1, 2, 4 and 1e-4 away from an
+        // integer otherwise), and its pair is first + r + (r / bw) * (4 - bw)
         const int inv = (int)(65536.0f * __builtin_amdgcn_rcpf((float)bw)) + 1;
-        packed2 = inv | ((8 - bw) << 17) | ((b0 * TILE + bx0) << 20);
+        packed2 = inv | ((TILE / 2 - bw) << 17) | ((b0 * (TILE / 2) + cp0) << 20);
     }
 }
 
@@ -1112,7 +1189,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
     Rec3 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
-    TriXY *const sxy = a.sxy + (size_t)blockIdx.x * a.list_stride;
+    float2 *const sxy = a.sxy + (size_t)blockIdx.x * 3 * a.list_stride;
     TriIds *const sid = a.sid + (size_t)blockIdx.x * a.list_stride;
     const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
     Rec3 *const srec = a.srec + rec0, *const crec = a.crec + rec0;
@@ -1293,7 +1370,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 const int i0 = ia, i1 = ib, i2 = ic;
                 ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + DCHUNK
                 f_nx = list_at(c0 + 2 * DCHUNK);
-                stage_faces(a, vn, xv_n, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy + c0, sid + c0);
+                stage_faces(a, vn, xv_n, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy, sid, c0, a.list_stride);
                 set_chunk_start(c0 / DCHUNK, (uint32_t)vbase);
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
@@ -1303,9 +1380,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 const int incl = wave_scan_add(cf);
                 const int off = incl - cf;          // first pair of this face in the chunk's pair list
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
-                packed |= off;                      // off <= DCHUNK * 64
-                if (vbase + n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform
-                STAT(20, n_pairs)
+                packed |= off;                      // off <= DCHUNK * 32
+                if (vbase + 2 * n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform (n_pairs lanes of two pixels each)
+                STAT(20, 2 * n_pairs)
                 // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
                 // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
                 // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
@@ -1338,50 +1415,62 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     const uint32_t pk = (uint32_t)__shfl((int)pk_rank.x, max(r, 0), WAVE), pk2 = (uint32_t)__shfl((int)pk_rank.y, max(r, 0), WAVE);
                     const int fs = (int)((pk >> 13) & (DCHUNK - 1));
                     const uint32_t rr = (uint32_t)(q0 + lane) - (pk & 0x1FFFu);
-                    // rr < 64 and the reciprocal has 17 bits: a 24-bit multiply (full rate) is exact.  Spelled in assembly because
+                    // rr < 32 and the reciprocal has 17 bits: a 24-bit multiply (full rate) is exact.  Spelled in assembly because
                     // hipcc widens __umul24 here to the quarter-rate v_mul_lo_u32 (it cannot see the range of rr)
                     uint32_t rr_inv;
                     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rr_inv) : "v"(rr), "v"(pk2 & 0x1FFFFu));
                     const uint32_t dy = rr_inv >> 16;
-                    const int p = (int)((__umul24(dy, (pk2 >> 17) & 7u) + rr + (pk2 >> 20)) & 63u);
-                    const float2 pc = lds.pixt[p];
-                    const float4 pt = make_float4(pc.x, pc.y, pc.x - cx, pc.y - cy);
-#ifdef ABL_GATHER  // timing experiment (garbage results): every lane reads the same face record (LDS broadcast, no conflicts)
-                    const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + (fs & 0) * FSTR);
-#else
-                    const FaceRec fr = *reinterpret_cast<const FaceRec *>(lds.rec + fs * FSTR);
+                    const int pp = (int)((__umul24(dy, (pk2 >> 17) & 3u) + rr + (pk2 >> 20)) & 31u);  // pixel pair: pixels 2 pp, 2 pp + 1
+                    const int p = 2 * pp;
+                    const float4 pc = *reinterpret_cast<const float4 *>(&lds.pixt[p]);   // (px, py) of both pixels: one 16-byte read
+                    const FaceRows fr = load_face_rows(lds.rec + fs * FSTR);
+                    PairEval2 e;
+                    eval_pair2(fr, pc.x, pc.z, pc.y, pc.x - cx, pc.z - cx, pc.y - cy, a.blur, e);
+#ifdef ABL_EXTRA_VALU  // timing experiment: ABL_EXTRA_VALU dependent-free v_fma_f32 per sweep step (how VALU-bound is the launch?)
+                    { float d0_ = pc.x, d1_ = pc.y, d2_ = pc.z, d3_ = pc.w;
+#pragma unroll
+                      for (int i_ = 0; i_ < ABL_EXTRA_VALU / 4; ++i_)
+                          asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(d0_), "+v"(d1_), "+v"(d2_), "+v"(d3_)); }
 #endif
-                    PairEval e;
-                    eval_pair(fr, pt.x, pt.y, pt.z, pt.w, a.blur, e);
-                    const bool cand = valid && e.cand && ((open_px >> p) & 1ull);
-                    const unsigned long long cm = __ballot(cand);
-                    if (cm == 0ull) continue;
+                    const uint32_t open2 = (uint32_t)(open_px >> p) & 3u;
+                    const bool cand0 = valid && e.cand0 && (open2 & 1u), cand1 = valid && e.cand1 && (open2 & 2u);
+                    const unsigned long long cm0 = __ballot(cand0), cm1 = __ballot(cand1);
+                    if ((cm0 | cm1) == 0ull) continue;
                     // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
                     // ... and never nearer than the face's nearest vertex (rounding of the convex combination), so that a record's
                     // digit is at least its face's: the closing rule above relies on it
-#ifdef ABL_DEPTH  // timing experiment (garbage results): no depth arithmetic
-                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(fr.z0), kmin), kmax)) : 3.0e38f;
-#else
-                    const float z = may_truncate ? __uint_as_float(min(max(__float_as_uint(vmax_raw(pair_depth(fr, e), fminf(fminf(fr.z0, fr.z1), fr.z2))), kmin), kmax)) : 3.0e38f;
-#endif
-                    const uint32_t zb = __float_as_uint(z);
-                    const uint32_t slot = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                    if (cand) {
-#ifdef ABL_STORE  // timing experiment: one lane stores
-                        if (lane == 0)
-#endif
-                        st_stream(srec, slot, Rec3{zb, (uint32_t)p | ((uint32_t)(c0 + fs) << 6) | (e.inside ? 1u << 22 : 0u) | ((uint32_t)e.edge << 23),
-                                                   __float_as_uint(e.sd)});
-#ifndef ABL_HIST  // (timing experiment: no per-pixel digit counts)
+                    uint32_t zb0 = 0x7F61B1E6u, zb1 = 0x7F61B1E6u;  // (3.0e38f: tiles that cannot truncate carry no depths)
+                    if (may_truncate) {
+                        const f32x2 z2 = pair_depth2(fr, e);
+                        const float zf = fminf(fminf(fr.r3.y, fr.r3.z), fr.r3.w);
+                        zb0 = min(max(__float_as_uint(vmax_raw(z2.x, zf)), kmin), kmax);
+                        zb1 = min(max(__float_as_uint(vmax_raw(z2.y, zf)), kmin), kmax);
+                    }
+                    // both records of a lane go next to each other (left pixel first): the stream stays in face-major, row-major
+                    // order, the order one pair per lane produced
+                    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm1,
+                                            __builtin_amdgcn_mbcnt_hi((uint32_t)(cm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm0, 0u))));
+                    const uint32_t slot0 = (uint32_t)vbase + before, slot1 = slot0 + (cand0 ? 1u : 0u);
+                    const uint32_t meta = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
+                    if (cand0) {
+                        st_stream(srec, slot0, Rec3{zb0, meta | (e.inside0 ? 1u << 22 : 0u) | e.ebits0, __float_as_uint(e.sd.x)});
                         if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
-                            const uint32_t bucket = ((zb - kmin) >> shift1) & ((1u << b1) - 1u);
+                            const uint32_t bucket = ((zb0 - kmin) >> shift1) & ((1u << b1) - 1u);
                             uint32_t *const hw = &lds.hist[(bucket >> 2) * WAVE + p];
                             const uint32_t sh = 8u * (bucket & 3u);
                             if (((*hw >> sh) & 0xFFu) < SAT8) atomicAdd(hw, 1u << sh);
                         }
-#endif
                     }
-                    vbase += __popcll(cm);
+                    if (cand1) {
+                        st_stream(srec, slot1, Rec3{zb1, (meta + 1u) | (e.inside1 ? 1u << 22 : 0u) | e.ebits1, __float_as_uint(e.sd.y)});
+                        if (may_truncate) {
+                            const uint32_t bucket = ((zb1 - kmin) >> shift1) & ((1u << b1) - 1u);
+                            uint32_t *const hw = &lds.hist[(bucket >> 2) * WAVE + p + 1];
+                            const uint32_t sh = 8u * (bucket & 3u);
+                            if (((*hw >> sh) & 0xFFu) < SAT8) atomicAdd(hw, 1u << sh);
+                        }
+                    }
+                    vbase += __popcll(cm0) + __popcll(cm1);
                 }
 #ifdef DBG_TIMERS
                 { const unsigned long long now_ = __builtin_readcyclecounter(); tsweep_ += now_ - tlast; tlast = now_; }
@@ -1620,8 +1709,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     // trip, requested together with the first records; the list -> face -> vertex chain they replace was three)
                     const int fch = ch * DCHUNK + lane;
                     const bool staged = fch < chunks_done * DCHUNK && fch < list_total;
-                    const TriXY txy = sxy[min(fch, list_total - 1)];
-                    const TriIds tid = sid[min(fch, list_total - 1)];
+                    const uint32_t fcl = (uint32_t)min(fch, list_total - 1);
+                    const float2 tv0 = at(sxy, fcl), tv1 = at(sxy, (uint32_t)a.list_stride + fcl), tv2 = at(sxy, 2u * (uint32_t)a.list_stride + fcl);
+                    const TriIds tid = at(sid, fcl);
                     struct GRec { uint32_t z, mt; float sd; };
                     auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
 #pragma unroll
@@ -1633,9 +1723,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     };
                     GRec ra[DGROUP], rb[DGROUP];
                     load_recs(ra, i_beg);
-                    fv[lane * 3 + 0] = make_float2(txy.x0, txy.y0);
-                    fv[lane * 3 + 1] = make_float2(txy.x1, txy.y1);
-                    fv[lane * 3 + 2] = make_float2(txy.x2, txy.y2);
+                    fv[lane * 3 + 0] = tv0;
+                    fv[lane * 3 + 1] = tv1;
+                    fv[lane * 3 + 2] = tv2;
                     TP3(1)
                     for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
                     lds_fence();
@@ -1884,8 +1974,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
         ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
-        a.sxy = (TriXY *)ws;
-        ws += grid * (size_t)a.list_stride * sizeof(TriXY);
+        a.sxy = (float2 *)ws;
+        ws += grid * (size_t)a.list_stride * 3 * sizeof(float2);
         a.sid = (TriIds *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(TriIds);
         const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3);

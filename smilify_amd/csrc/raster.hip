@@ -74,6 +74,9 @@
 #ifndef KGROUP
 #define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
 #endif
+#ifndef SELR
+#define SELR 6              // compact records a lane holds once the selection runs in registers (the stream is then at most SELR * 64 long)
+#endif
 #ifndef REC_CAP
 #define REC_CAP 65536       // pair records one (sub-)tile may produce
 #endif
@@ -1029,27 +1032,30 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
 // lane = pixel: in the histogram `hist` ([bucket / 2][pixel]) find the digit that holds the `need`-th smallest key.
 // Returns the number of keys counted for this pixel; updates (pre, need) and reports the count of the chosen digit.
 __device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b, uint32_t &pre, int &need, int &n_eq) {
-    int cum = 0, sel = 0, cnt_sel = 0, all = 0;
-    bool found = false;
+    uint32_t hw[(1 << SEL_BITS) / 2];
 #pragma unroll
-    for (int w_ = 0; w_ < (1 << SEL_BITS) / 2; ++w_) {
-        const uint32_t hw = hist[w_ * WAVE + lane];
-        const int h0 = (int)(hw & 0xFFFFu), h1 = (int)(hw >> 16);
-        all += h0 + h1;
-        if (!found && cum + h0 >= need) { sel = 2 * w_; cnt_sel = h0; found = true; }
-        cum += found ? 0 : h0;
-        if (!found && cum + h1 >= need) { sel = 2 * w_ + 1; cnt_sel = h1; found = true; }
-        cum += found ? 0 : h1;
+    for (int w_ = 0; w_ < (1 << SEL_BITS) / 2; ++w_) hw[w_] = hist[w_ * WAVE + lane];  // (all reads in flight together)
+    // Running sums c_k are non-decreasing: the chosen bucket is the number of c_k below `need`, the keys in lower buckets the largest
+    // such c_k, and the chosen bucket ends at the first c_k that reaches `need`.  Arithmetic selects only (as a chain of `if`s this
+    // was thirty-two exec-masked branches per call).
+    int c = 0, sel = 0, below = 0, first_ge = 0x7FFFFFFF;
+#pragma unroll
+    for (int k = 0; k < (1 << SEL_BITS); ++k) {
+        c += (k & 1) ? (int)(hw[k >> 1] >> 16) : (int)(hw[k >> 1] & 0xFFFFu);
+        const bool lt = c < need;
+        sel += lt ? 1 : 0;
+        below = lt ? c : below;
+        first_ge = min(first_ge, lt ? 0x7FFFFFFF : c);
     }
-    if (need > 0 && found) {
+    if (need > 0 && c >= need) {
         pre = (pre << b) | (uint32_t)sel;
-        need -= cum;
-        n_eq = cnt_sel;
+        need -= below;
+        n_eq = first_ge - below;
     } else {
         need = 0;  // fewer keys than the rank asked for: this pixel keeps everything
         n_eq = 0;
     }
-    return all;
+    return c;
 }
 
 // The same for the first digit, whose histogram holds four 8-bit counts per word ([bucket / 4][pixel]) that stop growing at
@@ -1570,6 +1576,104 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     nbits -= b2;
                     __syncthreads();
                 }
+                // refinement through memory while the compact stream is long (it shrinks about six-fold per sweep) ...
+                while (nbits > 0 && __ballot(need > 0) != 0ull && n_cmp > SELR * WAVE) {
+                    const int b = min(SEL_BITS, nbits);
+                    n_cmp = refine_sweep(lds, crec, n_cmp, nbits, b, lane, pre, need);
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
+                    nbits -= b;
+                    __syncthreads();
+                }
+                if (n_cmp <= SELR * WAVE) {
+                // ... then IN REGISTERS (round 4): a lane takes up to SELR of the remaining records and every further step - the digits
+                // still to go, the cut of a tie group by face id, the sum of the logs that made it - runs on them with the per-pixel
+                // histograms in LDS and no memory traffic at all.  Through memory each of those three to seven sweeps over a few
+                // hundred records was two exposed round trips (the first load, the drain of the in-place stores): the selection was
+                // 9.5 % of the launch for 23 % of the records.
+                constexpr uint32_t INV = 0xFFFFFFFFu;  // record that has left the selection (keys are below 2^31)
+                uint32_t rk[SELR], rm[SELR];
+                float rl[SELR];
+#pragma unroll
+                for (int r_ = 0; r_ < SELR; ++r_) {
+                    const int idx = r_ * WAVE + lane;
+                    const Rec3 q = at(crec, (uint32_t)min(idx, max(n_cmp - 1, 0)));
+                    rk[r_] = idx < n_cmp ? q.a : INV; rm[r_] = q.b; rl[r_] = __uint_as_float(q.c);
+                }
+                while (nbits > 0 && __ballot(need > 0) != 0ull) {
+                    const int b = min(SEL_BITS, nbits), shift = nbits - b;
+                    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+                    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+                    lds_fence();
+                    uint2 ps[SELR];
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_) ps[r_] = lds.psel[rm[r_] & 63u];
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_) {
+                        const uint32_t pxl = rm[r_] & 63u;
+                        const bool live = (rk[r_] != INV) & (ps[r_].y > 0u);
+                        const uint32_t top = rk[r_] >> nbits;
+                        const bool sure = live & (top < ps[r_].x), stay = live & (top == ps[r_].x);
+                        if (sure & (rl[r_] != 0.f)) atomicAdd(&lds.plog[pxl], (double)rl[r_]);
+                        if (stay) {
+                            const uint32_t bucket = (rk[r_] >> shift) & ((1u << b) - 1u);
+                            atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+                        }
+                        rk[r_] = (live & !stay) ? INV : rk[r_];  // decided either way: it leaves
+                    }
+                    lds_fence();
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
+                    nbits -= b;
+                    lds_fence();
+                }
+                if (trunc) zt_bits = pre + kmin;
+                // `need` of the n_eq faces at the threshold are kept: the ones with the smallest face ids
+                const bool split = trunc && need < n_eq;
+                uint32_t rf[SELR];  // face ids of the records at the threshold of a split pixel (fetched only in tiles that have one)
+#pragma unroll
+                for (int r_ = 0; r_ < SELR; ++r_) rf[r_] = INV;
+                if (__ballot(split) != 0ull) {
+                    lds.psel[lane] = make_uint2(split ? pre : INV, 0u);
+                    lds_fence();
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_)
+                        if (rk[r_] != INV && rk[r_] == lds.psel[rm[r_] & 63u].x) rf[r_] = lst[(rm[r_] >> 6) & 0xFFFFu];
+                    int pbits = 32 - __clz(max(a.FT - 1, 1));
+                    uint32_t ppre = 0u;
+                    int pneed = split ? need : 0, peq = 0;
+                    lds_fence();
+                    while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
+                        const int b = min(SEL_BITS, pbits), shift = pbits - b;
+                        lds.psel[lane] = make_uint2(ppre, (uint32_t)pneed);
+                        for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+                        lds_fence();
+#pragma unroll
+                        for (int r_ = 0; r_ < SELR; ++r_) {
+                            const uint32_t pxl = rm[r_] & 63u;
+                            const uint2 ps = lds.psel[pxl];
+                            const bool hit = (rf[r_] != INV) & (ps.y > 0u) & ((rf[r_] >> pbits) == ps.x);
+                            const uint32_t bucket = (rf[r_] >> shift) & ((1u << b) - 1u);
+                            if (hit) atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+                        }
+                        lds_fence();
+                        pick_digit(lds.hist, lane, b, ppre, pneed, peq);
+                        pbits -= b;
+                        lds_fence();
+                    }
+                    if (split) tie_cut = (int)ppre;
+                }
+                // the records still held that made it: depth below the threshold, or at it up to the tie cut
+                lds.psel[lane] = make_uint2(trunc ? pre : 0u, (uint32_t)tie_cut);
+                lds_fence();
+#pragma unroll
+                for (int r_ = 0; r_ < SELR; ++r_) {
+                    const uint32_t pxl = rm[r_] & 63u;
+                    const uint2 ps = lds.psel[pxl];
+                    const bool keep = (rk[r_] != INV) & ((rk[r_] < ps.x) | ((rk[r_] == ps.x) & (((int)ps.y == 0x7FFFFFFF) | ((int)rf[r_] <= (int)ps.y))));
+                    if (keep & (rl[r_] != 0.f)) atomicAdd(&lds.plog[pxl], (double)rl[r_]);
+                }
+                lds_fence();
+                } else {
+                // (the compact stream never got short - thousands of records tied in their first digits: everything through memory)
                 while (nbits > 0 && __ballot(need > 0) != 0ull) {
                     const int b = min(SEL_BITS, nbits);
                     n_cmp = refine_sweep(lds, crec, n_cmp, nbits, b, lane, pre, need);
@@ -1633,6 +1737,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     }
                 }
                 __syncthreads();
+                }
             }
             TMARK(2)
             TSUB(5)

@@ -53,9 +53,9 @@
 
 #define TILE 8
 #define DCHUNK 32           // faces staged per chunk
-#define FREC 32             // floats per staged face record
-#define FSTR 36             // its stride in LDS: 128-byte records would put the same field of every face in the same bank, and
-                            // pass 1 gathers 3-5 different faces per instruction; 144 bytes keeps 8 consecutive faces apart
+#define FREC 28             // floats per staged face record
+#define FSTR 28             // its stride in LDS: 112 bytes = 28 banks, so the 16-byte rows of 16 consecutive faces start in 16 different
+                            // bank quads (a 128-byte stride would put the same row of every face in the same banks)
 #define K_EPS 1e-8f
 #define ALPHA_GRAD_EPS 1e-12f  // pixels whose transmittance is below this contribute no gradient
 #ifndef SEL_BITS
@@ -592,7 +592,6 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
 // (w0, w1), the projections on the two edges leaving v0, ... become one packed fp32 instruction each (v_pk_fma_f32 / v_pk_mul_f32 /
 // v_pk_add_f32) without register moves; the third of each kind stays scalar.
 struct alignas(16) FaceRec {
-    float xmin, xmax, ymin, ymax;   // blurred bbox (absolute NDC)
     float A0, A1, B0, B1;
     float C0, C1, A2, B2;
     float C2, z0, z1, z2;
@@ -603,87 +602,34 @@ struct alignas(16) FaceRec {
     int i0, i1, i2;
 };
 static_assert(sizeof(FaceRec) == FREC * sizeof(float), "FaceRec layout");
-
-struct PairEval {
-    bool cand, inside;
-    float sd;             // signed squared distance
-    float w0, w1, w2;
-    // closest edge in the reference's order e01, e02, e12 with <= ties (its backward treats t as a constant):
-    // edge 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2)
-    int edge;
-};
+// (Round 4: the record no longer carries the blurred bounding box.  A lane only ever sees pixels of its face's pixel box, a superset of
+// the bounding box by 0.01 px, and a pixel outside the box is farther than sqrt(blur) from the face, so the distance test rejects it
+// as the box test did; the two can differ only for a pixel centre within rounding of the box edge.)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
 __device__ __forceinline__ f32x2 clamp01(f32x2 v) {  // (folds into the clamp bit of the producing instruction)
     return __builtin_elementwise_min(__builtin_elementwise_max(v, splat2(0.f)), splat2(1.f));
 }
-
-// Branch-free: every lane computes everything; `cand` says whether the pair exists.
-__device__ __forceinline__ void eval_pair(const FaceRec &f, float px, float py, float dxp, float dyp, float blur, PairEval &e) {
-    // inside [xmin, xmax] x [ymin, ymax] <=> the median of (p, lo, hi) is p itself (two instructions per axis; a masked
-    // pixel sits at 3e38 and fails; face coordinates are finite, the setup kernel drops the others)
-    const bool in_bb = (__builtin_amdgcn_fmed3f(px, f.xmin, f.xmax) == px) & (__builtin_amdgcn_fmed3f(py, f.ymin, f.ymax) == py);
-    const f32x2 dx = splat2(dxp), dy = splat2(dyp);
-    const f32x2 w01 = __builtin_elementwise_fma((f32x2){f.A0, f.A1}, dx, __builtin_elementwise_fma((f32x2){f.B0, f.B1}, dy, (f32x2){f.C0, f.C1}));
-    e.w0 = w01.x; e.w1 = w01.y;
-    e.w2 = fmaf(f.A2, dxp, fmaf(f.B2, dyp, f.C2));
-    e.inside = (e.w0 > 0.f) && (e.w1 > 0.f) && (e.w2 > 0.f);
-    // pixel relative to v0 (.x) and to v1 (.y)
-    const f32x2 qx = dx - (f32x2){f.x0c, f.x1c}, qy = dy - (f32x2){f.y0c, f.y1c};
-    // edges 01 and 02 leave v0: one packed lane each; edge 12 leaves v1: scalar
-    const f32x2 ex = {f.e01x, f.e02x}, ey = {f.e01y, f.e02y};
-    const f32x2 q0x = splat2(qx.x), q0y = splat2(qy.x);
-    const f32x2 t0 = clamp01((ex * q0x + ey * q0y) * (f32x2){f.rl01, f.rl02});
-    const float t12 = __builtin_amdgcn_fmed3f((f.e12x * qx.y + f.e12y * qy.y) * f.rl12, 0.f, 1.f);
-    const f32x2 rx = __builtin_elementwise_fma(t0, ex, -q0x), ry = __builtin_elementwise_fma(t0, ey, -q0y);
-    const float r12x = fmaf(t12, f.e12x, -qx.y), r12y = fmaf(t12, f.e12y, -qy.y);
-    const f32x2 d0 = __builtin_elementwise_fma(rx, rx, ry * ry);
-    const float d01 = d0.x, d02 = d0.y, d12 = fmaf(r12x, r12x, r12y * r12y);
-    const float dist = fminf(fminf(d01, d02), d12);
-    e.cand = in_bb && (e.inside || dist < blur);
-    e.sd = e.inside ? -dist : dist;
-    const bool c01 = (d01 <= d02) && (d01 <= d12);
-    const bool c02 = !c01 && (d02 <= d01) && (d02 <= d12);
-    e.edge = c01 ? 0 : (c02 ? 1 : 2);
-}
-
-// depth at the clipped, renormalised perspective-correct barycentrics:
-// c_i = max(p_i,0) / max(sum, 1e-5), p_i = w_i / den; 1/den cancels: c_i = max(w_i,0) / max(sum max(w,0), 1e-5 den).
-// When a single weight survives the clip the depth is EXACTLY that vertex's depth, so faces sharing the vertex tie
-// exactly (as x / x == 1 does in the reference) and the (depth, face id) order stays well defined.
 __device__ __forceinline__ float vmax_raw(float a, float b) {
+    // (v_max_f32 spelled out: hipcc puts a canonicalising v_max x, x in front of every fmaxf whose input it cannot prove canonical,
+    // and these inputs - results of fma instructions - always are)
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ float pair_depth(const FaceRec &f, const PairEval &e) {
-    const float den = fmaxf(e.w0 + e.w1 + e.w2, K_EPS);
-    // (v_max_f32 spelled out: hipcc puts a canonicalising v_max x, x in front of every fmaxf whose input it cannot prove canonical,
-    // and these inputs - results of fma instructions - always are)
-    const float m0 = vmax_raw(e.w0, 0.f), m1 = vmax_raw(e.w1, 0.f), m2 = vmax_raw(e.w2, 0.f);
-    const float cs = fmaxf(m0 + m1 + m2, 1e-5f * den);
-    const float rc = __builtin_amdgcn_rcpf(cs);
-    const float pz = (m0 * rc) * f.z0 + (m1 * rc) * f.z1 + (m2 * rc) * f.z2;
-    // one survivor <=> the sum of the clipped weights equals their maximum (and was not lifted by the 1e-5 floor)
-    const float mx = fmaxf(fmaxf(m0, m1), m2);
-    const bool single = (m0 + m1 + m2 == mx) && (mx >= cs);
-    const float zv = m0 > 0.f ? f.z0 : (m1 > 0.f ? f.z1 : f.z2);
-    return single ? zv : pz;
-}
 
 // Two horizontally adjacent pixels of one face per lane (round 4).  Everything a lane does per (face, pixel) pair that is not
-// arithmetic - finding its face and pixel, gathering the 32-float face record from LDS, the loop around it - is paid once per TWO pairs,
-// and the arithmetic itself packs over the two pixels (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, the face's constants as op_sel
-// splats): the two pixels share dy, and with it the y parts of every projection.  The per-pixel results are those of eval_pair /
-// pair_depth up to the rounding of a different (but equally valid) order of operations.
-// The face record as eight 16-byte rows read straight into registers.  (Reading it through a FaceRec in private memory let the
+// arithmetic - finding its face and pixel, gathering the face record from LDS, the loop around it - is paid once per TWO pairs, and
+// the arithmetic itself packs over the two pixels (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, the face's constants as op_sel
+// splats): the two pixels share dy, and with it the y parts of every projection.
+// The face record as seven 16-byte rows read straight into registers.  (Reading it through a FaceRec in private memory let the
 // optimiser turn `w0 > 0 ? z0 : z1` into an INDEXED load from that private copy - which then lives in scratch memory, with a
 // scratch store and six scratch loads per sweep step.)
-struct FaceRows { float4 r0, r1, r2, r3, r4, r5, r6, r7; };
+struct FaceRows { float4 r0, r1, r2, r3, r4, r5, r6; };
 __device__ __forceinline__ FaceRows load_face_rows(const float *rec) {
     const float4 *r = reinterpret_cast<const float4 *>(rec);
-    return FaceRows{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
+    return FaceRows{r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
 }
 struct PairEval2 {
     f32x2 w0, w1, w2;     // perspective-correct barycentric numerators, .x = left pixel (even column), .y = right pixel
@@ -692,43 +638,56 @@ struct PairEval2 {
     uint32_t ebits0, ebits1;  // closest edge << 23 (record layout)
 };
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ void eval_pair2(const FaceRows &q, float px0, float px1, float py, float dx0, float dx1, float dyp, float blur,
-                                           PairEval2 &e) {
-    const bool in_y = __builtin_amdgcn_fmed3f(py, q.r0.z, q.r0.w) == py;
-    const bool in0 = (__builtin_amdgcn_fmed3f(px0, q.r0.x, q.r0.y) == px0) & in_y, in1 = (__builtin_amdgcn_fmed3f(px1, q.r0.x, q.r0.y) == px1) & in_y;
+// clamp(v * s, 0, 1) for both pixels in one instruction, s = the low / high half of the pair `s2` (hipcc leaves the clamp of a packed
+// product as two separate v_max)
+__device__ __forceinline__ f32x2 pk_mul_clamp_lo(f32x2 v, f32x2 s2) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(v), "v"(s2));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_clamp_hi(f32x2 v, f32x2 s2) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] clamp" : "=v"(r) : "v"(v), "v"(s2));
+    return r;
+}
+__device__ __forceinline__ void eval_pair2(const FaceRows &q, float dx0, float dx1, float dyp, float blur, PairEval2 &e) {
     const f32x2 DX = {dx0, dx1};
-    const f32x2 base01 = pk_fma((f32x2){q.r1.z, q.r1.w}, splat2(dyp), (f32x2){q.r2.x, q.r2.y});
-    const float base2 = fmaf(q.r2.w, dyp, q.r3.x);
-    e.w0 = pk_fma(splat2(q.r1.x), DX, splat2(base01.x));
-    e.w1 = pk_fma(splat2(q.r1.y), DX, splat2(base01.y));
-    e.w2 = pk_fma(splat2(q.r2.z), DX, splat2(base2));
+    const f32x2 base01 = pk_fma((f32x2){q.r0.z, q.r0.w}, splat2(dyp), (f32x2){q.r1.x, q.r1.y});
+    const float base2 = fmaf(q.r1.w, dyp, q.r2.x);
+    e.w0 = pk_fma(splat2(q.r0.x), DX, splat2(base01.x));
+    e.w1 = pk_fma(splat2(q.r0.y), DX, splat2(base01.y));
+    e.w2 = pk_fma(splat2(q.r1.z), DX, splat2(base2));
     e.inside0 = fminf(fminf(e.w0.x, e.w1.x), e.w2.x) > 0.f;   // (all three positive; the numerators are finite)
     e.inside1 = fminf(fminf(e.w0.y, e.w1.y), e.w2.y) > 0.f;
     // pixels relative to v0 and to v1; the y parts are the same for both pixels
-    const f32x2 QX0 = DX - splat2(q.r4.x), QX1 = DX - splat2(q.r4.y);
-    const f32x2 qy = splat2(dyp) - (f32x2){q.r4.z, q.r4.w};             // .x relative to v0, .y relative to v1
-    const f32x2 eyq0 = (f32x2){q.r5.z, q.r5.w} * splat2(qy.x);        // y parts of the projections on the edges leaving v0
-    const float eyq12 = q.r6.w * qy.y;
-    const f32x2 T01 = clamp01(pk_fma(splat2(q.r5.x), QX0, splat2(eyq0.x)) * splat2(q.r6.x));
-    const f32x2 T02 = clamp01(pk_fma(splat2(q.r5.y), QX0, splat2(eyq0.y)) * splat2(q.r6.y));
-    const f32x2 T12 = clamp01(pk_fma(splat2(q.r6.z), QX1, splat2(eyq12)) * splat2(q.r7.x));
-    const f32x2 RX01 = pk_fma(T01, splat2(q.r5.x), -QX0), RY01 = pk_fma(T01, splat2(q.r5.z), -splat2(qy.x));
-    const f32x2 RX02 = pk_fma(T02, splat2(q.r5.y), -QX0), RY02 = pk_fma(T02, splat2(q.r5.w), -splat2(qy.x));
-    const f32x2 RX12 = pk_fma(T12, splat2(q.r6.z), -QX1), RY12 = pk_fma(T12, splat2(q.r6.w), -splat2(qy.y));
+    const f32x2 QX0 = DX - splat2(q.r3.x), QX1 = DX - splat2(q.r3.y);
+    const f32x2 qy = splat2(dyp) - (f32x2){q.r3.z, q.r3.w};           // .x relative to v0, .y relative to v1
+    const f32x2 eyq0 = (f32x2){q.r4.z, q.r4.w} * splat2(qy.x);        // y parts of the projections on the edges leaving v0
+    const float eyq12 = q.r5.w * qy.y;
+    const f32x2 rl0102 = {q.r5.x, q.r5.y}, rl12_ = {q.r6.x, q.r6.y};
+    const f32x2 T01 = pk_mul_clamp_lo(pk_fma(splat2(q.r4.x), QX0, splat2(eyq0.x)), rl0102);
+    const f32x2 T02 = pk_mul_clamp_hi(pk_fma(splat2(q.r4.y), QX0, splat2(eyq0.y)), rl0102);
+    const f32x2 T12 = pk_mul_clamp_lo(pk_fma(splat2(q.r5.z), QX1, splat2(eyq12)), rl12_);
+    const f32x2 RX01 = pk_fma(T01, splat2(q.r4.x), -QX0), RY01 = pk_fma(T01, splat2(q.r4.z), -splat2(qy.x));
+    const f32x2 RX02 = pk_fma(T02, splat2(q.r4.y), -QX0), RY02 = pk_fma(T02, splat2(q.r4.w), -splat2(qy.x));
+    const f32x2 RX12 = pk_fma(T12, splat2(q.r5.z), -QX1), RY12 = pk_fma(T12, splat2(q.r5.w), -splat2(qy.y));
     const f32x2 D01 = pk_fma(RX01, RX01, RY01 * RY01), D02 = pk_fma(RX02, RX02, RY02 * RY02), D12 = pk_fma(RX12, RX12, RY12 * RY12);
     const float dist0 = fminf(fminf(D01.x, D02.x), D12.x), dist1 = fminf(fminf(D01.y, D02.y), D12.y);
-    e.cand0 = in0 && (e.inside0 || dist0 < blur);
-    e.cand1 = in1 && (e.inside1 || dist1 < blur);
+    e.cand0 = e.inside0 || dist0 < blur;
+    e.cand1 = e.inside1 || dist1 < blur;
     e.sd = (f32x2){e.inside0 ? -dist0 : dist0, e.inside1 ? -dist1 : dist1};
     // closest edge in the reference's order e01, e02, e12 with <= ties: the first whose distance IS the minimum
     e.ebits0 = D01.x == dist0 ? 0u : (D02.x == dist0 ? 1u << 23 : 2u << 23);
     e.ebits1 = D01.y == dist1 ? 0u : (D02.y == dist1 ? 1u << 23 : 2u << 23);
 }
-// depths of both pixels (see pair_depth)
+// depth at the clipped, renormalised perspective-correct barycentrics, both pixels:
+// c_i = max(p_i,0) / max(sum, 1e-5), p_i = w_i / den; 1/den cancels: c_i = max(w_i,0) / max(sum max(w,0), 1e-5 den).
+// When a single weight survives the clip the depth is EXACTLY that vertex's depth, so faces sharing the vertex tie
+// exactly (as x / x == 1 does in the reference) and the (depth, face id) order stays well defined.
 __device__ __forceinline__ f32x2 pair_depth2(const FaceRows &q, const PairEval2 &e) {
     // (the vertex depths as opaque scalars: selecting among the ELEMENTS of a row makes the optimiser index the row dynamically,
     // through scratch memory)
-    float z0 = q.r3.y, z1 = q.r3.z, z2 = q.r3.w;
+    float z0 = q.r2.y, z1 = q.r2.z, z2 = q.r2.w;
     asm("" : "+v"(z0), "+v"(z1), "+v"(z2));
     const f32x2 den3 = e.w0 + e.w1 + e.w2;
     const f32x2 den = {fmaxf(den3.x, K_EPS), fmaxf(den3.y, K_EPS)};
@@ -970,26 +929,24 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
             const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
             // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
             const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
-            r[1] = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);                                      // A0 A1 B0 B1
-            r[2] = make_float4(edge_fn(cx, cy, x1, y1, x2, y2) * s0, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);  // C0 C1 A2 B2
-            r[3] = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
+            r[0] = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);                                      // A0 A1 B0 B1
+            r[1] = make_float4(edge_fn(cx, cy, x1, y1, x2, y2) * s0, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);  // C0 C1 A2 B2
+            r[2] = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
             const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
             const int yi_lo = (int)ceilf(((ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - yi_hi - ty * TILE, oy0);
             b1 = min(a.S - 1 - yi_lo - ty * TILE, oy1);
         } else {
             const float xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur, xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
-            const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
-            r[0] = make_float4(xmin, xmax, ymin, ymax);
             const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
             const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
             const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
             const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
             const float rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
-            r[4] = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
-            r[5] = make_float4(e01x, e02x, e01y, e02y);
-            r[6] = make_float4(rl01, rl02, e12x, e12y);
-            r[7] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
+            r[3] = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
+            r[4] = make_float4(e01x, e02x, e01y, e02y);
+            r[5] = make_float4(rl01, rl02, e12x, e12y);
+            r[6] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
             at(sxy, (uint32_t)(2 * list_stride + c0 + slot)) = make_float2(x2, y2);  // (the table, see above)
             const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
@@ -1431,7 +1388,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     const float4 pc = *reinterpret_cast<const float4 *>(&lds.pixt[p]);   // (px, py) of both pixels: one 16-byte read
                     const FaceRows fr = load_face_rows(lds.rec + fs * FSTR);
                     PairEval2 e;
-                    eval_pair2(fr, pc.x, pc.z, pc.y, pc.x - cx, pc.z - cx, pc.y - cy, a.blur, e);
+                    eval_pair2(fr, pc.x - cx, pc.z - cx, pc.y - cy, a.blur, e);
 #ifdef ABL_EXTRA_VALU  // timing experiment: ABL_EXTRA_VALU dependent-free v_fma_f32 per sweep step (how VALU-bound is the launch?)
                     { float d0_ = pc.x, d1_ = pc.y, d2_ = pc.z, d3_ = pc.w;
 #pragma unroll
@@ -1448,7 +1405,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     uint32_t zb0 = 0x7F61B1E6u, zb1 = 0x7F61B1E6u;  // (3.0e38f: tiles that cannot truncate carry no depths)
                     if (may_truncate) {
                         const f32x2 z2 = pair_depth2(fr, e);
-                        const float zf = fminf(fminf(fr.r3.y, fr.r3.z), fr.r3.w);
+                        const float zf = fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w);
                         zb0 = min(max(__float_as_uint(vmax_raw(z2.x, zf)), kmin), kmax);
                         zb1 = min(max(__float_as_uint(vmax_raw(z2.y, zf)), kmin), kmax);
                     }

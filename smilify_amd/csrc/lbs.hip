@@ -450,15 +450,9 @@ __global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_proje
                 float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
                 if (a.trans) { ox += tx; oy += ty; oz += tz; }
                 vL[3 * v] = ox; vL[3 * v + 1] = oy; vL[3 * v + 2] = oz;
-#ifndef FWD_ABL_NO_VERTS
                 float *o = a.verts + ((size_t)b * V + v) * 3;
                 o[0] = ox; o[1] = oy; o[2] = oz;
-#endif
-#ifdef FWD_ABL_NO_NDC
-                if (a.ndc && ox == 123.456f)
-#else
                 if (a.ndc)
-#endif
                     for (int view = 0; view < views; ++view) {
                         const float *cp = sCam + 16 * view;
                         const float vx = ox * cp[0] + oy * cp[3] + oz * cp[6] + cp[9];
@@ -475,11 +469,7 @@ __global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_proje
                     t2 = a.trans_after ? a.trans_after[3 * b + 2] : 0.f;
         // joints: sixteen lanes per joint (a regressor row holds ~30 non-zeros), four joints per wave at a time; the sum inside
         // the 16-lane row is four DPP adds.  Then the joint goes through the cameras (lane = view, sixteen at a time).
-#ifdef FWD_ABL_NO_JOINTS
-        for (int j0_ = 0; j0_ < 0; j0_ += 4 * NW) {
-#else
         for (int j0_ = 0; j0_ < J; j0_ += 4 * NW) {
-#endif
             const int j = j0_ + 4 * wid + (lane >> 4), sub = lane & 15;
             const bool live = j < J;
             float q0 = 0.f, q1 = 0.f, q2 = 0.f;
@@ -1148,11 +1138,7 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
         float term[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) term[i] = 0.f;
-#ifdef NDC_ABL_NO_REG  // (timing experiment, garbage results)
-        const bool reg = false;
-#else
         const bool reg = a.regress && a.d_yx;
-#endif
         for (int v0 = tid; v0 < V; v0 += NDC_UNR2 * NT) {
             uint32_t ids[NDC_UNR2];
             float4 w4[NDC_UNR2];
@@ -1191,9 +1177,6 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
                     dvL[3 * v] = dv[0]; dvL[3 * v + 1] = dv[1]; dvL[3 * v + 2] = dv[2];
                 }
                 if (!a.trans_after) { term[9] += dv[0]; term[10] += dv[1]; term[11] += dv[2]; }
-#ifdef NDC_ABL_NO_SHAPE  // (timing experiment, garbage results)
-                continue;
-#endif
                 if (a.nB_used == 0) continue;
                 const float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
                 float T[9];
@@ -1241,11 +1224,7 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
         // ---- phase 3: d_A[j] = sum_{v in bone j} w (dv (x) [v_skin; 1]), one wave per bone, longest lists first.  The list
         // entries of the NEXT 64-entry segment (of this bone or of the wave's next one) are requested before this segment's
         // gathers: those come from LDS, so the list is the only memory round trip and it is hidden ----
-#ifdef NDC_ABL_NO_BONES  // (timing experiment, garbage results)
-        int o = n_slots;
-#else
         int o = sBone[3 * wid + 2] >= 0 ? wid : n_slots;  // (a wave's bones are its first slots)
-#endif
         int e0 = 0, e1 = 0;
         if (o < n_slots) { e0 = sBone[3 * o]; e1 = sBone[3 * o + 1]; }
         int vid_n = 0;

@@ -16,7 +16,13 @@ void smil_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *smil_last_error(void) { return g_err; }
-extern "C" const char *smil_version(void) { return "smilfit 0.1 (gfx950)"; }
+// "instrumented" marks a library built by `make variant` for tools/dbg (timers, counters, cut-off experiments - possibly with garbage
+// results by design): tests/test_abi_cpu.py checks that the library the product loads is not one of those.
+#ifdef SMIL_INSTRUMENTED
+extern "C" const char *smil_version(void) { return "smilfit 0.2 (gfx950) instrumented"; }
+#else
+extern "C" const char *smil_version(void) { return "smilfit 0.2 (gfx950)"; }
+#endif
 
 template <typename T>
 static int upload(SmilModel *m, T **dst, const T *src, size_t n) {

@@ -92,37 +92,10 @@
 #endif
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
-// -DDBG_TIMERS: per-phase cycle sums and work counters of the tile kernel (printed by the next launch); off in normal
-// builds (tools/dbg builds libsmilfit_dbg.so with it).  The marks only read the cycle counter into registers; the one
-// place that touches memory is TIMERS_FLUSH / STAT: lane 0 of a single-wave workgroup issuing returning-free global
-// atomics on a 256-byte buffer, outside any divergent region and with no barrier or spin depending on their completion -
-// nothing another wave waits for, so they cannot deadlock the persistent loop (the kernel's exit condition is the work
-// counter alone).
-// -DRASTER_EXPERIMENT: ablation knobs read from the environment by the host side (SMIL_STOP, SMIL_WRAP, SMIL_RESIDENT);
-// results are garbage under SMIL_WRAP / SMIL_STOP by design - timing experiments only, never in libsmilfit.so.
-#ifdef DBG_TIMERS
-#define TIMERS_INIT unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter(); const unsigned long long tstart_ = tlast; unsigned long long tstage_ = 0, tsweep_ = 0; unsigned long long tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub_last = tlast; unsigned long long tp3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp3_last = tlast;
-#define TSUB(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tsub[k] += now_ - tsub_last; tsub_last = now_; }  // finer marks, independent of TMARK
-#define TMARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[k] += now_ - tlast; tlast = now_; }
-#define TP3_START { tp3_last = __builtin_readcyclecounter(); }
-#define TP3(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tp3[k] += now_ - tp3_last; tp3_last = now_; }  // inside pass 3 (dbg[48 + k])
-#ifdef DBG_STATS  // work counters: thousands of waves adding to the same few words - the launch runs several times longer, so the timers are read without them
-#define STAT(k, v) { const unsigned long long v_ = (unsigned long long)(v); /* (all lanes: v may hold a ballot) */ if (a.dbg && lane == 0) atomicAdd(&a.dbg[k], v_); }
-#else
-#define STAT(k, v)
-#endif
-#define TIMERS_FLUSH if (a.dbg && lane == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&a.dbg[k_], tph[k_]); \
-        atomicMin(&a.dbg[5], tstart_); atomicMin(&a.dbg[6], tlast); atomicMax(&a.dbg[7], tlast); \
-        atomicAdd(&a.dbg[3], tstage_); atomicAdd(&a.dbg[1], tsweep_); for (int k_ = 0; k_ < 8; ++k_) { atomicAdd(&a.dbg[32 + k_], tsub[k_]); atomicAdd(&a.dbg[48 + k_], tp3[k_]); } }
-#else
-#define TIMERS_INIT
-#define TSUB(k)
-#define TMARK(k)
-#define TP3_START
-#define TP3(k)
-#define STAT(k, v)
-#define TIMERS_FLUSH
-#endif
+// Instrumentation hooks (phase timers, work counters, cut-off / wrap experiments): empty in libsmilfit.so.  `make variant` builds the
+// instrumented libraries of tools/dbg with -DSMIL_INSTRUMENTED, which pulls their definitions from tools/dbg/raster_hooks_dbg.h; this
+// translation unit itself holds no experiment code, and smil_version() says which kind of build a library is.
+#include "raster_hooks.h"
 
 // Work items (touched tiles) are queued in four cost classes by the number of (face, pixel) pairs the tile will evaluate
 // (the sum of its faces' pixel boxes), and handed out heaviest class first: a persistent kernel whose longest items take
@@ -231,10 +204,7 @@ struct RasterArgs {
     // records that survive the first selection digit: {key = depth bits - tile minimum, meta, log2 of the blend factor}
     Rec3 *crec;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
-    unsigned long long *dbg; // DBG_TIMERS builds: per-phase cycle sums
-    int stop_after;          // RASTER_EXPERIMENT builds: ablation (0 list, 1 + staging, 2 + pair sweep, 3 + blend / select, 4 no LDS
-                             // gradient atomics, 5 no global gradient atomics; else all)
-    int force_split;         // RASTER_EXPERIMENT builds: >= 0 overrides the pieces a tile is dealt out in (log2)
+    HOOK_ARGS_FIELDS         // (instrumented builds: counter buffer, cut-off phase, forced split)
 };
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
@@ -256,12 +226,6 @@ __device__ __forceinline__ float image_fx_scale(float img_bound, float pix_scale
 
 // Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
 // VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
-#ifdef RASTER_EXPERIMENT  // tools/dbg experiments only: wrap every stream index (results are garbage, timing is not)
-__constant__ uint32_t g_wrap_mask = 0xFFFFFFFFu;
-#define WRAP_IDX(i) ((i) & g_wrap_mask)
-#else
-#define WRAP_IDX(i) (i)
-#endif
 // (12-byte elements: the index is below 2^24, so the full-rate 24-bit multiply is exact; left to itself hipcc emits the
 // quarter-rate v_mul_lo_u32, also for the shift-and-add spelling)
 template <typename T>
@@ -275,12 +239,12 @@ __device__ __forceinline__ uint32_t byte_offset(uint32_t i) {
 }
 template <typename T>
 __device__ __forceinline__ T &at(T *base, uint32_t i) {
-    i = WRAP_IDX(i);
+    i = HOOK_WRAP_IDX(i);
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset<T>(i));
 }
 template <typename T>
 __device__ __forceinline__ const T &at(const T *base, uint32_t i) {
-    i = WRAP_IDX(i);
+    i = HOOK_WRAP_IDX(i);
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset<T>(i));
 }
 
@@ -570,13 +534,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         const float2 zr = q.fzr[(size_t)n * FT + f];
         const Rec3 ent = {(uint32_t)f, __float_as_uint(zr.x), __float_as_uint(zr.y)};
         for (int ty = ty0; ty <= ty1; ++ty)
-#if defined(ABL_BIN_WRAP)      // timing experiments (garbage lists): every append lands in the image's first 12 KB ...
-            for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u) & 1023u) = ent;
-#elif defined(ABL_BIN_NOSTORE)  // ... only the cursor atomics
-            for (int tx = tx0; tx <= tx1; ++tx) if (atomicAdd(&tcur[ty * tiles_x + tx], 1u) == 0xFFFFFFFFu) at(lists, 0u) = ent;
-#else
             for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
-#endif
     }
 }
 
@@ -782,14 +740,10 @@ struct alignas(16) DenseLds {
 };
 static_assert(sizeof(DenseLds) * RESIDENT_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
 
-// Record-stream accesses: written once, read once or twice, never shared between workgroups.
-#ifdef STREAM_NT
-template <typename T> __device__ __forceinline__ T ld_stream(const T *base, uint32_t i) { return __builtin_nontemporal_load(&at(base, i)); }
-template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_t i, T v) { __builtin_nontemporal_store(v, &at(base, i)); }
-#else
+// Record-stream accesses: written once, read once or twice, never shared between workgroups (non-temporal forms measured 12 % slower
+// in round 2: the streams do live on L2 / Infinity Cache hits between pass 1 and the sweeps).
 template <typename T> __device__ __forceinline__ T ld_stream(const T *base, uint32_t i) { return at(base, i); }
 template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_t i, T v) { at(base, i) = v; }
-#endif
 
 // Single-wave workgroups: lanes exchange data through LDS without s_barrier, but the compiler must not forward a lane's
 // own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
@@ -1164,12 +1118,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         for (int c = 0; c < N_CLASSES; ++c) n_items_all += a.ctr->n_class[q][c];
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
     // the launch finishes in a fraction of one tile's serial time.
-#ifdef RASTER_EXPERIMENT
-    const unsigned int split_log = a.force_split >= 0 ? (unsigned int)a.force_split :
-#else
-    const unsigned int split_log =
-#endif
-        n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u));
+    const unsigned int split_log = HOOK_SPLIT_LOG(
+        n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u)));
     // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
     // near to far).
     const unsigned int split0_log = SPLIT0_LOG;
@@ -1192,9 +1142,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         if (lane == 0) unit = atomicAdd(&a.ctr->deal[part].next, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= n_units) break;
-#ifdef DBG_TIMERS
-        const unsigned long long tunit_ = tlast;
-#endif
+        TUNIT_START
         const bool heavy = unit < units0;
         const unsigned int sl = heavy ? split0_log : split_log, u_ = heavy ? unit : unit - units0;
         const unsigned int item = (u_ >> sl) + (heavy ? 0u : nc0);
@@ -1258,9 +1206,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         }
         TMARK(0)
         TSUB(3)
-#ifdef RASTER_EXPERIMENT
-        if (a.stop_after == 0) continue;
-#endif
+        HOOK_STOP_AFTER(0, continue)
 
         // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
         // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
@@ -1337,9 +1283,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 set_chunk_start(c0 / DCHUNK, (uint32_t)vbase);
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();
-#ifdef RASTER_EXPERIMENT
-                if (a.stop_after == 1) continue;
-#endif
+                HOOK_STOP_AFTER(1, continue)
                 const int incl = wave_scan_add(cf);
                 const int off = incl - cf;          // first pair of this face in the chunk's pair list
                 const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
@@ -1364,9 +1308,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 const uint32_t fl_hi = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane + 1) & 63];
                 const uint2 pk_rank = lds.psel[lane & (DCHUNK - 1)];
                 lds_fence();
-#ifdef DBG_TIMERS
-                { const unsigned long long now_ = __builtin_readcyclecounter(); tstage_ += now_ - tlast; tlast = now_; }
-#endif
+                TSTAGE_MARK
                 uint32_t carry = 0;                 // faces started before this step
                 for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
                     const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)fl_lo, q0 >> 6), whi = (uint32_t)__builtin_amdgcn_readlane((int)fl_hi, q0 >> 6);
@@ -1389,12 +1331,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     const FaceRows fr = load_face_rows(lds.rec + fs * FSTR);
                     PairEval2 e;
                     eval_pair2(fr, pc.x - cx, pc.z - cx, pc.y - cy, a.blur, e);
-#ifdef ABL_EXTRA_VALU  // timing experiment: ABL_EXTRA_VALU dependent-free v_fma_f32 per sweep step (how VALU-bound is the launch?)
-                    { float d0_ = pc.x, d1_ = pc.y, d2_ = pc.z, d3_ = pc.w;
-#pragma unroll
-                      for (int i_ = 0; i_ < ABL_EXTRA_VALU / 4; ++i_)
-                          asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(d0_), "+v"(d1_), "+v"(d2_), "+v"(d3_)); }
-#endif
+                    HOOK_EXTRA_VALU(pc)
                     const uint32_t open2 = (uint32_t)(open_px >> p) & 3u;
                     const bool cand0 = valid && e.cand0 && (open2 & 1u), cand1 = valid && e.cand1 && (open2 & 2u);
                     const unsigned long long cm0 = __ballot(cand0), cm1 = __ballot(cand1);
@@ -1435,9 +1372,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     }
                     vbase += __popcll(cm0) + __popcll(cm1);
                 }
-#ifdef DBG_TIMERS
-                { const unsigned long long now_ = __builtin_readcyclecounter(); tsweep_ += now_ - tlast; tlast = now_; }
-#endif
+                TSWEEP_MARK
                 lds_fence();  // rec is rewritten by the next chunk
             }
             if (!fits) {  // wave-uniform: try again with half the pixels
@@ -1449,9 +1384,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             STAT(21, vbase) STAT(26, 1) STAT(27, list_total) STAT(28, chunks_done) STAT(29, (list_total + DCHUNK - 1) / DCHUNK) STAT(30, __popcll(open_px))
             __syncthreads();  // also: record stores of other lanes are visible from here on
             TMARK(1)
-#ifdef RASTER_EXPERIMENT
-            if (a.stop_after == 1 || a.stop_after == 2) { p_lo += span; continue; }
-#endif
+            HOOK_STOP_AFTER(1, { p_lo += span; continue; }) HOOK_STOP_AFTER(2, { p_lo += span; continue; })
 
             // ---------------- select + pass 2 ---------------------------------------------------------------------
             // K-th smallest depth of every pixel that has more than K candidates, and log2 of every kept blend factor summed
@@ -1698,9 +1631,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             }
             TMARK(2)
             TSUB(5)
-#ifdef RASTER_EXPERIMENT
-            if (a.stop_after == 3) { p_lo += span; continue; }
-#endif
+            HOOK_STOP_AFTER(3, { p_lo += span; continue; })
             STAT(22, n_cmp) STAT(23, __popcll(__ballot(trunc))) STAT(24, __popcll(__ballot(lds.plog[lane] != 0.0)))
             STAT(40, any_trunc ? 1 : 0) STAT(41, may_truncate ? 1 : 0) STAT(42, any_trunc ? vbase : 0) STAT(43, may_truncate ? vbase : 0) STAT(44, __popcll(__ballot(tie_cut != 0x7FFFFFFF)))
             const float alpha = exp2f((float)lds.plog[lane]);
@@ -1883,15 +1814,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             TSUB(7)
             p_lo += span;
         }
-#ifdef DBG_TIMERS
-        if (a.dbg && lane == 0) {
-            const int cls = item < nc0 ? 0 : (item < nc0 + nc1 ? 1 : (item < nc0 + nc1 + nc2 ? 2 : 3));
-            const unsigned long long dt_ = tlast - tunit_;
-            atomicAdd(&a.dbg[8 + cls], dt_);
-            atomicMax(&a.dbg[12 + cls], dt_);
-            atomicMax(&a.dbg[16 + cls], tunit_ - tstart_);  // latest start of a unit of this class
-        }
-#endif
+        TUNIT_END
     }
     }  // next partition
     TIMERS_FLUSH
@@ -1917,9 +1840,7 @@ static int device_cus() {
 static int tile_grid(int N, int tiles_x) {
     const long long max_items = (long long)N * tiles_x * tiles_x;
     long long resident = (long long)device_cus() * RESIDENT_PER_CU;
-#ifdef RASTER_EXPERIMENT
-    if (const char *e = getenv("SMIL_RESIDENT")) resident = (long long)device_cus() * (atoi(e) > 0 && atoi(e) <= RESIDENT_PER_CU ? atoi(e) : RESIDENT_PER_CU);
-#endif
+    HOOK_RESIDENT(resident)
     return (int)(max_items < resident ? max_items : resident);
 }
 
@@ -2048,44 +1969,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
-    a.dbg = nullptr;
-    a.stop_after = 99;
-    a.force_split = -1;
-#ifdef RASTER_EXPERIMENT
-    if (const char *e = getenv("SMIL_STOP")) a.stop_after = atoi(e);
-    if (const char *e = getenv("SMIL_SPLIT")) a.force_split = atoi(e);
-    {
-        uint32_t mask = 0xFFFFFFFFu;
-        if (const char *e = getenv("SMIL_WRAP")) mask = (uint32_t)strtoul(e, nullptr, 0);
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wrap_mask), &mask, sizeof(mask), 0, hipMemcpyHostToDevice, stream);
-    }
-#endif
-#ifdef DBG_TIMERS
-    {
-        static unsigned long long *dbg_dev = nullptr;
-        if (!dbg_dev) { (void)hipMalloc(&dbg_dev, 512); (void)hipMemset(dbg_dev, 0, 512); }
-        unsigned long long h[64];
-        (void)hipMemcpy(h, dbg_dev, 512, hipMemcpyDeviceToHost);  // totals of the launches so far
-        fprintf(stderr, "[dbg sub] other %.3e  item fetch %.3e  list bounds %.3e  sort %.3e  blend sweep %.3e  select %.3e  epilogue %.3e  pass3 %.3e\n",
-                (double)h[32], (double)h[33], (double)h[34], (double)h[35], (double)h[36], (double)h[37], (double)h[38], (double)h[39]);
-        fprintf(stderr, "[dbg pass3] chunk starts %.3e  vertex chain %.3e  zero + sync %.3e  record loop %.3e  sync %.3e  flush %.3e\n",
-                (double)h[48], (double)h[49], (double)h[50], (double)h[51], (double)h[52], (double)h[53]);
-        fprintf(stderr, "[dbg timers] list %.3e  pass1 sweep %.3e  blend+select %.3e  pass1 staging %.3e  pass3 %.3e cycles (summed over waves); "
-                "first wave exit %.3e, last wave exit %.3e cycles after the first start\n",
-                (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)(h[6] - h[5]), (double)(h[7] - h[5]));
-        fprintf(stderr, "[dbg timers] per class: unit time sums %.3e %.3e %.3e %.3e  longest unit %.3e %.3e %.3e %.3e  latest unit start %.3e %.3e %.3e %.3e\n",
-                (double)h[8], (double)h[9], (double)h[10], (double)h[11], (double)h[12], (double)h[13], (double)h[14], (double)h[15],
-                (double)h[16], (double)h[17], (double)h[18], (double)h[19]);
-        fprintf(stderr, "[dbg stats] units %.4e  list entries %.4e  pairs evaluated %.4e  accepted %.4e  compact %.4e  pixels: touched %.4e truncated %.4e with gradient %.4e; chunks walked %.4e of %.4e, pixels still open at the end %.4e\n",
-                (double)h[26], (double)h[27], (double)h[20], (double)h[21], (double)h[22], (double)h[24], (double)h[23], (double)h[25], (double)h[28], (double)h[29], (double)h[30]);
-        fprintf(stderr, "[dbg stats] staged faces with a non-empty pixel box %.4e\n", (double)h[31]);
-        fprintf(stderr, "[dbg stats] (sub-)tiles with a truncated pixel %.4e (their records %.4e), that may truncate %.4e (records %.4e); pixels with a split tie group %.4e\n",
-                (double)h[40], (double)h[42], (double)h[41], (double)h[43], (double)h[44]);
-        (void)hipMemset(dbg_dev, 0, 512);
-        { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
-        a.dbg = dbg_dev;
-    }
-#endif
+    HOOK_HOST_LAUNCH_SETUP(a, stream)
     a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.target_u8 = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr;
     a.d_ndc = nullptr;
     return SMIL_OK;

@@ -20,6 +20,25 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.smil_version()
 
 
+def test_the_product_library_is_not_an_instrumented_build():
+    """libsmilfit.so holds no experiment code: the timers / counters / cut-off and wrap experiments of tools/dbg exist only in libraries
+    built by `make variant` (which define SMIL_INSTRUMENTED and say so in smil_version()), and the kernels' translation units
+    contain no ablation switch at all."""
+    from smilify_amd import _lib
+
+    lib = _lib.load()
+    assert b"instrumented" not in lib.smil_version(), lib.smil_version()
+    assert os.path.basename(_lib.LIB_PATH) == "libsmilfit.so" or os.environ.get("SMILFIT_LIB")
+    csrc = os.path.join(REPO, "smilify_amd", "csrc")
+    banned = re.compile(r"\b(ABL_[A-Z0-9_]+|NDC_ABL_[A-Z0-9_]+|FWD_ABL_[A-Z0-9_]+|RASTER_EXPERIMENT|STREAM_NT|DBG_TIMERS|DBG_STATS)\b")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")) and f != "raster_hooks.h":
+            hits = banned.findall(open(os.path.join(csrc, f)).read())
+            assert not hits, (f, sorted(set(hits)))
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "-DSMIL_INSTRUMENTED" in mk.split("variant:")[1] and "-DSMIL_INSTRUMENTED" not in mk.split("variant:")[0]
+
+
 def test_argument_validation_without_gpu():
     from smilify_amd import _lib
 

@@ -60,7 +60,7 @@ class LbsOutputs(Structure):
 class LbsGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("d_verts", "d_joints", "d_beta", "d_theta", "d_logscale", "d_btrans",
                                         "d_trans", "d_A", "d_Jrest", "d_Rs", "d_vposed", "d_posefeat", "d_del_v", "d_Rs_in")] + [
-        ("accumulate_shared_beta", c_int32), ("up_Rs", c_void_p), ("up_v_shaped", c_void_p)]
+        ("accumulate_shared_beta", c_int32), ("up_Rs", c_void_p), ("up_v_shaped", c_void_p), ("beta_rows", c_void_p)]
 
 
 class Cameras(Structure):

@@ -683,6 +683,53 @@ __global__ void __launch_bounds__(1024) k_skin_bwd_transforms(
     }
 }
 
+// Deterministic sum over frames of the SHARED shape gradient (the one quantity ranks all-reduce, SMALFitter.betas).  Every block of
+// every contributing kernel leaves its partial sum as a row of `rows` (a plain store; the order of the frames inside a block is fixed
+// by the launch), and the last block of the LAST kernel of the call to finish - found by a counter, no extra launch - adds the rows
+// in a fixed order.  Two runs on the same inputs give the same bits, whatever order the blocks ran in (the float atomics this
+// replaces did not).
+struct BetaSum {
+    float *rows;        // this kernel's rows [gridDim.x][n] (NULL: it contributes nothing)
+    const float *all;   // finishing kernel: every row of the call, [n_all][n] ...
+    int n_all;
+    unsigned int *ctr;  // ... and the block counter (zero between calls); NULL in a kernel that does not finish the sum
+    float *out;         // (n) the gradient
+    int accumulate;     // add to what `out` holds instead of overwriting it
+    int n;              // shape coefficients in use
+};
+__device__ __forceinline__ void beta_row_store(const BetaSum &q, int k, float v) {
+    __hip_atomic_store(&q.rows[(size_t)blockIdx.x * q.n + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: another XCD reads it)
+}
+// Called by every thread of every block of the finishing kernel, after the block's own rows are stored.  `red`: LDS, one float per wave.
+__device__ __forceinline__ void beta_sum_finish(const BetaSum &q, float *red) {
+    if (!q.ctr) return;  // (uniform)
+    __shared__ unsigned int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // this block's rows are visible device-wide before it counts as done
+        s_last = atomicAdd(q.ctr, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;  // (uniform)
+    __threadfence();
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE, nw = (blockDim.x + WAVE - 1) / WAVE;
+    for (int k = 0; k < q.n; ++k) {
+        float r = 0.f;
+        for (int i = threadIdx.x; i < q.n_all; i += blockDim.x)  // thread t adds rows t, t + T, ... in this order
+            r += __hip_atomic_load(&q.all[(size_t)i * q.n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = wave_sum(r);  // (a fixed shuffle pattern)
+        if (lane == 0) red[wid] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = q.accumulate ? q.out[k] : 0.f;
+            for (int w = 0; w < nw; ++w) tot += red[w];
+            q.out[k] = tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *q.ctr = 0u;  // ready for the next call (stream order)
+}
+
 struct ChainBwdArgs {
     const float *theta, *theta_mask, *Rs, *logscale, *btrans, *J_rest, *G, *d_A, *d_newJ;
     const float *d_posefeat;  // (B,9(J-1)) gradient on vec(Rs[1:] - I) from the pose blend shapes, or NULL
@@ -694,7 +741,8 @@ struct ChainBwdArgs {
     // the shape gradient that flows through the REST JOINTS, d beta[k] += sum_j d J_rest[j] . (J_regressor shapedirs[k])[j]
     // (model table jreg_shape): added here when the caller's vertex pass leaves it out (smil_lbs_backward_ndc), else NULL
     const float *jreg_shape;
-    float *d_beta_frame, *d_beta_shared;  // (B,nB_used) rows ADDED to / (nB_used,) atomically added to; one of them
+    float *d_beta_frame;      // (B,nB_used) rows ADDED to (per-frame betas), or NULL
+    BetaSum beta;             // shared betas: this kernel's partial rows and, when it is the call's last kernel, the final sum
     int nB_used;
 };
 
@@ -850,15 +898,17 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                 else red[k] = r;
             }
         }
-        if (a.d_beta_shared) {  // the block's frames first, then one atomic per shape coefficient and block
+        if (a.beta.rows) {  // the block's frames in a fixed order: one row per block
             __syncthreads();
             if ((int)threadIdx.x < a.nB_used) {
                 float r = 0.f;
                 for (int w = 0; w < FRAMES_PER_BLOCK; ++w) r += smem[(size_t)w * J * 30 + threadIdx.x];
-                if (r != 0.f) atomicAdd(&a.d_beta_shared[threadIdx.x], r);
+                beta_row_store(a.beta, threadIdx.x, r);
             }
         }
     }
+    __syncthreads();  // (smem is free from here on)
+    beta_sum_finish(a.beta, smem);
 }
 
 #define BETA_CHUNK 8
@@ -875,7 +925,7 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
     const float *__restrict__ d_verts, const float *__restrict__ d_joints, const float *__restrict__ d_Jrest,
     const float *__restrict__ A, const uint32_t *__restrict__ skin_idx, const float4 *__restrict__ skin_w,
     const int *__restrict__ colptr, const int *__restrict__ row, const float *__restrict__ cval,
-    const float *__restrict__ sd, float *__restrict__ d_beta_frame, float *__restrict__ d_beta_shared, float *__restrict__ d_trans,
+    const float *__restrict__ sd, float *__restrict__ d_beta_frame, BetaSum beta, float *__restrict__ d_trans,
     float *__restrict__ d_vshaped, int V, int J, int nB_used, int regress, int trans_after,
     const float *__restrict__ up_vshaped_all, int up_rows /* upstream gradient on the returned v_shaped (up_rows = 1 or B rows), or NULL */) {
     extern __shared__ float smem[];
@@ -965,13 +1015,15 @@ __global__ void __launch_bounds__(1024) k_shape_bwd(
             if (k < BETA_CHUNK) {
                 if (k0 + k < nB_used) {
                     if (d_beta_frame) d_beta_frame[(size_t)b * nB_used + k0 + k] = r;
-                    if (d_beta_shared && r != 0.f) atomicAdd(&d_beta_shared[k0 + k], r);  // sum over frames
+                    if (beta.rows) beta_row_store(beta, k0 + k, r);  // (one row per frame; summed over frames by the last block)
                 }
             } else if (with_trans) {
                 d_trans[3 * b + k - BETA_CHUNK] = r;
             }
         }
     }
+    __syncthreads();
+    beta_sum_finish(beta, red);
 }
 
 
@@ -1003,7 +1055,8 @@ struct LbsBwdNdcArgs {
     const int *colptr, *row;
     const int2 *vfirst;
     const float *cval, *sd;
-    float *d_A, *d_joints, *d_beta_frame, *d_beta_shared, *d_trans, *d_fov_img;
+    float *d_A, *d_joints, *d_beta_frame, *d_trans, *d_fov_img;
+    BetaSum beta;                               // shared betas: one row per workgroup (summed by the chain kernel's last block)
     int B, V, J, nS, nB_used, regress, trans_after, bone_slots;
 };
 
@@ -1270,7 +1323,7 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
         }
         __syncthreads();  // the next frame overwrites dvL, sA, sDJ
     }
-    if (a.d_beta_shared && tid < a.nB_used && beta_acc != 0.f) atomicAdd(&a.d_beta_shared[tid], beta_acc);
+    if (a.beta.rows && tid < a.nB_used) beta_row_store(a.beta, tid, beta_acc);  // (this workgroup's frames, added in launch order)
 }
 
 // out[c] = sum_b in[b][c]; grid ceil(C/64), block (64,4)
@@ -1351,17 +1404,16 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
     // widest block (the launch is one block's latency)
     const int few_frames = B < 64;
     const int nBu_all = g->d_beta ? in->nB_used : 0;
-    float *dbeta_frame_all = nullptr, *dbeta_shared_all = nullptr;
-    if (g->d_beta && nBu_all > 0) {
-        // shared betas: every frame adds its term to the one (nB,) gradient (float atomics, like the rasteriser's vertex
-        // gradients); per-frame betas: one row per frame
-        if (in->shared_beta) {
-            dbeta_shared_all = g->d_beta;
-            if (!g->accumulate_shared_beta) SMIL_HIP(hipMemsetAsync(g->d_beta, 0, (size_t)nBu_all * sizeof(float), stream));
-        } else {
-            dbeta_frame_all = g->d_beta;
-        }
-    }
+    float *dbeta_frame_all = nullptr;
+    // shared betas: every block of the kernels below leaves a partial row in g->beta_rows and the last block of the last kernel
+    // adds them in a fixed order (BetaSum: bit-reproducible); per-frame betas: one row per frame
+    const bool beta_shared = g->d_beta && nBu_all > 0 && in->shared_beta;
+    if (g->d_beta && nBu_all > 0 && !in->shared_beta) dbeta_frame_all = g->d_beta;
+    SMIL_REQUIRE(!beta_shared || g->beta_rows, "smil_lbs_backward: shared betas need the beta_rows scratch (2 B nB_used floats)");
+    BetaSum bsum;  // template: rows / all / n_all / ctr are set per kernel
+    bsum.rows = nullptr; bsum.all = g->beta_rows; bsum.n_all = 0; bsum.ctr = nullptr; bsum.out = g->d_beta;
+    bsum.accumulate = g->accumulate_shared_beta ? 1 : 0; bsum.n = nBu_all;
+    int rows_used = 0;
     const float *d_joints_up = up ? up->d_joints : g->d_joints;
     if (up) {
         LbsBwdNdcArgs a;
@@ -1371,7 +1423,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.skin_idx = m->skin_idx; a.skin_w = m->skin_w;
         a.bone_ptr = m->bone_ptr; a.bone_vid = m->bone_vid; a.bone_order = m->bone_order; a.bone_w = m->bone_w;
         a.colptr = m->jreg_colptr; a.row = m->jreg_row; a.cval = m->jreg_cval; a.sd = m->shapedirs; a.vfirst = m->jreg_vfirst;
-        a.d_A = g->d_A; a.d_joints = up->d_joints; a.d_beta_frame = dbeta_frame_all; a.d_beta_shared = dbeta_shared_all;
+        a.d_A = g->d_A; a.d_joints = up->d_joints; a.d_beta_frame = dbeta_frame_all;
         a.d_trans = g->d_trans; a.d_fov_img = up->d_fov_img;
         a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress; a.bone_slots = m->bone_slots;
         a.trans_after = in->trans_after_joints ? 1 : 0;
@@ -1379,6 +1431,8 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int cus = device_cu_count();
         const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
         const int grid = std::min(B, std::max(1, cus) * per_cu);
+        a.beta = bsum;
+        if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; }
         if (nBu_all <= 3) hipLaunchKernelGGL(k_lbs_bwd_ndc<3>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
         else if (nBu_all <= 6) hipLaunchKernelGGL(k_lbs_bwd_ndc<6>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
         else hipLaunchKernelGGL(k_lbs_bwd_ndc<NDC_BWD_MAX_BETAS>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
@@ -1419,7 +1473,11 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         // (the fused vertex pass leaves the shape gradient through the rest joints to this kernel)
         const bool js = up && !m->static_joints && nBu_all > 0;
         a.jreg_shape = js ? m->jreg_shape : nullptr;
-        a.d_beta_frame = js ? dbeta_frame_all : nullptr; a.d_beta_shared = js ? dbeta_shared_all : nullptr; a.nB_used = nBu_all;
+        a.d_beta_frame = js ? dbeta_frame_all : nullptr; a.nB_used = nBu_all;
+        a.beta = bsum;
+        const int chain_blocks = ceil_div(B, FRAMES_PER_BLOCK);
+        if (beta_shared && js) { a.beta.rows = g->beta_rows + (size_t)rows_used * nBu_all; rows_used += chain_blocks; }
+        if (beta_shared && up) { a.beta.n_all = rows_used; a.beta.ctr = m->sync_ctr; }  // (the fused route ends here: this kernel finishes the sum)
         a.d_posefeat = d_posefeat;
         a.d_Rs_up = g->up_Rs;
         a.parents = m->parents; a.depth = m->depth;
@@ -1442,12 +1500,14 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
     }
     if (!up && (g->d_beta || g->d_trans || g->d_del_v)) {
         const int nBu = nBu_all;
-        float *dbeta_frame = dbeta_frame_all, *dbeta_shared = dbeta_shared_all;
+        float *dbeta_frame = dbeta_frame_all;
+        BetaSum bshape = bsum;
+        if (beta_shared) { bshape.rows = g->beta_rows; bshape.n_all = B; bshape.ctr = m->sync_ctr; }  // (one row per frame; this kernel finishes the sum)
         const int shape_threads = few_frames ? 1024 : SHAPE_BWD_THREADS;
         const size_t lds = ((size_t)J * 18 + (shape_threads / WAVE) * SHAPE_TERMS) * sizeof(float);
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(shape_threads), lds, stream, g->d_verts, g->d_joints,
                            m->static_joints ? nullptr : g->d_Jrest, sv->A, m->skin_idx, m->skin_w, m->jreg_colptr,
-                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, dbeta_shared, g->d_trans, g->d_del_v, V, J, nBu, regress,
+                           m->jreg_row, m->jreg_cval, m->shapedirs, dbeta_frame, bshape, g->d_trans, g->d_del_v, V, J, nBu, regress,
                            in->trans_after_joints ? 1 : 0, g->up_v_shaped, nS);
         SMIL_LAUNCH_CHECK();
     }

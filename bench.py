@@ -257,12 +257,11 @@ def main():
     hook = (lambda block: optimize.allreduce_block(block, host_staged=staged)) if world > 1 else None
 
     def step():
-        hp = hn = None
-        if world > 1:  # temporal halo: each shard's first / last parameter row
+        halo = None
+        if world > 1:  # temporal halo: each shard's first / last parameter row, posted now and waited for in front of the epilogue kernel
             first, last = fitter.boundary_rows()
-            hp, hn = optimize.exchange_halos(first, last, rank, world, host_staged=staged)
-        return fitter.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=window, halo_prev=hp, halo_next=hn,
-                               shared_grad_hook=hook)
+            halo = optimize.post_halos(first, last, rank, world, host_staged=staged)
+        return fitter.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=window, halo=halo, shared_grad_hook=hook)
 
     for _ in range(args.warmup):
         step()

@@ -248,11 +248,13 @@ class SMALFitter(nn.Module):
     # the fused loss + gradient evaluation
     # ------------------------------------------------------------------------------------------
     def _loss_and_grads(self, frames: Optional[Sequence[int]], weights, w_temp: float, window: Optional[int] = None,
-                        halo_prev=None, halo_next=None):
+                        halo_prev=None, halo_next=None, halo=None):
         """Evaluate every loss term and the gradient of their sum for ``frames`` (None = all frames of this rank).
 
         Returns ``(objs (10,), grads)`` with full-size gradient tensors (zero rows outside ``frames``).
         ``window``: frames per loss window; None = the selected frames form one window (``forward`` semantics).
+        ``halo``: an ``optimize.PendingHalo`` instead of ``halo_prev`` / ``halo_next`` - waited for right before the epilogue kernel,
+        the only reader of the rows, so the messages travel while skinning and rasteriser run.
         """
         if self._targets_dirty or self._signature() != self._target_signature:
             self._refresh_targets()
@@ -376,6 +378,8 @@ class SMALFitter(nn.Module):
             d_pose = torch.empty(n, J, 3, dtype=torch.float32, device=dev)
             d_trans = torch.zeros(n, 3, dtype=torch.float32, device=dev)
             accumulate = False
+        if halo is not None:
+            halo_prev, halo_next = halo.wait()
         # priors + temporal terms + silhouette objective + fov reduction: one launch
         engine.fit_epilogue(fc, pose, trans, betas, self.mean_betas, self.betas_prec, mask, objs, d_pose, d_trans, d_betas,
                             halo_prev=halo_prev, halo_next=halo_next, accumulate=accumulate, loss_img=loss_img, pix_scale=pscale,
@@ -507,7 +511,7 @@ class SMALFitter(nn.Module):
             engine.adam_step_multi(items, h["betas"][0], h["betas"][1], h["eps"])
 
     def fit_step(self, weights, w_temp: float, window: Optional[int] = None, halo_prev=None, halo_next=None,
-                 shared_grad_hook=None):
+                 shared_grad_hook=None, halo=None):
         """One epoch over all frames of this rank: losses + gradients + Adam.  Returns objs (10,) (device).
 
         Several ranks: ``shared_grad_hook(block)`` receives the shared block - one contiguous tensor ``[10 loss terms | d_betas
@@ -515,7 +519,7 @@ class SMALFitter(nn.Module):
         (``optimize.allreduce_block``).  The per-frame parameters take their Adam step while that collective is in flight;
         the shared ones after ``handle.wait()``."""
         window = self.config.WINDOW_SIZE if window is None else window
-        objs, grads = self._loss_and_grads(None, weights, w_temp, window=window, halo_prev=halo_prev, halo_next=halo_next)
+        objs, grads = self._loss_and_grads(None, weights, w_temp, window=window, halo_prev=halo_prev, halo_next=halo_next, halo=halo)
         if shared_grad_hook is None:
             self.apply_adam(grads)
             return objs
@@ -565,8 +569,14 @@ class SMALFitter(nn.Module):
         g["graph"].replay()
         return g["objs"]
 
-    def _capture_step(self, weights, w_temp, window):
+    def _capture_step(self, weights, w_temp, window, ranks=None):
+        """Capture the iteration: one graph (single rank), or - ``ranks=(rank, world)`` - the losses + backward and the Adam update as
+        two graphs, the first reading the persistent halo buffers."""
         dev = self.device
+        halo_kw = {}
+        if ranks is not None:
+            halo_kw = dict(halo_prev=self._halo_buf[0] if ranks[0] > 0 else None,
+                           halo_next=self._halo_buf[1] if ranks[0] + 1 < ranks[1] else None)
         if not hasattr(self, "_adam_t"):
             self._adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
         h = self._adam_hyper
@@ -574,7 +584,7 @@ class SMALFitter(nn.Module):
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             # eager dry run (no parameter update): sizes the rasteriser workspace and tells which parameters get a gradient
-            _, grads = self._loss_and_grads(None, weights, w_temp, window=window)
+            _, grads = self._loss_and_grads(None, weights, w_temp, window=window, **halo_kw)
             for name, gr in grads.items():
                 if gr is not None and name not in self._adam:
                     p = self._param_tensor(name)
@@ -582,10 +592,7 @@ class SMALFitter(nn.Module):
         torch.cuda.current_stream(dev).wait_stream(side)
         self._adam_t.fill_(self._adam_step)
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._adam_t.add_(1)
-            objs, grads = self._loss_and_grads(None, weights, w_temp, window=window)
+        def adam_all(grads):
             for name, gr in grads.items():
                 if gr is None:
                     continue
@@ -593,9 +600,63 @@ class SMALFitter(nn.Module):
                 lr = h["fov_lr"] if name == "fov" else h["lr"]
                 engine.adam_step_dev(self._param_tensor(name), gr.contiguous(), st["m"], st["v"], lr, self._adam_t, st["t0"],
                                      h["betas"][0], h["betas"][1], h["eps"])
+
+        graph = torch.cuda.CUDAGraph()
+        graph_adam = shared_block = None
+        with torch.cuda.graph(graph):
+            self._adam_t.add_(1)
+            objs, grads = self._loss_and_grads(None, weights, w_temp, window=window, **halo_kw)
+            if ranks is None:
+                adam_all(grads)
+            else:
+                shared_block = self._shared_block  # summed over the ranks in place between the two graphs
+        if ranks is not None:
+            graph_adam = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_adam, pool=graph.pool()):
+                adam_all(grads)
         # keyed on the state AFTER the dry run, which may have (re)allocated the rasteriser workspace
-        self._graph = dict(key=self._graph_key(weights, w_temp, window), graph=graph, objs=objs, t_mirror=self._adam_step)
+        self._graph = dict(key=self._graph_key(weights, w_temp, window), graph=graph, objs=objs, t_mirror=self._adam_step,
+                           graph_adam=graph_adam, shared_block=shared_block, grads=grads)
         return self._graph
+
+    def fit_step_graph_ranks(self, weights, w_temp: float, window: Optional[int], rank: int, world: int, group, shared_grad_hook,
+                             host_staged: bool = False):
+        """``fit_step`` of one rank among several as TWO hipGraphs with the collective between them:
+        ``[losses + backward] | all-reduce of the shared block | [Adam of every parameter]``.  The temporal-halo rows are received
+        straight into two persistent device buffers the first graph reads (posted before the replay, waited for in front of it:
+        a graph cannot wait in its middle - the eager ``fit_step`` can, and does).  Identical results to the eager step."""
+        from . import optimize  # (local: optimize imports nothing from here)
+
+        window = self.config.WINDOW_SIZE if window is None else window
+        if self._targets_dirty or self._signature() != self._target_signature:
+            self._refresh_targets()
+        self._mask_table()
+        dev = self.device
+        if not hasattr(self, "_halo_buf"):
+            n_row = self._pose.shape[1] * 3 + 3
+            self._halo_buf = (torch.zeros(n_row, device=dev), torch.zeros(n_row, device=dev))
+        first, last = self.boundary_rows()
+        pending = optimize.post_halos(first, last, rank, world, group, host_staged=host_staged,
+                                      recv_prev=self._halo_buf[0], recv_next=self._halo_buf[1])
+        prev_row, next_row = pending.wait()
+        for buf, row in zip(self._halo_buf, (prev_row, next_row)):  # (host-staged rehearsals arrive in fresh tensors)
+            if row is not None and row.data_ptr() != buf.data_ptr():
+                buf.copy_(row)
+        key = ("ranks", rank, world) + self._graph_key(weights, w_temp, window)
+        g = getattr(self, "_graph", None)
+        if g is None or g["key"] != key:
+            g = self._capture_step(weights, w_temp, window, ranks=(rank, world))
+            g["key"] = ("ranks", rank, world) + g["key"]
+        if g["t_mirror"] != self._adam_step:
+            self._adam_t.fill_(self._adam_step)
+        self._adam_step += 1
+        g["t_mirror"] = self._adam_step
+        g["graph"].replay()
+        handle = shared_grad_hook(g["shared_block"]) if shared_grad_hook is not None else None
+        if handle is not None:
+            handle.wait()
+        g["graph_adam"].replay()
+        return g["objs"]
 
     def straddling_faces(self) -> int:
         """Faces of the most recent silhouette launch with one or two vertices nearer than ``z_clip = znear / 2``.  They are cut

@@ -58,28 +58,51 @@ def plan_shards(n_total: int, world: int, window: int) -> List[ShardPlan]:
     return plans
 
 
-def exchange_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None,
-                   host_staged: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+class PendingHalo:
+    """Temporal-halo rows on their way: ``wait()`` returns (row before my first frame, row after my last frame) on the device.
+    Posting (``post_halos``) and waiting are separate so that the skinning and rasteriser kernels of an iteration run while the
+    two tiny messages are in flight - only ``fit_epilogue`` (the temporal terms) reads the rows."""
+
+    def __init__(self, reqs, prev_row, next_row, dev, keep=()):
+        self._reqs, self._prev, self._next, self._dev, self._keep = reqs, prev_row, next_row, dev, keep
+        self._done = None
+
+    def wait(self):
+        if self._done is None:
+            for req in self._reqs:
+                req.wait()  # (RCCL: orders the current stream behind the receive; gloo: blocks the host)
+            back = lambda t: None if t is None else t.to(self._dev)  # noqa: E731
+            self._done = (back(self._prev), back(self._next))
+            self._reqs = self._keep = ()
+        return self._done
+
+
+def post_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None, host_staged: bool = False,
+               recv_prev: Optional[torch.Tensor] = None, recv_next: Optional[torch.Tensor] = None) -> PendingHalo:
     """Temporal halo: every shard sends its first parameter row to the rank before it and its last row to
-    the rank after it - point-to-point, one batch of non-blocking sends / receives per rank; returns (row before my first
-    frame, row after my last frame).  ``host_staged`` moves the rows through host memory (gloo rehearsals); RCCL runs keep
-    them on the device."""
-    if world == 1:
-        return None, None
+    the rank after it - point to point, one batch of non-blocking sends / receives per rank, returned as a ``PendingHalo``.
+    ``host_staged`` moves the rows through host memory (gloo rehearsals); RCCL runs keep them on the device.  ``recv_prev`` /
+    ``recv_next``: receive straight into these (persistent) device buffers - what a captured iteration reads."""
     dev = first_row.device
+    if world == 1:
+        return PendingHalo((), None, None, dev)
     stage = (lambda t: t.detach().cpu().contiguous()) if host_staged else (lambda t: t.detach().contiguous())
     first, last = stage(first_row), stage(last_row)
-    prev_row = torch.empty_like(first) if rank > 0 else None
-    next_row = torch.empty_like(first) if rank + 1 < world else None
+    into = lambda buf: torch.empty_like(first) if (buf is None or host_staged) else buf  # noqa: E731
+    prev_row = into(recv_prev) if rank > 0 else None
+    next_row = into(recv_next) if rank + 1 < world else None
     ops = []
     if rank > 0:
         ops += [dist.P2POp(dist.isend, first, rank - 1, group), dist.P2POp(dist.irecv, prev_row, rank - 1, group)]
     if rank + 1 < world:
         ops += [dist.P2POp(dist.isend, last, rank + 1, group), dist.P2POp(dist.irecv, next_row, rank + 1, group)]
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    back = lambda t: None if t is None else t.to(dev)  # noqa: E731
-    return back(prev_row), back(next_row)
+    return PendingHalo(dist.batch_isend_irecv(ops), prev_row, next_row, dev, keep=(first, last))
+
+
+def exchange_halos(first_row: torch.Tensor, last_row: torch.Tensor, rank: int, world: int, group=None,
+                   host_staged: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """``post_halos`` + ``wait()``: returns (row before my first frame, row after my last frame)."""
+    return post_halos(first_row, last_row, rank, world, group, host_staged).wait()
 
 
 class _Done:
@@ -151,19 +174,22 @@ def configure_stage(fitter, stage_id: int, full_visibility: torch.Tensor) -> Non
 
 def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, world: int = 1, group=None,
              on_epoch: Optional[Callable[[int, int, torch.Tensor], None]] = None, max_epochs: Optional[int] = None,
-             use_graph: bool = True):
+             use_graph: bool = True, host_staged: bool = False):
     """Run the staged optimisation on this rank's shard; returns the per-epoch loss terms of the last stage.
 
     Single rank: every stage captures its iteration (losses, backward, Adam) once in a hipGraph and replays it per epoch
     (``SMALFitter.fit_step_graph``) - the device-side schedule of SURVEY.md 8(f) row 4; ``use_graph=False`` launches
-    the kernels one by one instead (identical results).  Several ranks: the eager step, because the shared-parameter
-    gradients pass through the RCCL all-reduce between backward and the optimiser step of the shared parameters."""
+    the kernels one by one instead (identical results).  Several ranks: the shared-parameter gradients pass through the all-reduce
+    between backward and the optimiser step, so the iteration is TWO graphs with the collective between them
+    (``SMALFitter.fit_step_graph_ranks``: losses + backward | all-reduce | Adam); ``use_graph=False`` is the eager step, which posts
+    the temporal halo first and waits for it only in front of the kernel that reads it.  ``host_staged``: collectives through host
+    memory (gloo rehearsals)."""
     cfg = fitter.config
     stages = stages or stages_from_config(cfg)
     full_vis = fitter.target_visibility.clone()
     hook = None
     if world > 1:
-        hook = lambda block: allreduce_block(block, group)  # noqa: E731
+        hook = lambda block: allreduce_block(block, group, host_staged)  # noqa: E731
     graph = use_graph and world == 1
     history = []
     for stage_id, st in enumerate(stages):
@@ -174,13 +200,15 @@ def optimize(fitter, stages: Optional[List[StageSpec]] = None, rank: int = 0, wo
         for epoch in range(epochs):
             if graph:
                 objs = fitter.fit_step_graph(st.weights, st.w_temp, window=cfg.WINDOW_SIZE).clone()
+            elif use_graph:  # several ranks: the iteration as two graphs around the collective
+                objs = fitter.fit_step_graph_ranks(st.weights, st.w_temp, cfg.WINDOW_SIZE, rank, world, group, hook,
+                                                   host_staged=host_staged).clone()
             else:
-                halo_prev = halo_next = None
-                if world > 1:
+                halo = None
+                if world > 1:  # posted now, waited for right before the one kernel that reads the rows
                     first, last = fitter.boundary_rows()
-                    halo_prev, halo_next = exchange_halos(first, last, rank, world, group)
-                objs = fitter.fit_step(st.weights, st.w_temp, window=cfg.WINDOW_SIZE, halo_prev=halo_prev, halo_next=halo_next,
-                                       shared_grad_hook=hook)
+                    halo = post_halos(first, last, rank, world, group, host_staged=host_staged)
+                objs = fitter.fit_step(st.weights, st.w_temp, window=cfg.WINDOW_SIZE, halo=halo, shared_grad_hook=hook)
             history.append(objs)
             if on_epoch is not None:
                 on_epoch(stage_id, epoch, objs)

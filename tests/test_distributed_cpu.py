@@ -50,7 +50,13 @@ def _worker(rank, world, port, n_total, window, out_dir):
     g = torch.Generator().manual_seed(0)
     rows_all = torch.randn(n_total, E, generator=g)  # every rank can regenerate the whole sequence
     mine = rows_all[plan.start:plan.stop]
-    prev_row, next_row = optimize.exchange_halos(mine[0].clone(), mine[-1].clone(), rank, world)
+    pending = optimize.post_halos(mine[0].clone(), mine[-1].clone(), rank, world)  # posted first ...
+    work_meanwhile = (mine * 2).sum()  # (stands for the skinning / rasteriser kernels that run while the rows travel)
+    prev_row, next_row = pending.wait()  # ... waited for in front of the one consumer
+    assert pending.wait() == (prev_row, next_row) and torch.isfinite(work_meanwhile)
+    again = optimize.exchange_halos(mine[0].clone(), mine[-1].clone(), rank, world)  # (the blocking form: same rows)
+    for a_, b_ in zip(again, (prev_row, next_row)):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
     if plan.start > 0:
         assert torch.equal(prev_row, rows_all[plan.start - 1])
     else:

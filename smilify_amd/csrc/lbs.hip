@@ -705,13 +705,15 @@ __device__ __forceinline__ void beta_sum_finish(const BetaSum &q, float *red) {
     if (!q.ctr) return;  // (uniform)
     __shared__ unsigned int s_last;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();  // this block's rows are visible device-wide before it counts as done
-        s_last = atomicAdd(q.ctr, 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (gridDim.x > 1u) {  // (a single block - a handful of frames - is its own last block: no fences, no counter)
+        if (threadIdx.x == 0) {
+            __threadfence();  // this block's rows are visible device-wide before it counts as done
+            s_last = atomicAdd(q.ctr, 1u) == gridDim.x - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_last) return;  // (uniform)
+        __threadfence();
     }
-    __syncthreads();
-    if (!s_last) return;  // (uniform)
-    __threadfence();
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE, nw = (blockDim.x + WAVE - 1) / WAVE;
     for (int k = 0; k < q.n; ++k) {
         float r = 0.f;
@@ -727,7 +729,7 @@ __device__ __forceinline__ void beta_sum_finish(const BetaSum &q, float *red) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *q.ctr = 0u;  // ready for the next call (stream order)
+    if (threadIdx.x == 0 && gridDim.x > 1u) *q.ctr = 0u;  // ready for the next call (stream order)
 }
 
 struct ChainBwdArgs {

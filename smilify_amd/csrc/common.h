@@ -135,6 +135,9 @@ __device__ __forceinline__ float swap16_add(float a, float b) {  // rows 0, 2: a
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libsmilfit is written for gfx950 (MI355X) only: v_permlane32_swap / v_permlane16_swap and the tile kernel's LDS and register budgets have no other target"
+#endif
 __device__ __forceinline__ void wave_sum12(const float (&v)[12], float (&q)[3]) {
     float h[6];
 #pragma unroll

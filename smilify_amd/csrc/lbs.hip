@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include <mutex>
 
 #define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels
 
@@ -503,18 +504,30 @@ __global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_proje
 
 #define FWD_REG_LDS_MAX 4096  // regressor non-zeros staged in LDS (32 KB)
 static int fwd_fused_nnz_lds(const SmilModel *m) { return (!m->static_joints && m->jreg_nnz <= FWD_REG_LDS_MAX) ? m->jreg_nnz : 0; }
-// CUs of the current device (the grids of the per-frame persistent kernels); 0 if the query fails
-static int device_cu_count() {
-    static int cached_dev = -1, cached = 0;
+// CUs and LDS of the current device, asked once per device (the grids of the per-frame persistent kernels; what a workgroup may
+// take of the CU's LDS).  Thread-safe: one mutex-guarded table.
+struct DeviceLimits { int cus; size_t lds_block, lds_cu; };
+static DeviceLimits device_limits() {
+    static std::mutex mu;
+    static DeviceLimits table[16];
+    static bool known[16] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (dev != cached_dev) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        cached = cus; cached_dev = dev;
+    DeviceLimits q = {0, 64 * 1024, 64 * 1024};
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return q;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[dev]) {
+        int cus = 0, lds = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) q.cus = cus;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && lds > 0) q.lds_block = (size_t)lds;
+        q.lds_cu = q.lds_block;  // (MI355X: a workgroup may take all 160 KB of its CU)
+        table[dev] = q;
+        known[dev] = true;
     }
-    return cached;
+    return table[dev];
 }
+static int device_cu_count() { return device_limits().cus; }
+// LDS a fused per-frame kernel may ask for so that TWO workgroups fit a CU: meshes beyond it take the separate kernels
+static size_t fused_lds_limit() { return device_limits().lds_cu / 2; }
 
 static size_t fwd_fused_lds_bytes(const SmilModel *m, int views) {
     return ((size_t)3 * m->V + 4 + 12 * m->J + 16 * views + m->J + 1 + 2 * fwd_fused_nnz_lds(m)) * sizeof(float);
@@ -589,7 +602,7 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
         nS_skin = B;
     }
     const float *trans_after = (in->trans_after_joints && in->trans) ? in->trans : nullptr;
-    if (cam && cam->views <= FWD_FUSED_MAX_VIEWS && fwd_fused_lds_bytes(m, cam->views) <= 80 * 1024) {
+    if (cam && cam->views <= FWD_FUSED_MAX_VIEWS && fwd_fused_lds_bytes(m, cam->views) <= fused_lds_limit()) {
         // skinning, joint regression and both projections in one kernel per frame (the frame's vertices stay in LDS)
         SkinProjectArgs a;
         a.cam = *cam;
@@ -601,7 +614,7 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
         a.nnz_lds = fwd_fused_nnz_lds(m);
         const size_t lds = fwd_fused_lds_bytes(m, cam->views);
         const int cus = device_cu_count();
-        const int per_cu = std::max(1, std::min(FWD_MIN_WAVES / 2, (int)((160 * 1024) / lds)));
+        const int per_cu = std::max(1, std::min(FWD_MIN_WAVES / 2, (int)(device_limits().lds_cu / lds)));
         hipLaunchKernelGGL(k_skin_project_fwd, dim3(std::min(B, std::max(1, cus) * per_cu)), dim3(FWD_FUSED_THREADS), lds, stream, a);
         SMIL_LAUNCH_CHECK();
         return SMIL_OK;
@@ -1359,7 +1372,7 @@ static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views) {
 
 extern "C" int smil_lbs_backward_ndc_supported(const SmilModel *m, int32_t nB_used, int32_t views) {
     return m && !m->posedirs && nB_used >= 0 && nB_used <= NDC_BWD_MAX_BETAS && views >= 1 && views <= NDC_BWD_MAX_VIEWS &&
-           ndc_bwd_lds_bytes(m, views) <= 80 * 1024;  // (two workgroups per CU)
+           ndc_bwd_lds_bytes(m, views) <= fused_lds_limit();  // (two workgroups per CU)
 }
 
 static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv, const SmilLbsGrads *g,
@@ -1431,7 +1444,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.trans_after = in->trans_after_joints ? 1 : 0;
         const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views);
         const int cus = device_cu_count();
-        const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+        const int per_cu = std::max(1, std::min(2, (int)(device_limits().lds_cu / lds)));
         const int grid = std::min(B, std::max(1, cus) * per_cu);
         a.beta = bsum;
         if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; }

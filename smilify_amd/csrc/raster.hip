@@ -143,9 +143,9 @@ struct TriIds { int a, b, c; };
 // vertex's coordinates / gradient row goes through one compare that picks the table.  A new vertex is
 // c_a xy[a] + c_b xy[b] of the cut edge's end points (interpolated in view space); its gradient goes back to them with the
 // coefficients held constant (k_clip_backward).  Faces beyond the tables' capacity are rendered as before and counted.
-#define CLIP_FX 512   // front-part triangles per image
-#define CLIP_VX 1024  // new vertices per image (two per cut face)
-#define CLIP_CUTS (CLIP_FX / 2)  // cut faces per image: each owns two face and two vertex slots
+#define CLIP_CUTS 256            // cut faces per image (ONE capacity: each owns two front-part triangle slots and two new-vertex slots)
+#define CLIP_FX (2 * CLIP_CUTS)  // front-part triangles per image
+#define CLIP_VX (2 * CLIP_CUTS)  // new vertices per image
 struct ClipTables {
     float *xv;          // (N, CLIP_VX, 3) new vertices (x_ndc, y_ndc, z_clip)
     int *xf;            // (N, CLIP_FX, 3) vertex ids of the front-part triangles (>= V: new vertices)

@@ -47,6 +47,7 @@ def require_gpu(device) -> torch.device:
 
 
 _SHARED_WS: Dict = {}  # (device type, index) -> the device's rasteriser workspace
+_WS_USER: Dict = {}    # (device type, index) -> (model, stream) of the most recent rasteriser call in that workspace
 
 
 class DeviceModel:
@@ -102,19 +103,34 @@ class DeviceModel:
             self._faces_dev = torch.from_numpy(np.ascontiguousarray(self.tables.faces, np.int32)).to(self.device)
         return self._faces_dev
 
+    def _ws_key(self):
+        return (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+
     def workspace(self, N: int, S: int) -> torch.Tensor:
         """Rasteriser workspace: ONE buffer per device, shared by every model and topology on it (most of it is the scratch
-        arena of the resident workgroups, 6.6 GB whatever the mesh), grown when a call needs more.  Calls are stream ordered and
-        every call rewrites what it reads, so models may take turns; a captured hipGraph keeps the tensor it was captured with
-        alive through ``_ws``."""
+        arena of the resident workgroups, whatever the mesh), grown when a call needs more; every model then points at the
+        grown buffer (a captured hipGraph holds the tensor it was captured with itself, ``SMALFitter._capture_step``).
+        Every call rewrites what it reads, so models may take turns - in STREAM ORDER: a call on another stream than the
+        previous one first waits for everything submitted to that stream (``_claim_workspace``)."""
         need = int(_lib.load().smil_raster_workspace_bytes(self.handle, N, S))
-        key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+        key = self._ws_key()
         ws = _SHARED_WS.get(key)
         if ws is None or ws.numel() < need:
             ws = _SHARED_WS[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = ws
-        return self._ws
+        self._ws = ws
+        return ws
+
+    def _claim_workspace(self, n_last_slice: int) -> None:
+        """Book-keeping of a rasteriser call about to be launched: order it behind the previous user of the shared workspace when that
+        one ran on another stream, and remember who used the workspace last and with which slice size (``raster_stats`` reads the
+        counters at an offset that depends on it)."""
+        key = self._ws_key()
+        cur = torch.cuda.current_stream(self.device)
+        prev = _WS_USER.get(key)
+        if prev is not None and prev[1] != cur and not torch.cuda.is_current_stream_capturing():
+            cur.wait_stream(prev[1])
+        _WS_USER[key] = (self, cur)
+        self._last_launch = n_last_slice
 
 
 @dataclass
@@ -393,10 +409,15 @@ def _slices(N: int, step: int = MAX_IMAGES_PER_LAUNCH):
 
 
 def raster_stats(model: DeviceModel, N: int) -> dict:
-    """Counters of the last rasteriser call of ``model`` on ``N`` images (of its last slice when the batch was cut): faces
-    straddling z_clip (rendered whole; the reference would clip them) and touched tiles.  Synchronises."""
-    step = model.__dict__.get("_last_slice", MAX_IMAGES_PER_LAUNCH)
-    last = N - ((N - 1) // step) * step
+    """Counters of the most recent rasteriser call of ``model`` (of its last slice when the batch was cut into several launches):
+    faces straddling z_clip, touched tiles, faces beyond the clip tables.  ``N`` is ignored (kept for callers of round 3): the slice
+    size is recorded at launch time.  Zeros when the model has not rasterised since the workspace was last used by another model.
+    Synchronises."""
+    zero = {"straddling_faces": 0, "tiles": 0, "unclipped_faces": 0}
+    user = _WS_USER.get(model._ws_key())
+    last = model.__dict__.get("_last_launch")
+    if model._ws is None or last is None or user is None or user[0] is not model:
+        return zero  # this model has not rasterised, or another model / topology has used the shared workspace since
     out = (ctypes.c_uint32 * 4)()
     _lib.check(_lib.load().smil_raster_stats(model.handle, last, _ptr(model._ws), _stream(), out), "smil_raster_stats")
     return {"straddling_faces": int(out[0]), "tiles": int(out[1]), "unclipped_faces": int(out[2])}
@@ -408,6 +429,7 @@ def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=N
     sil = torch.empty(N, S, S, dtype=torch.float32, device=verts_ndc.device)
     step = model._last_slice = _slice_images(model, N, S)
     ws = model.workspace(step, S)
+    model._claim_workspace(N - ((N - 1) // step) * step)
     for n0, n1 in _slices(N, step):
         _lib.check(_lib.load().smil_silhouette_forward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
                                                        _ptr(sil[n0:n1]), _ptr(ws), _stream()), "smil_silhouette_forward")
@@ -420,6 +442,7 @@ def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, gra
     d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=verts_ndc.device)
     step = model._last_slice = _slice_images(model, N, S)
     ws = model.workspace(step, S)
+    model._claim_workspace(N - ((N - 1) // step) * step)
     for n0, n1 in _slices(N, step):
         _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
                                                         _ptr(grad_sil[n0:n1]), _ptr(d_ndc[n0:n1]), _ptr(ws), _stream()),
@@ -443,6 +466,7 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
     scale = torch.empty(N, dtype=torch.float32, device=dev) if packed_out else None
     step = model._last_slice = _slice_images(model, N, S)
     ws = model.workspace(step, S)
+    model._claim_workspace(N - ((N - 1) // step) * step)
     if target.dtype not in (torch.float32, torch.uint8):
         raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
     for n0, n1 in _slices(N, step):

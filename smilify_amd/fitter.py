@@ -616,7 +616,8 @@ class SMALFitter(nn.Module):
                 adam_all(grads)
         # keyed on the state AFTER the dry run, which may have (re)allocated the rasteriser workspace
         self._graph = dict(key=self._graph_key(weights, w_temp, window), graph=graph, objs=objs, t_mirror=self._adam_step,
-                           graph_adam=graph_adam, shared_block=shared_block, grads=grads)
+                           graph_adam=graph_adam, shared_block=shared_block, grads=grads,
+                           ws=self.device_model._ws)  # (the graph's kernels hold raw pointers into this workspace tensor)
         return self._graph
 
     def fit_step_graph_ranks(self, weights, w_temp: float, window: Optional[int], rank: int, world: int, group, shared_grad_hook,
@@ -662,7 +663,7 @@ class SMALFitter(nn.Module):
         """Faces of the most recent silhouette launch with one or two vertices nearer than ``z_clip = znear / 2``.  They are cut
         at the plane like pytorch3d's ``clip_faces`` does (left on by the reference's settings, p3d_renderer.py:36-47): the
         part in front is rendered.  A non-zero count still deserves a look - the mesh has reached the camera - so the first
-        one warns; faces beyond the per-image clip tables (512 front-part triangles, 256 cut faces per image) are rendered unclipped and always
+        one warns; faces beyond the per-image clip tables (256 cut faces per image) are rendered unclipped and always
         reported.  Synchronises the stream (call it between stages, not per iteration)."""
         if self.device_model._ws is None:
             return 0

@@ -123,3 +123,43 @@ def test_two_ranks_run_the_staged_trajectory_of_one_rank(mode, tmp_path):
         np.testing.assert_allclose(two["fov"][r], one["fov"][0], **tol)
         np.testing.assert_allclose(two["objs"][r], one["objs"][0], rtol=2e-4, atol=1e-5)
     assert np.array_equal(two["betas"][0], two["betas"][1]) and np.array_equal(two["fov"][0], two["fov"][1])
+
+
+def test_gradient_of_a_cut_face_by_finite_differences(tables):
+    """A face that crosses z_clip is rendered as its front part, whose new vertices are ``c_a xy_a + c_b xy_b`` of the cut edge's end
+    points with coefficients that depend on the depths only (pytorch3d clip_faces; reference settings p3d_renderer.py:36-47).  Moving
+    an end point in x or y therefore moves the new vertex linearly, and the analytic vertex gradient - new vertices handing theirs
+    back through k_clip_backward - must agree with central finite differences of the rendered silhouette (round-3 advice: the clip
+    fuzz compared forward passes only).  Scene: the posed synthetic mesh at a distance (a silhouette with a soft rim, not a filled
+    image), three of its vertices pulled through the clipping plane."""
+    from smilify_amd import engine as eng
+    from oracle import render_ref
+    from test_gpu_edge_cases import _scene
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 48
+    ndc = _scene(t, 1, S, 2.5, 3).clone()
+    pulled = [5, 40, 77]
+    # nearer than z_clip = 5e-4 but in front of the camera: the coefficients stay O(1) (behind the camera they reach hundreds and a
+    # finite step on an end point moves the new vertex by many blur radii)
+    ndc[0, pulled, 2] = torch.tensor([2e-4, 1e-5, 4e-4])
+    _, _, src, _ = render_ref.clip_faces_np(ndc[0].numpy(), t.faces, 5e-4)
+    ends = sorted({int(v) for ab in src for v in ab if ndc[0, int(v), 2] >= 5e-4})  # the cut edges' end points in front of the plane
+    assert len(src) >= 4 and ends
+    gs = torch.from_numpy(np.cos(0.3 * np.arange(S * S)).astype(np.float32).reshape(1, S, S)).to(DEV)
+    grad = eng.silhouette_backward(dm, ndc.to(DEV), S, gs).cpu().numpy()[0]
+    assert eng.raster_stats(dm, 1)["straddling_faces"] > 0
+    loss = lambda x: float((eng.silhouette_forward(dm, x.to(DEV), S).double() * gs.double()).sum())  # noqa: E731
+    eps, checked = 2e-4, 0
+    for v in ends:
+        for c in (0, 1):
+            if abs(grad[v, c]) < 0.05 * np.abs(grad).max():
+                continue  # (too flat for a difference of two fp32 renders to say anything)
+            hi, lo = ndc.clone(), ndc.clone()
+            hi[0, v, c] += eps
+            lo[0, v, c] -= eps
+            fd = (loss(hi) - loss(lo)) / (2 * eps)
+            assert abs(fd - grad[v, c]) <= 0.06 * abs(grad[v, c]) + 0.02 * np.abs(grad).max(), (v, c, fd, grad[v, c])
+            checked += 1
+    assert checked >= 3, (checked, np.abs(grad).max())

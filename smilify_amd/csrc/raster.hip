@@ -860,7 +860,13 @@ __device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t
 // centres inside [lo, hi] are ceil(v_lo) .. floor(v_hi) with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding
 // (a superset; eval_pair applies the exact test).
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
-__device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__restrict__ vn, const float *__restrict__ xv_n, int i0, int i1, int i2, int m,
+struct Tri9 { float x0, y0, z0, x1, y1, z1, x2, y2, z2; };
+// the nine vertex floats of a lane's face (both lanes of a face load the same: one transaction), through the clip tables
+__device__ __forceinline__ Tri9 load_tri(const RasterArgs &a, const float *__restrict__ vn, const float *__restrict__ xv_n, int i0, int i1, int i2) {
+    const float *p0 = vertex_ptr(vn, xv_n, a.V, i0), *p1 = vertex_ptr(vn, xv_n, a.V, i1), *p2 = vertex_ptr(vn, xv_n, a.V, i2);
+    return Tri9{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2]};
+}
+__device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
                                             int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2, float2 *__restrict__ sxy,
                                             TriIds *__restrict__ sid, int c0, int list_stride) {
@@ -868,10 +874,9 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const float *__
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
     if (slot < m) {
-        const float *p0 = vertex_ptr(vn, xv_n, a.V, i0), *p1 = vertex_ptr(vn, xv_n, a.V, i1), *p2 = vertex_ptr(vn, xv_n, a.V, i2);
-        const float x0 = p0[0], y0 = p0[1], z0 = p0[2];
-        const float x1 = p1[0], y1 = p1[1], z1 = p1[2];
-        const float x2 = p2[0], y2 = p2[1], z2 = p2[2];
+        const float x0 = tv.x0, y0 = tv.y0, z0 = tv.z0;
+        const float x1 = tv.x1, y1 = tv.y1, z1 = tv.z1;
+        const float x2 = tv.x2, y2 = tv.y2, z2 = tv.z2;
         float4 *r = reinterpret_cast<float4 *>(rec + slot * FSTR);
         // The tile's vertex table for pass 3: three arrays of float2 (v0, v1, v2 by list position) and the vertex ids, so that every
         // store instruction writes whole runs of bytes (one 24-byte structure per face, stored as 16 + 8 bytes, cost 0.45 ms per
@@ -1251,9 +1256,15 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             // flight (four registers), so a chunk starts with one memory round trip instead of three.
             const int slot_ = lane & (DCHUNK - 1);
             auto list_at = [&](int c) { return (int)lst[min(c + slot_, list_total - 1)]; };
-            int f_nx = list_at(DCHUNK);
-            int ia, ib, ic;
-            { const int f_ = list_at(0); ia = face_vertex(a.faces, xf_n, a.F, f_, 0); ib = face_vertex(a.faces, xf_n, a.F, f_, 1); ic = face_vertex(a.faces, xf_n, a.F, f_, 2); }
+            // (round 4: one more link ahead - the VERTICES of chunk k + 1 are requested before chunk k is evaluated and wait in nine
+            // registers, so a chunk starts with the drain of the previous sweep's stores only, not with a vertex fetch behind it)
+            int f_nx = list_at(2 * DCHUNK);
+            int ia, ib, ic;      // vertex ids of chunk k + 1 ...
+            int ja, jb, jc;      // ... and of chunk k
+            Tri9 tv_nx;          // vertices of chunk k (requested one chunk ahead)
+            { const int f_ = list_at(0); ja = face_vertex(a.faces, xf_n, a.F, f_, 0); jb = face_vertex(a.faces, xf_n, a.F, f_, 1); jc = face_vertex(a.faces, xf_n, a.F, f_, 2); }
+            { const int f_ = list_at(DCHUNK); ia = face_vertex(a.faces, xf_n, a.F, f_, 0); ib = face_vertex(a.faces, xf_n, a.F, f_, 1); ic = face_vertex(a.faces, xf_n, a.F, f_, 2); }
+            tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);
             for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
                 if (may_truncate) {
                     // digit of this chunk's first face = number of buckets that start at or before it, minus one
@@ -1276,10 +1287,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 }
                 const int m = min(DCHUNK, list_total - c0);
                 int cf, packed2, packed = 0;
-                const int i0 = ia, i1 = ib, i2 = ic;
-                ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + DCHUNK
-                f_nx = list_at(c0 + 2 * DCHUNK);
-                stage_faces(a, vn, xv_n, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy, sid, c0, a.list_stride);
+                const int i0 = ja, i1 = jb, i2 = jc;
+                const Tri9 tv = tv_nx;                       // this chunk's vertices (in flight since the chunk before)
+                ja = ia; jb = ib; jc = ic;
+                tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);  // chunk c0 + DCHUNK
+                ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + 2 DCHUNK
+                f_nx = list_at(c0 + 3 * DCHUNK);
+                stage_faces(a, tv, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy, sid, c0, a.list_stride);
                 set_chunk_start(c0 / DCHUNK, (uint32_t)vbase);
                 chunks_done = c0 / DCHUNK + 1;
                 lds_fence();

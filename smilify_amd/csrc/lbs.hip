@@ -387,8 +387,9 @@ __global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_proje
     extern __shared__ float smem[];
     const int V = a.V, J = a.J, views = a.cam.views;
     constexpr int NT = FWD_FUSED_THREADS, NW = NT / WAVE;
-    float *vL = smem;                              // (V,3) posed vertices of the frame
-    float *sA = smem + ((3 * V + 3) & ~3);         // (J,12)
+    float *vL = smem;                              // (V,3) posed vertices of the frame: what the joint regressor gathers from (models with
+                                                   // static joints keep none: any mesh size fits - round 4, the mouse)
+    float *sA = smem + (((a.regress ? 3 * V : 0) + 3) & ~3);  // (J,12)
     float *sCam = sA + 12 * J;                     // (views,16)
     // the joint regressor (CSR) is staged once per workgroup when it fits: a joint is then LDS reads only (from memory every joint
     // is a chain of two round trips, seven joints deep per wave - measured: 126 -> see profiles/r3_small_kernels.md)
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_proje
                 float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
                 float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
                 if (a.trans) { ox += tx; oy += ty; oz += tz; }
-                vL[3 * v] = ox; vL[3 * v + 1] = oy; vL[3 * v + 2] = oz;
+                if (a.regress) { vL[3 * v] = ox; vL[3 * v + 1] = oy; vL[3 * v + 2] = oz; }
                 float *o = a.verts + ((size_t)b * V + v) * 3;
                 o[0] = ox; o[1] = oy; o[2] = oz;
                 if (a.ndc)
@@ -530,7 +531,7 @@ static int device_cu_count() { return device_limits().cus; }
 static size_t fused_lds_limit() { return device_limits().lds_cu / 2; }
 
 static size_t fwd_fused_lds_bytes(const SmilModel *m, int views) {
-    return ((size_t)3 * m->V + 4 + 12 * m->J + 16 * views + m->J + 1 + 2 * fwd_fused_nnz_lds(m)) * sizeof(float);
+    return ((size_t)(m->static_joints ? 0 : 3 * m->V) + 4 + 12 * m->J + 16 * views + m->J + 1 + 2 * fwd_fused_nnz_lds(m)) * sizeof(float);
 }
 
 static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, const SmilCameras *cam, float *ndc,
@@ -1097,14 +1098,18 @@ __device__ __forceinline__ void project_point_bwd(const float *cp /* 15 floats: 
 #define NDC_UNR2 2   // phase 2 (seven + three per shape coefficient)
 
 // NBT: shape coefficients held in registers per vertex (3, 6 or 9: the smallest that covers nB_used).
-template <int NBT>
-__global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_ndc(LbsBwdNdcArgs a) {
+// VPL: the vertices the skinning transforms were applied to are staged in LDS next to the frame's vertex gradient (24 bytes per vertex:
+// two workgroups of NT = 512 threads per CU hold meshes up to ~3 300 vertices).  Larger meshes (round 4: the mouse, V = 11 263) keep only
+// the gradient in LDS - 12 bytes per vertex, ONE workgroup of NT = 1024 threads per CU with up to the CU's whole 160 KB - and phase 3
+// gathers those vertices from memory (L2: one set for all frames when the betas are shared), requested one list segment ahead.
+template <int NBT, bool VPL, int NT>
+__global__ void __launch_bounds__(NT, NDC_BWD_MIN_WAVES) k_lbs_bwd_ndc(LbsBwdNdcArgs a) {
     extern __shared__ float smem[];
     const int V = a.V, J = a.J, views = a.cam.views;
-    constexpr int NT = NDC_BWD_THREADS, NW = NT / WAVE;
+    constexpr int NW = NT / WAVE;
     float *dvL = smem;                  // (V,3) the frame's vertex gradient
-    float *vpL = dvL + 3 * V;           // (V,3) the vertices the skinning transforms were applied to (v_shaped / v_posed)
-    float *sA = smem + ((6 * V + 3) & ~3);  // (J,12), 16-byte aligned
+    float *vpL = dvL + 3 * V;           // (V,3) the vertices the skinning transforms were applied to (v_shaped / v_posed)   [VPL]
+    float *sA = smem + (((VPL ? 6 : 3) * V + 3) & ~3);  // (J,12), 16-byte aligned
     float *sDJ = sA + 12 * J;           // (J,3) gradient on the posed joints
     float *sCam = sDJ + 3 * J;          // (views,16)
     float *sFov = sCam + 16 * views;    // (views) raw fov sums of the frame's images
@@ -1112,13 +1117,13 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
     int *sBone = reinterpret_cast<int *>(red + NW * 12);  // (bone_slots,3) {first entry, end, bone} in the order the waves take them
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const float h = 0.5f * (float)a.cam.S;
-    static_assert(NW == BONE_WAVES, "the model's bone schedule is dealt to this many waves");
+    static_assert(NW >= BONE_WAVES, "the model's bone schedule is dealt to BONE_WAVES waves (the first ones of the workgroup)");
     const int n_slots = a.bone_slots;
     for (int o = tid; o < n_slots; o += NT) {
         const int j = a.bone_order[o];
         sBone[3 * o] = j >= 0 ? a.bone_ptr[j] : 0; sBone[3 * o + 1] = j >= 0 ? a.bone_ptr[j + 1] : 0; sBone[3 * o + 2] = j;
     }
-    if (a.nS == 1)  // one set of rest vertices for every frame: staged once (each thread its own vertices; phase 3 is behind a barrier)
+    if (VPL && a.nS == 1)  // one set of rest vertices for every frame: staged once (each thread its own vertices; phase 3 is behind a barrier)
         for (int v = tid; v < V; v += NT) { vpL[3 * v] = a.v_skin[3 * v]; vpL[3 * v + 1] = a.v_skin[3 * v + 1]; vpL[3 * v + 2] = a.v_skin[3 * v + 2]; }
     float beta_acc = 0.f;               // thread k < nB_used: the shared shape gradient summed over this workgroup's frames
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -1158,7 +1163,7 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
         }
         // ---- phase 1: projection backward of the vertices, view by view, into this thread's rows of dvL ----
         const float *vb = a.verts + (size_t)b * V * 3;
-        if (a.nS != 1) {
+        if (VPL && a.nS != 1) {
             const float *vpb = a.v_skin + (size_t)b * V * 3;
             for (int v = tid; v < V; v += NT) { vpL[3 * v] = vpb[3 * v]; vpL[3 * v + 1] = vpb[3 * v + 1]; vpL[3 * v + 2] = vpb[3 * v + 2]; }
         }
@@ -1203,17 +1208,18 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
             }
         __syncthreads();  // sDJ (and the fov sums) complete
         // ---- phase 2: + regressor^T d_joints; translation and shape terms ----
+        constexpr int U2 = NBT > 6 ? 1 : NDC_UNR2;  // (nine coefficients x two vertices in flight spilled 30 registers)
         float term[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) term[i] = 0.f;
         const bool reg = a.regress && a.d_yx;
-        for (int v0 = tid; v0 < V; v0 += NDC_UNR2 * NT) {
-            uint32_t ids[NDC_UNR2];
-            float4 w4[NDC_UNR2];
-            int2 first[NDC_UNR2];  // the vertex's first regressor entry {joint | entries << 16, weight bits}
-            float s3[NDC_UNR2][NBT][3];
+        for (int v0 = tid; v0 < V; v0 += U2 * NT) {
+            uint32_t ids[U2];
+            float4 w4[U2];
+            int2 first[U2];  // the vertex's first regressor entry {joint | entries << 16, weight bits}
+            float s3[U2][NBT][3];
 #pragma unroll
-            for (int u = 0; u < NDC_UNR2; ++u) {
+            for (int u = 0; u < U2; ++u) {
                 const int v = min(v0 + u * NT, V - 1);
                 ids[u] = a.skin_idx[v];
                 w4[u] = a.skin_w[v];
@@ -1226,7 +1232,7 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
                     }
             }
 #pragma unroll
-            for (int u = 0; u < NDC_UNR2; ++u) {
+            for (int u = 0; u < U2; ++u) {
                 const int v = v0 + u * NT;
                 if (v >= V) continue;
                 float dv[3] = {dvL[3 * v], dvL[3 * v + 1], dvL[3 * v + 2]};
@@ -1289,52 +1295,62 @@ __global__ void __launch_bounds__(NDC_BWD_THREADS, NDC_BWD_MIN_WAVES) k_lbs_bwd_
             }
         }
         if (a.d_fov_img && tid < views && sFov[tid] != 0.f) atomicAdd(&a.d_fov_img[b * views + tid], sFov[tid]);
-        // ---- phase 3: d_A[j] = sum_{v in bone j} w (dv (x) [v_skin; 1]), one wave per bone, longest lists first.  The list
-        // entries of the NEXT 64-entry segment (of this bone or of the wave's next one) are requested before this segment's
-        // gathers: those come from LDS, so the list is the only memory round trip and it is hidden ----
-        int o = sBone[3 * wid + 2] >= 0 ? wid : n_slots;  // (a wave's bones are its first slots)
-        int e0 = 0, e1 = 0;
-        if (o < n_slots) { e0 = sBone[3 * o]; e1 = sBone[3 * o + 1]; }
-        int vid_n = 0;
-        float w_n = 0.f;
-        if (o < n_slots && e0 + lane < e1) { vid_n = a.bone_vid[e0 + lane]; w_n = a.bone_w[e0 + lane]; }
+        // ---- phase 3: d_A[j] = sum_{v in bone j} w (dv (x) [v_skin; 1]), one wave per bone (the first BONE_WAVES waves), longest lists
+        // first.  The list entries of the segment after next (64 entries of this bone or of the wave's next one) are requested before
+        // this segment's gathers, and - without the LDS copy - the next segment's vertices right behind them: the gathers of the gradient
+        // come from LDS, so the memory round trips of a segment are all hidden behind the one before ----
+        struct Seg { int o, e0, e1; };
+        auto seg_next = [&](const Seg &c) -> Seg {  // (wave-uniform)
+            if (c.o >= n_slots) return c;
+            Seg r = {c.o, c.e0 + WAVE, c.e1};
+            if (c.e0 + WAVE >= c.e1) {  // the bone is done: the wave's next one
+                r.o = c.o + BONE_WAVES; r.e0 = r.e1 = 0;
+                if (r.o < n_slots && sBone[3 * r.o + 2] < 0) r.o = n_slots;  // behind the wave's last bone
+                if (r.o < n_slots) { r.e0 = sBone[3 * r.o]; r.e1 = sBone[3 * r.o + 1]; }
+            }
+            return r;
+        };
+        struct Ent { int vid; float w; };  // (vertex 0 with weight 0 beyond the end of a list)
+        auto seg_load = [&](const Seg &c) -> Ent {
+            Ent e = {0, 0.f};
+            if (c.o < n_slots && c.e0 + lane < c.e1) { e.vid = a.bone_vid[c.e0 + lane]; e.w = a.bone_w[c.e0 + lane]; }
+            return e;
+        };
+        const float *const vs = a.v_skin + (size_t)(a.nS == 1 ? 0 : b) * V * 3;
+        Seg s0 = {n_slots, 0, 0};
+        if (wid < BONE_WAVES && sBone[3 * wid + 2] >= 0) s0 = Seg{wid, sBone[3 * wid], sBone[3 * wid + 1]};  // (a wave's bones are its first slots)
+        Seg s1 = seg_next(s0);
+        Ent l0 = seg_load(s0), l1 = seg_load(s1);
+        float x0 = 0.f, y0 = 0.f, z0 = 0.f;
+        if (!VPL) { x0 = vs[3 * l0.vid]; y0 = vs[3 * l0.vid + 1]; z0 = vs[3 * l0.vid + 2]; }
         float acc[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-        while (o < n_slots) {  // (wave-uniform)
-            const int vid = vid_n;
-            const float w = w_n;  // (0 beyond the end of the list)
-            // where the next segment starts
-            const int j_cur = sBone[3 * o + 2];
-            const bool bone_done = e0 + WAVE >= e1;
-            int o_nx = o, e0_nx = e0 + WAVE, e1_nx = e1;
-            if (bone_done) {
-                o_nx = o + NW;
-                e0_nx = e1_nx = 0;
-                if (o_nx < n_slots && sBone[3 * o_nx + 2] < 0) o_nx = n_slots;  // behind the wave's last bone
-                if (o_nx < n_slots) { e0_nx = sBone[3 * o_nx]; e1_nx = sBone[3 * o_nx + 1]; }
-            }
-            vid_n = 0; w_n = 0.f;
-            if (o_nx < n_slots && e0_nx + lane < e1_nx) { vid_n = a.bone_vid[e0_nx + lane]; w_n = a.bone_w[e0_nx + lane]; }
+        while (s0.o < n_slots) {  // (wave-uniform)
+            const Seg s2 = seg_next(s1);
+            const Ent l2 = seg_load(s2);
+            float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+            if (!VPL) { x1 = vs[3 * l1.vid]; y1 = vs[3 * l1.vid + 1]; z1 = vs[3 * l1.vid + 2]; }
             {
-                const float x = vpL[3 * vid], y = vpL[3 * vid + 1], z = vpL[3 * vid + 2];
+                const int vid = l0.vid;
+                const float x = VPL ? vpL[3 * vid] : x0, y = VPL ? vpL[3 * vid + 1] : y0, z = VPL ? vpL[3 * vid + 2] : z0;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const float g = w * dvL[3 * vid + r];
+                    const float g = l0.w * dvL[3 * vid + r];
                     acc[4 * r] += g * x; acc[4 * r + 1] += g * y; acc[4 * r + 2] += g * z; acc[4 * r + 3] += g;
                 }
             }
-            if (bone_done) {
+            if (s0.e0 + WAVE >= s0.e1) {  // the bone's last segment
                 float q[3];
                 wave_sum12(acc, q);
                 if ((lane & 15) == 0) {
-                    float *o12 = a.d_A + ((size_t)b * J + j_cur) * 12 + 3 * (lane >> 4);
+                    float *o12 = a.d_A + ((size_t)b * J + sBone[3 * s0.o + 2]) * 12 + 3 * (lane >> 4);
                     o12[0] = q[0]; o12[1] = q[1]; o12[2] = q[2];
                 }
 #pragma unroll
                 for (int i = 0; i < 12; ++i) acc[i] = 0.f;
             }
-            o = o_nx; e0 = e0_nx; e1 = e1_nx;
+            s0 = s1; s1 = s2; l0 = l1; l1 = l2; x0 = x1; y0 = y1; z0 = z1;
         }
         __syncthreads();  // the next frame overwrites dvL, sA, sDJ
     }
@@ -1366,13 +1382,23 @@ struct NdcUpstream {
     float *d_joints, *d_fov_img;
 };
 
-static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views) {
-    return ((size_t)6 * m->V + 4 + 15 * m->J + 3 * m->bone_slots + 17 * views + (NDC_BWD_THREADS / WAVE) * 12) * sizeof(float);
+#define NDC_BWD_THREADS_WIDE 1024  // the one-workgroup-per-CU form for meshes whose vertex state does not fit twice
+// vp_lds: the skinned-from vertices are staged next to the gradient (24 instead of 12 bytes per vertex)
+static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views, bool vp_lds) {
+    const int waves = (vp_lds ? NDC_BWD_THREADS : NDC_BWD_THREADS_WIDE) / WAVE;
+    return ((size_t)(vp_lds ? 6 : 3) * m->V + 4 + 15 * m->J + 3 * m->bone_slots + 17 * views + waves * 12) * sizeof(float);
+}
+// 1: two workgroups of 512 threads per CU, all vertex state in LDS; 2: one workgroup of 1024 threads with the vertex gradient in LDS
+// (meshes up to ~13 000 vertices on the 160 KB of an MI355X CU); 0: the separate kernels
+static int ndc_bwd_form(const SmilModel *m, int views) {
+    if (ndc_bwd_lds_bytes(m, views, true) <= fused_lds_limit()) return 1;
+    if (ndc_bwd_lds_bytes(m, views, false) <= device_limits().lds_block) return 2;
+    return 0;
 }
 
 extern "C" int smil_lbs_backward_ndc_supported(const SmilModel *m, int32_t nB_used, int32_t views) {
     return m && !m->posedirs && nB_used >= 0 && nB_used <= NDC_BWD_MAX_BETAS && views >= 1 && views <= NDC_BWD_MAX_VIEWS &&
-           ndc_bwd_lds_bytes(m, views) <= fused_lds_limit();  // (two workgroups per CU)
+           ndc_bwd_form(m, views) != 0;
 }
 
 static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *sv, const SmilLbsGrads *g,
@@ -1442,15 +1468,29 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.d_trans = g->d_trans; a.d_fov_img = up->d_fov_img;
         a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress; a.bone_slots = m->bone_slots;
         a.trans_after = in->trans_after_joints ? 1 : 0;
-        const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views);
+        const int form = ndc_bwd_form(m, up->cam->views);
+        SMIL_REQUIRE(form != 0, "smil_lbs_backward_ndc: V=%d does not fit the fused kernel's LDS (ask smil_lbs_backward_ndc_supported first)", V);
+        const bool wide = form == 2;
+        const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views, !wide);
         const int cus = device_cu_count();
-        const int per_cu = std::max(1, std::min(2, (int)(device_limits().lds_cu / lds)));
+        const int per_cu = wide ? 1 : std::max(1, std::min(2, (int)(device_limits().lds_cu / lds)));
         const int grid = std::min(B, std::max(1, cus) * per_cu);
         a.beta = bsum;
         if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; }
-        if (nBu_all <= 3) hipLaunchKernelGGL(k_lbs_bwd_ndc<3>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
-        else if (nBu_all <= 6) hipLaunchKernelGGL(k_lbs_bwd_ndc<6>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
-        else hipLaunchKernelGGL(k_lbs_bwd_ndc<NDC_BWD_MAX_BETAS>, dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a);
+#define NDC_LAUNCH(NBT) \
+        do { \
+            if (wide) { \
+                auto kern = k_lbs_bwd_ndc<NBT, false, NDC_BWD_THREADS_WIDE>; \
+                SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(NDC_BWD_THREADS_WIDE), lds, stream, a); \
+            } else { \
+                hipLaunchKernelGGL((k_lbs_bwd_ndc<NBT, true, NDC_BWD_THREADS>), dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a); \
+            } \
+        } while (0)
+        if (nBu_all <= 3) NDC_LAUNCH(3);
+        else if (nBu_all <= 6) NDC_LAUNCH(6);
+        else NDC_LAUNCH(NDC_BWD_MAX_BETAS);
+#undef NDC_LAUNCH
         SMIL_LAUNCH_CHECK();
     } else {
     hipLaunchKernelGGL(k_skin_bwd_transforms, dim3(B), dim3(few_frames ? 1024 : SKIN_BWD_THREADS), (size_t)J * 3 * sizeof(float), stream, g->d_verts,

@@ -168,7 +168,8 @@ struct RasterArgs {
     const int *faces;        // (F,3)
     const uint32_t *tbox;    // (N,F) tile box of every face
     const uint32_t *gbox;    // (N, ceil(F/64)) union of the tile boxes of 64 consecutive faces
-    const uint32_t *items;   // work lists, per partition q at 2 q cap: [0, cap) classes 0 (front) / 1 (back), [cap, 2 cap) classes 2 / 3
+    const uint4 *items;      // work lists of {tile code, first list entry, entries (0xFFFFFFFF: build the list here), depth extent of the
+                             // image's deepest face}, per partition q at 2 q cap: [0, cap) classes 0 (front) / 1 (back), [cap, 2 cap) classes 2 / 3
     uint32_t item_cap;       // entries of one array of ONE partition: ceil(N / N_PARTS) * tiles
     const float2 *fzr;       // (N,F) nearest / farthest vertex depth of every face
     RasterCounters *ctr;
@@ -187,10 +188,9 @@ struct RasterArgs {
     float *loss_img;         // FUSED (N,)
     float *d_ndc;            // (N,V,2)
     // scratch per resident workgroup
-    const Rec3 *lists;       // (N, list_cap) tile lists binned by the setup kernel: {face id, bits of its nearest / farthest vertex depth}
-    const uint2 *tdesc;      // (N, tiles) {first entry, entries} of a tile's binned list; entries = 0xFFFFFFFF: build it here
+    const uint2 *lists;      // (N, list_cap) tile lists binned by the setup kernel: {face id, bits of its nearest vertex depth}
     uint32_t list_cap;
-    Rec3 *slist;             // the current tile's faces when it builds its list itself (ascending id; same entry layout) ...
+    uint2 *slist;            // the current tile's faces when it builds its list itself (ascending id; same entry layout) ...
     uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may
                              // truncate (the sort reads the depths it needs from slist instead of gathering them per face)
     uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk from the 128th on (the others live in registers)
@@ -270,13 +270,13 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 struct SetupArgs {
     ClipTables clip;
     const float *verts_ndc; const int *faces;
-    uint32_t *tbox, *gbox, *items; uint32_t item_cap; float2 *fzr;
+    uint32_t *tbox, *gbox; uint4 *items; uint32_t item_cap; float2 *fzr;
     RasterCounters *ctr;
     int V, F, S, tiles_x; float sqrt_blur, z_clip;
     float *d_ndc_zero; const float *loss_src; float *loss_dst; float *img_bound; int max_valence;
     float *dndc_scale; const float *pix_scale; float inv_sigma; int packed;
-    Rec3 *lists;        // (N, list_cap) binned tile lists: {face id, bits of its nearest / farthest vertex depth}
-    uint2 *tdesc;       // (N, tiles) {first entry, entries} of every tile's list; entries = 0xFFFFFFFF: not binned (the tile kernel builds it)
+    uint2 *lists;       // (N, list_cap) binned tile lists: {face id, bits of its nearest vertex depth} (8 bytes: the farthest depth only ever fed the
+                        // tile's depth range, and farthest <= nearest + the image's largest face extent bounds that as well)
     uint32_t list_cap;  // entries per image (0: no binning)
 };
 // One workgroup per image.  Pass 1: per face validity, blurred pixel box -> tile box, depth range; per covered tile ONE LDS
@@ -288,8 +288,10 @@ struct SetupArgs {
 __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) {  // (two blocks per CU: <= 64 VGPRs)
     __shared__ uint32_t s_maxpx;  // largest blurred pixel box of a face
     __shared__ uint32_t s_straddle;
-    if (threadIdx.x == 0) { s_maxpx = 0u; s_straddle = 0u; }
+    __shared__ uint32_t s_zext;   // bits of the largest depth extent (farthest - nearest vertex) of a rendered face
+    if (threadIdx.x == 0) { s_maxpx = 0u; s_straddle = 0u; s_zext = 0u; }
     uint32_t my_px = 0u, my_straddle = 0u;
+    float my_zext = 0.f;
     // per tile: entries << 32 | cost (counted), or a touched-tile bitmap when the image has too many tiles; behind it the tiles'
     // list cursors
     extern __shared__ __align__(16) unsigned long long tcnt64[];
@@ -341,6 +343,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
             xi_hi = min(xi_hi, S - 1); yi_hi = min(yi_hi, S - 1);
             if (xi_lo <= xi_hi && yi_lo <= yi_hi) {
                 my_px = max(my_px, (uint32_t)((xi_hi - xi_lo + 1) * (yi_hi - yi_lo + 1)));
+                my_zext = fmaxf(my_zext, zmax - zmin);
                 // output column xo = S-1-xi
                 const int tx0 = (S - 1 - xi_hi) / TILE, tx1 = (S - 1 - xi_lo) / TILE;
                 const int ty0 = (S - 1 - yi_hi) / TILE, ty1 = (S - 1 - yi_lo) / TILE;
@@ -456,6 +459,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     // alpha <= 1 - p, and r p (1 - p) <= 0.197 sqrt(sigma) for every r (maximum of sqrt(u) s(u) (1 - s(u)), u = r^2 / sigma);
     // a face has at most its blurred pixel box of records; a vertex has at most max_valence faces.
     if (my_px) atomicMax(&s_maxpx, my_px);
+    if (my_zext > 0.f) atomicMax(&s_zext, __float_as_uint(my_zext));  // (non-negative floats order like their bit patterns)
     if (my_straddle) atomicAdd(&s_straddle, my_straddle);
     __syncthreads();
     if (threadIdx.x == 0 && q.img_bound) {
@@ -504,14 +508,12 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
 #pragma unroll
     for (int k = 0; k < N_CLASSES; ++k) off[k] += s_base[k];
     uint32_t run = ent_off;
+    const uint32_t zext_bits = s_zext;  // (final since the barrier behind the atomicMax above)
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int c = tile_class(t);
-        if (q.tdesc) {
-            const uint32_t e = counted ? (uint32_t)(tcnt64[t] >> 32) : 0u;
-            q.tdesc[(size_t)n * n_tiles + t] = binned ? make_uint2(run, e) : make_uint2(0u, 0xFFFFFFFFu);
-            if (binned) tcur[t] = run;
-            run += e;
-        }
+        const uint32_t e = counted ? (uint32_t)(tcnt64[t] >> 32) : 0u, first = run;
+        if (binned) tcur[t] = run;
+        run += e;
         if (c < 0) continue;
         uint32_t slot = 0u;
 #pragma unroll
@@ -519,20 +521,22 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
             if (c == k) slot = off[k]++;
         // classes 0 and 2 grow from the front of their array, 1 and 3 from the back
         const uint32_t idx = (uint32_t)(2 * part + (c >> 1)) * q.item_cap + ((c & 1) ? q.item_cap - 1u - slot : slot);
-        q.items[idx] = (uint32_t)n * (uint32_t)n_tiles + (uint32_t)t;
+        // the work item carries its tile's list with it: {image * tiles + tile, first entry, entries (0xFFFFFFFF: the tile kernel builds the
+        // list), largest depth extent of a face of this image} - one 16-byte load in the tile kernel where the item code and a tile
+        // descriptor were two dependent ones
+        q.items[idx] = make_uint4((uint32_t)n * (uint32_t)n_tiles + (uint32_t)t, binned ? first : 0u, binned ? e : 0xFFFFFFFFu, zext_bits);
     }
-    if (!binned || !q.tdesc) return;  // (block-uniform)
+    if (!binned) return;  // (block-uniform)
     __syncthreads();
     // pass 2: every face to the lists of the tiles of its box (its own tile box and depth range come back from L1 / L2)
-    Rec3 *const lists = q.lists + (size_t)n * q.list_cap;
+    uint2 *const lists = q.lists + (size_t)n * q.list_cap;
     // (consecutive faces cover the same tiles: their entries take consecutive slots, so a wave's stores land in few cache lines;
     // spreading the lanes over distant faces to thin out the same-address atomics was measured slower, 601 -> 658 us)
     for (int f = threadIdx.x; f < FT; f += blockDim.x) {
         const uint32_t box = q.tbox[(size_t)n * FT + f];
         const int tx0 = box & 0xFF, ty0 = (box >> 8) & 0xFF, tx1 = (box >> 16) & 0xFF, ty1 = box >> 24;
         if (tx0 > tx1) continue;
-        const float2 zr = q.fzr[(size_t)n * FT + f];
-        const Rec3 ent = {(uint32_t)f, __float_as_uint(zr.x), __float_as_uint(zr.y)};
+        const uint2 ent = make_uint2((uint32_t)f, __float_as_uint(q.fzr[(size_t)n * FT + f].x));
         for (int ty = ty0; ty <= ty1; ++ty)
             for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
     }
@@ -762,7 +766,7 @@ __device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
 #ifndef LGROUP
 #define LGROUP 8  // 64-face groups whose tile boxes / depth ranges are requested together by the list build
 #endif
-__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, Rec3 *list, int lane, uint32_t &kmin,
+__device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, int ty, uint2 *list, int lane, uint32_t &kmin,
                                           uint32_t &kmax) {
     const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.FT;
     const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.FT;
@@ -792,7 +796,7 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
                 const bool hit = fidx[u] < a.FT && box_has(tb[u], tx, ty);
                 const unsigned long long mask = __ballot(hit);
                 if (hit) {
-                    at(list, (uint32_t)(cnt + __popcll(mask & ((1ull << lane) - 1ull)))) = Rec3{(uint32_t)fidx[u], __float_as_uint(zz[u].x), __float_as_uint(zz[u].y)};
+                    at(list, (uint32_t)(cnt + __popcll(mask & ((1ull << lane) - 1ull)))) = make_uint2((uint32_t)fidx[u], __float_as_uint(zz[u].x));
                     zlo = fminf(zlo, zz[u].x);
                     zhi = fmaxf(zhi, zz[u].y);
                 }
@@ -817,16 +821,16 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
 // nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
 // Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
 // recovers through `out`.  bstart[d] = first position of bucket d.
-__device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
+__device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
                                                       DenseLds &lds, int lane) {
     const int n_buckets = 1 << b1;
     lds.start[lane] = 0;
     __syncthreads();
-    auto digit_of = [&](const Rec3 &e) { return (int)(((e.b - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
+    auto digit_of = [&](const uint2 &e) { return (int)(((e.y - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
     // (four rows per step: the loads of a step are in flight together - at small launches a tile's time is its chain of
     // memory round trips)
     for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
-        Rec3 e[4];
+        uint2 e[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) e[u] = at(list, (uint32_t)min(i0 + u * WAVE + lane, n - 1));
 #pragma unroll
@@ -841,12 +845,12 @@ __device__ __forceinline__ void sort_list_near_to_far(const Rec3 *list, uint32_t
     lds.start[lane] = incl - c;  // running cursor of every bucket
     __syncthreads();
     for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
-        Rec3 e[4];
+        uint2 e[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) e[u] = at(list, (uint32_t)min(i0 + u * WAVE + lane, n - 1));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * WAVE + lane < n) out[atomicAdd(&lds.start[digit_of(e[u])], 1)] = e[u].a;
+            if (i0 + u * WAVE + lane < n) out[atomicAdd(&lds.start[digit_of(e[u])], 1)] = e[u].x;
     }
     __syncthreads();
 }
@@ -1108,7 +1112,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs a) {
     __shared__ DenseLds lds;
     const int lane = threadIdx.x;
-    Rec3 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
+    uint2 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
     float2 *const sxy = a.sxy + (size_t)blockIdx.x * 3 * a.list_stride;
@@ -1140,7 +1144,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
     const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
     const unsigned int units0 = nc0 << split0_log;
     const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
-    const uint32_t *const items = a.items + (size_t)part * 2u * a.item_cap;
+    const uint4 *const items = a.items + (size_t)part * 2u * a.item_cap;
     while (n_units > 0u) {
         unsigned int unit = 0;
         TSUB(0)
@@ -1153,10 +1157,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         const unsigned int item = (u_ >> sl) + (heavy ? 0u : nc0);
         const int p_begin = (int)(u_ & ((1u << sl) - 1u)) * (WAVE >> sl), p_end = p_begin + (WAVE >> sl);
         // heaviest class first
-        const uint32_t code = item < nc0 ? items[item]
-                            : item < nc0 + nc1 ? items[a.item_cap - 1u - (item - nc0)]
-                            : item < nc0 + nc1 + nc2 ? items[a.item_cap + (item - nc0 - nc1)]
-                            : items[2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2)];
+        const uint32_t item_at = item < nc0 ? item
+                               : item < nc0 + nc1 ? a.item_cap - 1u - (item - nc0)
+                               : item < nc0 + nc1 + nc2 ? a.item_cap + (item - nc0 - nc1)
+                               : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
+        const uint4 it = items[item_at];
+        const uint32_t code = it.x;
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
@@ -1170,26 +1176,31 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         uint32_t kmin, kmax;  // bounds of the depth keys of this tile
         // the faces whose blurred box reaches this tile: binned by the setup kernel (any order), or found here through the tile
         // boxes of the 64-face groups (ascending id) when the image's lists did not fit
-        const uint2 td = a.tdesc ? a.tdesc[code] : make_uint2(0u, 0xFFFFFFFFu);
+        const uint2 td = make_uint2(it.y, it.z);
         const bool binned = td.y != 0xFFFFFFFFu;  // (wave-uniform)
         TSUB(1)
-        const Rec3 *const list_src = binned ? a.lists + (size_t)n * a.list_cap + td.x : slist;
+        const uint2 *const list_src = binned ? a.lists + (size_t)n * a.list_cap + td.x : slist;
         int list_total;
         if (binned) {
+            // every depth of the tile lies between the nearest vertex of its nearest face and the farthest vertex of any: the entries
+            // carry the nearest depth only (8 bytes), and farthest <= nearest + (largest depth extent of a face of the image, from
+            // the setup kernel with the work item) bounds the other end - an upper bound is all the key range needs
             list_total = (int)td.y;
-            uint32_t lo = 0x7F7FFFFFu, hi = 0u;  // every depth of the tile lies between its faces' nearest and farthest vertices
+            uint32_t lo = 0x7F7FFFFFu, hi = 0u;
             for (int i0 = 0; i0 < list_total; i0 += 4 * WAVE) {
-                Rec3 e[4];
+                uint2 e[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) e[u] = at(list_src, (uint32_t)min(i0 + u * WAVE + lane, list_total - 1));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { lo = min(lo, e[u].b); hi = max(hi, e[u].c); }
+                for (int u = 0; u < 4; ++u) { lo = min(lo, e[u].y); hi = max(hi, e[u].y); }
             }
             for (int o = 32; o > 0; o >>= 1) {
                 lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, WAVE));
                 hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, WAVE));
             }
-            kmin = lo; kmax = hi;
+            kmin = lo;
+            // (rounded up twice: the extent was a rounded difference, the sum rounds again)
+            kmax = __float_as_uint((__uint_as_float(hi) + __uint_as_float(it.w) * 1.000001f) * 1.0000005f) + 1u;
         } else {
             list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
         }
@@ -1206,7 +1217,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         if (may_truncate) {
             sort_list_near_to_far(list_src, slist2, list_total, kmin, shift1, b1, lds, lane);
         } else {  // at most K faces: the order of the list is kept
-            for (int i = lane; i < list_total; i += WAVE) slist2[i] = at(list_src, (uint32_t)i).a;
+            for (int i = lane; i < list_total; i += WAVE) slist2[i] = at(list_src, (uint32_t)i).x;
             __syncthreads();
         }
         TMARK(0)
@@ -1858,16 +1869,16 @@ static int tile_grid(int N, int tiles_x) {
     return (int)(max_items < resident ? max_items : resident);
 }
 
-// per resident workgroup: F x {face id, nearest / farthest depth} in id order (tiles of images that are not binned), F face ids in walking order,
+// per resident workgroup: F x {face id, nearest depth} in id order (tiles of images that are not binned), F face ids in walking order,
 // F x {projected vertices (24 B), vertex ids (12 B)} by list position, F / DCHUNK + 2 chunk starts,
 // (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
 #define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
-    return (size_t)grid * (13 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+    return (size_t)grid * (12 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
                            (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
 
-// binned tile lists: LIST_CAP_PER_FACE entries per face and image (12 bytes each) + one descriptor per tile; images with more than
+// binned tile lists: LIST_CAP_PER_FACE entries per face and image (8 bytes each) + one depth range per tile; images with more than
 // COUNT_TILES_MAX tiles are never binned
 static inline uint32_t list_cap_of(const SmilModel *m, int S) {
     return ceil_div(S, TILE) * ceil_div(S, TILE) <= COUNT_TILES_MAX ? (uint32_t)LIST_CAP_PER_FACE * (S > 256 ? 2u : 1u) * (uint32_t)m->F : 0u;
@@ -1883,12 +1894,12 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
     if (!m || N <= 0 || S <= 0) return 0;
     const size_t tiles = (size_t)ceil_div(S, TILE) * ceil_div(S, TILE);
     const size_t FT = (size_t)face_rows(m);
-    // tile boxes (N,FT), counters, work lists (2, N, tiles), per-face depth ranges (N,FT), binned lists + tile descriptors, clip tables, per-workgroup scratch
+    // tile boxes (N,FT), counters, work lists (2, N, tiles), per-face depth ranges (N,FT), binned lists, clip tables, per-workgroup scratch
     return align256((size_t)N * FT * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
-           align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint32_t)) +
+           align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint4)) +
            align256((size_t)N * FT * sizeof(float2)) + align256((size_t)N * (FT / WAVE) * sizeof(uint32_t)) +
-           align256((size_t)N * sizeof(float)) + align256((size_t)N * list_cap_of(m, S) * sizeof(Rec3)) +
-           align256((size_t)N * tiles * sizeof(uint2)) + clip_bytes(N) + 256 +
+           align256((size_t)N * sizeof(float)) + align256((size_t)N * list_cap_of(m, S) * sizeof(uint2)) +
+           clip_bytes(N) + 256 +
            scratch_bytes(tile_grid(N, ceil_div(S, TILE)), face_rows(m));
 }
 
@@ -1924,9 +1935,9 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += align256((size_t)N * FT * sizeof(uint32_t));
     RasterCounters *ctr = (RasterCounters *)ws;  // (the probe tool reads the counters right behind the tile boxes)
     ws += align256(sizeof(RasterCounters));
-    uint32_t *items = (uint32_t *)ws;
+    uint4 *items = (uint4 *)ws;
     const uint32_t item_cap = (uint32_t)ceil_div(N, N_PARTS) * (uint32_t)(tiles_x * tiles_x);
-    ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(uint32_t));
+    ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(uint4));
     float2 *fzr = (float2 *)ws;
     ws += align256((size_t)N * FT * sizeof(float2));
     uint32_t *gbox = (uint32_t *)ws;
@@ -1934,10 +1945,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     float *img_bound = (float *)ws;
     ws += align256((size_t)N * sizeof(float));
     const uint32_t list_cap = list_cap_of(m, S);
-    Rec3 *lists = (Rec3 *)ws;
-    ws += align256((size_t)N * list_cap * sizeof(Rec3));
-    uint2 *tdesc = (uint2 *)ws;
-    ws += align256((size_t)N * tiles_x * tiles_x * sizeof(uint2));
+    uint2 *lists = (uint2 *)ws;
+    ws += align256((size_t)N * list_cap * sizeof(uint2));
     ClipTables clip;
     clip.xv = (float *)ws; ws += align256((size_t)N * CLIP_VX * 12);
     clip.xg = (float *)ws; ws += align256((size_t)N * CLIP_VX * 8);
@@ -1954,7 +1963,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         q.ctr = ctr; q.V = m->V; q.F = m->F; q.S = S; q.tiles_x = tiles_x; q.sqrt_blur = sqrt_blur; q.z_clip = rs->z_clip;
         q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.img_bound = img_bound; q.max_valence = m->max_valence;
         q.dndc_scale = dndc_scale; q.pix_scale = pix_scale; q.inv_sigma = 1.0f / rs->sigma; q.packed = packed;
-        q.lists = lists; q.tdesc = tdesc; q.list_cap = list_cap; q.clip = clip;
+        q.lists = lists; q.list_cap = list_cap; q.clip = clip;
         // per tile: 8 bytes of counts + 4 bytes of list cursor, or one bit
         const size_t setup_lds = n_tiles <= COUNT_TILES_MAX ? (size_t)n_tiles * 12 : (size_t)((n_tiles + 31) / 32) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, q);
@@ -1965,8 +1974,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.list_stride = (int)(align256((size_t)FT * sizeof(uint32_t)) / sizeof(uint32_t));
         a.n_cf = (int)(align256((size_t)(FT / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
         ws += 256;
-        a.slist = (Rec3 *)ws;
-        ws += grid * (size_t)a.list_stride * sizeof(Rec3);
+        a.slist = (uint2 *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(uint2);
         a.slist2 = (uint32_t *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
         a.scfirst = (uint32_t *)ws;
@@ -1979,7 +1988,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.srec = (Rec3 *)ws; ws += stream;
         a.crec = (Rec3 *)ws;
     }
-    a.lists = lists; a.tdesc = tdesc; a.list_cap = list_cap; a.clip = clip; a.FT = FT;
+    a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT;
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);

@@ -18,11 +18,14 @@ from smilify_amd import model_io
 DEV = "cuda:0"
 
 
-def random_model(rng, wide=False):
+def random_model(rng, wide=False, big=False):
     J = int(rng.integers(3, 251 if wide else 121))
     side = int(rng.integers(4, 41))
     while (J + 1) * side + 2 > 5000:
         side -= 1
+    if big:  # more than 3 600 vertices: beyond the 80 KB of LDS two workgroups per CU can take each (24 bytes per vertex)
+        J = int(rng.integers(90, 121))
+        side = int(rng.integers(3600 // (J + 1) + 1, 4998 // (J + 1) + 1))
     nB = int(rng.integers(0, 10))
     static = bool(rng.integers(0, 2))
     t = model_io.synthetic_model(V_side=side, J=J, nB=nB, seed=int(rng.integers(0, 1 << 30)), static_joints=static)
@@ -67,10 +70,10 @@ def close(a, b, tol, what):
 
 
 
-def run_case(seed, wide=False):
-    """One random model and call.  Returns (checks, info): checks = [(failed_error_or_None, what, error)]."""
+def run_case(seed, wide=False, big=False, table=None):
+    """One random model (or ``table``) and call.  Returns (checks, info): checks = [(failed_error_or_None, what, error)]."""
     rng = np.random.default_rng(seed)
-    t = random_model(rng, wide)
+    t = random_model(rng, wide, big) if table is None else table
     dm = eng.DeviceModel(t, DEV)
     J, V, nB = dm.J, dm.V, dm.nB
     B, views, S = int(rng.integers(1, 40)), int(rng.integers(1, 21 if wide else 7)), 64

@@ -102,14 +102,14 @@ def test_backward_from_the_image_plane_decodes_packed_rows_and_declines_what_it_
         _close(a[k], b[k], 2e-5, k)
     _close(fov_a, fov_b, 2e-5, "fov")
     mouse = eng.DeviceModel(tables("mouse"), DEV)
-    assert not eng.lbs_backward_ndc_supported(mouse, mouse.nB, 1)  # 11 263 vertices x 12 bytes
+    assert eng.lbs_backward_ndc_supported(mouse, mouse.nB, 18)  # round 4: 11 263 vertices x 12 bytes in one workgroup per CU
 
 
 @pytest.mark.parametrize("key,views,trans_after", [("stick", 1, True), ("stick", 3, False), ("synthetic", 5, True), ("synthetic_static", 2, True),
                                                    ("synthetic_static", 2, False), ("mouse", 2, True)])
 def test_forward_with_projection_equals_forward_then_projection(key, views, trans_after, tables):
-    """``smil_lbs_forward_project``: skinning + joint regression + both projections in one kernel per frame (the mouse does not
-    fit its LDS and takes the separate kernels behind the same entry point)."""
+    """``smil_lbs_forward_project``: skinning + joint regression + both projections in one kernel per frame (round 4: the mouse, whose joints are
+    static, keeps no vertex copy in LDS and takes the same kernel)."""
     from smilify_amd import cameras as cam_mod
     from smilify_amd import engine as eng
 
@@ -212,8 +212,11 @@ def test_fused_entries_refuse_what_they_cannot_do(tables):
     from smilify_amd import engine as eng
     from smilify_amd._lib import SmilError
 
-    t = tables("mouse")
+    from smilify_amd import model_io
+
+    t = model_io.synthetic_model(V_side=125, J=120, nB=3, seed=1)  # 15 127 vertices: 12 bytes each exceed a CU's 160 KB of LDS
     dm = eng.DeviceModel(t, DEV)
+    assert not eng.lbs_backward_ndc_supported(dm, dm.nB, 1)
     B, S = 3, 32
     g = torch.Generator().manual_seed(2)
     beta = torch.zeros(dm.nB, device=DEV)

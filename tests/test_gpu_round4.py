@@ -25,13 +25,34 @@ def test_fused_lbs_kernels_against_the_oracle(seed, wide):
     assert not fails, (info, fails)
 
 
+@pytest.mark.parametrize("seed,key", [(200, None), (201, None), (202, None), (203, "mouse"), (204, "mouse")])
+def test_fused_lbs_kernels_on_meshes_beyond_half_a_cu(seed, key, tables):
+    """Meshes whose per-frame vertex state (24 bytes per vertex) does not fit twice into a CU's LDS take the fused kernels' second
+    form since round 4: one workgroup of 1024 threads per CU, only the vertex gradient in LDS (12 bytes per vertex), the rest
+    vertices gathered from memory one bone-list segment ahead; the forward kernel keeps no vertex copy at all for models with
+    static joints.  Random tubes with 3 600 - 5 000 vertices and the mouse (V = 11 263, BASELINE configs 3 and 5) against the
+    CPU oracle's autograd and against the separate-kernel route (reference smal_model/smal_torch.py:320-351)."""
+    import lbs_cases
+    from smilify_amd import engine as eng
+
+    t = tables(key) if key else None
+    checks, info = lbs_cases.run_case(seed, big=key is None, table=t)
+    assert info["V"] > 3500 and info["fused_bwd"] == 1, info
+    assert any(w.startswith("oracle d_") for _, w, _ in checks) and any(w.startswith("bwd d_") for _, w, _ in checks), info
+    fails = [(w, e) for f, w, e in checks if f is not None]
+    assert not fails, (info, fails)
+    if key:  # the form is chosen by the model alone: every BASELINE camera rig of the mouse is covered
+        dm = eng.DeviceModel(t, DEV)
+        assert all(eng.lbs_backward_ndc_supported(dm, dm.nB, v) for v in (1, 2, 18, 32))
+
+
 @pytest.mark.parametrize("key,frames,views", [("stick", 96, 2), ("mouse", 24, 3)])
 def test_the_shared_shape_gradient_is_bit_reproducible(key, frames, views, tables):
     """Two evaluations of the same fit step return the same bits in d_betas - the one quantity ranks all-reduce (reference
     fitter.py:236-335: ``betas`` is shared by every frame, so its gradient is a sum over frames).  Round 3 summed the frames with
     float atomics, whose result depends on the order the blocks arrive in; since round 4 every block leaves a partial row and the
-    last block adds the rows in a fixed order (lbs.hip BetaSum).  STICK goes through the fused per-frame kernel + chain kernel, the
-    mouse through the separate shape kernel; several runs, because a race would only show now and then.  (At least 64 images per
+    last block adds the rows in a fixed order (lbs.hip BetaSum).  STICK goes through the fused per-frame kernel (two workgroups per
+    CU) + chain kernel, the mouse through its one-workgroup-per-CU form; several runs, because a race would only show now and then.  (At least 64 images per
     launch, so that the rasteriser's vertex gradients upstream are the integer-exact packed ones.)"""
     from smilify_amd import synthetic
 

@@ -177,9 +177,10 @@ int smil_fov_reduce(const SmilCameras *cam, const float *d_fov_img, float *d_fov
 
 /* smil_lbs_forward followed by the projection of its vertices and joints through `cam` (N = in->B * cam->views images):
  * ndc (N,V,3) as smil_project(verts) and yx (N,J,2) as smil_project(joints); either may be NULL.  Replaces SMAL.__call__
- * + Renderer's two projections of one fit iteration (fitter.py:270-290, p3d_renderer.py:137-146).  Where the frame's vertices
- * fit a workgroup's LDS (3 V floats <= 64 KB) skinning, joint regression and both projections are ONE kernel per frame and
- * `verts` is written once and not read back; otherwise the separate kernels run.  Outputs are those of the separate calls. */
+ * + Renderer's two projections of one fit iteration (fitter.py:270-290, p3d_renderer.py:137-146).  Skinning, joint regression and
+ * both projections are ONE kernel per frame and `verts` is written once and not read back where the model's joints are static
+ * (nothing is gathered from the frame's vertices: any mesh size) or the frame's vertices fit half a CU's LDS (3 V floats <= 80 KB);
+ * otherwise the separate kernels run.  Outputs are those of the separate calls. */
 int smil_lbs_forward_project(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, const SmilCameras *cam,
                              float *ndc, float *yx, void *stream);
 
@@ -190,8 +191,10 @@ int smil_lbs_forward_project(const SmilModel *m, const SmilLbsInputs *in, const 
  * smal_torch.py:240-351) without writing the (B,V,3) vertex gradient to memory.  g->d_verts, g->d_joints and g->d_del_v
  * must be NULL; d_joints (B,J,3) receives the world-space joint gradient (an output); d_fov_img (N,) or NULL is ADDED to
  * as by smil_project_backward.  saved->verts and saved->joints are read.  Results equal the two-call route up to fp32
- * summation order.  smil_lbs_backward_ndc_supported: 1 when this entry handles the model (no pose blend shapes, the frame's
- * vertex gradient and rest vertices fit 80 KB of LDS) with nB_used shape coefficients (<= 9) and `views` views per frame (<= 32). */
+ * summation order.  smil_lbs_backward_ndc_supported: 1 when this entry handles the model with nB_used shape coefficients (<= 9)
+ * and `views` views per frame (<= 32): no pose blend shapes, and either the frame's vertex gradient AND rest vertices fit half a
+ * CU's LDS (24 V bytes <= 80 KB: two workgroups of 512 threads per CU) or the vertex gradient alone fits the CU's whole LDS
+ * (12 V bytes <= 160 KB, V <= ~13 000: one workgroup of 1024 threads per CU, rest vertices gathered from memory). */
 int smil_lbs_backward_ndc(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *saved, const SmilLbsGrads *g,
                           const SmilCameras *cam, const float *d_ndc, const float *d_ndc_scale, const float *d_yx_joints,
                           float *d_joints, float *d_fov_img, void *stream);

@@ -366,11 +366,19 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         q.fzr[(size_t)n * FT + fid] = make_float2(zmin, zmax);
         return box;
     };
+    // (the vertex ids of the NEXT round's face are requested before this round's vertices are gathered: a round is one memory
+    // round trip - ids -> vertices was two - and an image is a chain of F / blockDim.x rounds)
+    int nx0 = 0, nx1 = 0, nx2 = 0;
+    if ((int)threadIdx.x < F) { nx0 = q.faces[3 * threadIdx.x]; nx1 = q.faces[3 * threadIdx.x + 1]; nx2 = q.faces[3 * threadIdx.x + 2]; }
     for (int f0 = 0; f0 < FP; f0 += blockDim.x) {  // every wave handles 64 consecutive faces per round
         const int f = f0 + threadIdx.x;
         uint32_t box = 0x0000FFFFu;
+        const int ii[3] = {nx0, nx1, nx2};
+        {
+            const int fn = min(f + (int)blockDim.x, F - 1);
+            nx0 = q.faces[3 * fn]; nx1 = q.faces[3 * fn + 1]; nx2 = q.faces[3 * fn + 2];
+        }
         if (f < F) {
-            const int ii[3] = {q.faces[3 * f], q.faces[3 * f + 1], q.faces[3 * f + 2]};
             float X[3], Y[3], Z[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { X[k] = vn[3 * ii[k]]; Y[k] = vn[3 * ii[k] + 1]; Z[k] = vn[3 * ii[k] + 2]; }
@@ -534,9 +542,9 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     // spreading the lanes over distant faces to thin out the same-address atomics was measured slower, 601 -> 658 us)
     for (int f = threadIdx.x; f < FT; f += blockDim.x) {
         const uint32_t box = q.tbox[(size_t)n * FT + f];
+        const uint2 ent = make_uint2((uint32_t)f, __float_as_uint(q.fzr[(size_t)n * FT + f].x));  // (requested with the box: one round trip)
         const int tx0 = box & 0xFF, ty0 = (box >> 8) & 0xFF, tx1 = (box >> 16) & 0xFF, ty1 = box >> 24;
         if (tx0 > tx1) continue;
-        const uint2 ent = make_uint2((uint32_t)f, __float_as_uint(q.fzr[(size_t)n * FT + f].x));
         for (int ty = ty0; ty <= ty1; ++ty)
             for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
     }
@@ -1659,7 +1667,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             HOOK_STOP_AFTER(3, { p_lo += span; continue; })
             STAT(22, n_cmp) STAT(23, __popcll(__ballot(trunc))) STAT(24, __popcll(__ballot(lds.plog[lane] != 0.0)))
             STAT(40, any_trunc ? 1 : 0) STAT(41, may_truncate ? 1 : 0) STAT(42, any_trunc ? vbase : 0) STAT(43, may_truncate ? vbase : 0) STAT(44, __popcll(__ballot(tie_cut != 0x7FFFFFFF)))
-            const float alpha = exp2f((float)lds.plog[lane]);
+            const double plog_px = lds.plog[lane];
+            const float alpha = exp2f((float)plog_px);
             TMARK(3)
 
             // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
@@ -1686,7 +1695,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             // ---------------- pass 3: lane = record -------------------------------------------------
             // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
             const float coef = -g * alpha * a.inv_sigma;
-            const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS);
+            // (a pixel whose records all have 1 - p == 1 in fp32 - or that has none - hands nothing back: its coefficient must not enter
+            // the fixed-point bound below either, or a tile of empty pixels sets the resolution for its one contributing pixel)
+            const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS) && (plog_px != 0.0);
             const bool any_split = __ballot(tie_cut != 0x7FFFFFFF) != 0ull;  // a pixel whose tie group at the K-th depth is cut by face id
             TSUB(6)
             STAT(25, __popcll(__ballot(active)))

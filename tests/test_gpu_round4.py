@@ -184,3 +184,28 @@ def test_gradient_of_a_cut_face_by_finite_differences(tables):
             assert abs(fd - grad[v, c]) <= 0.06 * abs(grad[v, c]) + 0.02 * np.abs(grad).max(), (v, c, fd, grad[v, c])
             checked += 1
     assert checked >= 3, (checked, np.abs(grad).max())
+
+
+def test_a_saturated_pixel_keeps_its_gradient_among_empty_pixels(tables):
+    """A small, far silhouette: one pixel of the tile holds every candidate and is all but saturated (transmittance 2e-7), the other
+    63 pixels hold none but carry upstream gradients of ordinary size.  The fixed-point scale of the tile's gradient accumulators is
+    set by the pixels that can contribute; round 3 let the empty ones in, and their coefficients (1e7 times the saturated pixel's)
+    quantised its whole gradient away: |error| / |gradient| = 0.5 (long fuzz of round 4, seed 1249; profiles/r4_fuzz_one.txt).
+    Reference semantics: p3d_renderer.py:41-47 - every pixel's gradient, whatever its size."""
+    from smilify_amd import engine as eng
+    from oracle import render_ref
+    from test_gpu_edge_cases import _scene
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S = 9
+    ndc = _scene(t, 1, S, 8.4, 1249)
+    with render_ref.select_mode(1):
+        sil, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S)
+    assert int((ncand > 0).sum()) <= 4 and float(sil.max()) > 0.99, (ncand.max(), sil.max())  # (the scene this test is about)
+    gs = np.random.default_rng(5).standard_normal((1, S, S)).astype(np.float32)
+    with render_ref.select_mode(1):
+        want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs)[..., :2]
+    got = eng.silhouette_backward(dm, ndc.to(DEV), S, torch.from_numpy(gs).to(DEV)).cpu().numpy()
+    assert np.linalg.norm(want) > 0
+    assert np.linalg.norm(got - want) <= 1e-3 * np.linalg.norm(want), (np.linalg.norm(got - want), np.linalg.norm(want))

@@ -1134,12 +1134,21 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
     for (int q = 0; q < N_PARTS; ++q)
         for (int c = 0; c < N_CLASSES; ++c) n_items_all += a.ctr->n_class[q][c];
     // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
-    // the launch finishes in a fraction of one tile's serial time.
+    // the launch finishes in a fraction of one tile's serial time.  Round 4, from a sweep over 1 ... 64 images x workgroups per CU x
+    // pieces (profiles/r4_small_launches.txt): the launch is fastest with ~2.3 pieces per WORKING workgroup and about 1.2 pieces per
+    // resident slot in all (8-pixel pieces - a whole list walk for one row of pixels - only while even they number under 0.6 per
+    // slot); the workgroups beyond that leave at once - a one-image launch runs on 512 of them, not on 4 096 that queue for the same
+    // ticket counter.
+    const unsigned int slots = gridDim.x;
     const unsigned int split_log = HOOK_SPLIT_LOG(
-        n_items_all * 8u <= gridDim.x ? 3u : (n_items_all * 4u <= gridDim.x ? 2u : (n_items_all * 2u <= gridDim.x ? 1u : 0u)));
+        n_items_all * 8u <= slots * 5u / 8u ? 3u : (n_items_all * 4u <= slots * 5u / 4u ? 2u : (n_items_all * 2u <= slots * 5u / 4u ? 1u : 0u)));
+    {
+        const unsigned int working = max(slots / 8u, (n_items_all << split_log) * 7u / 16u);
+        if (blockIdx.x >= working) return;  // (workgroup-uniform, before any barrier)
+    }
     // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
-    // near to far).
-    const unsigned int split0_log = SPLIT0_LOG;
+    // near to far) - and is, like the others, when the launch has workgroups to spare.
+    const unsigned int split0_log = SPLIT0_LOG > split_log ? SPLIT0_LOG : split_log;
     const float fS = (float)a.S;
     unsigned int xcc;  // the XCD this workgroup runs on: which partition it drains first
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1874,7 +1883,9 @@ static int device_cus() {
 }
 
 static int tile_grid(int N, int tiles_x) {
-    const long long max_items = (long long)N * tiles_x * tiles_x;
+    // (a handful of images: a tile is dealt out in up to 8 runs of pixels - see split_log in the tile kernel - so the launch can use
+    // 8 workgroups per tile; before round 4 a one-image launch got 1 024 workgroups for its ~2 400 possible pieces and split in two)
+    const long long max_items = (long long)N * tiles_x * tiles_x * 8;
     long long resident = (long long)device_cus() * RESIDENT_PER_CU;
     HOOK_RESIDENT(resident)
     return (int)(max_items < resident ? max_items : resident);

@@ -394,7 +394,7 @@ def _slice_images(model: "DeviceModel", N: int, S: int) -> int:
     """Images per rasteriser call: at most MAX_IMAGES_PER_LAUNCH, fewer when the per-image workspace tables would push the
     workspace past MAX_WORKSPACE_BYTES (mouse-sized meshes at 512^2)."""
     step = min(N, MAX_IMAGES_PER_LAUNCH)
-    key = (N, S)
+    key = (N, S, step)
     cached = model.__dict__.setdefault("_slice_cache", {})
     if key not in cached:
         while step > 256 and int(_lib.load().smil_raster_workspace_bytes(model.handle, step, S)) > MAX_WORKSPACE_BYTES:

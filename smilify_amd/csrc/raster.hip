@@ -1479,6 +1479,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                         rmax2 = fmaxf(rmax2, fabsf(r[u].sd));  // (the clamped tail repeats a record: harmless)
                         const float lf = __log2f(1.0f - face_prob(r[u].sd, a.inv_sigma_log2e));
                         if (sure & (lf != 0.f)) atomicAdd(&lds.plog[r[u].mt & 63u], (double)lf);
+                        STAT(45, __popcll(__ballot(sure))) STAT(46, __popcll(__ballot(valid & !sure & !maybe)))
                         if (any_trunc) {  // wave-uniform
                             const unsigned long long km = __ballot(maybe);
                             const uint32_t slot = (uint32_t)n_cmp + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));

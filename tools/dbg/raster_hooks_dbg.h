@@ -99,6 +99,7 @@ static inline void raster_dbg_report(unsigned long long *&dbg_out) {
         fprintf(stderr, "[dbg stats] staged faces with a non-empty pixel box %.4e\n", (double)h[31]);
         fprintf(stderr, "[dbg stats] (sub-)tiles with a truncated pixel %.4e (their records %.4e), that may truncate %.4e (records %.4e); pixels with a split tie group %.4e\n",
                 (double)h[40], (double)h[42], (double)h[41], (double)h[43], (double)h[44]);
+        fprintf(stderr, "[dbg stats] blend sweep: records kept for certain %.4e, above their pixel's chosen first digit (dropped) %.4e\n", (double)h[45], (double)h[46]);
         (void)hipMemset(dbg_dev, 0, 512);
         { const unsigned long long big[3] = {~0ull, ~0ull, 0ull}; (void)hipMemcpy(dbg_dev + 5, big, 24, hipMemcpyHostToDevice); }
         dbg_out = dbg_dev;

@@ -13,7 +13,13 @@
 #include "common.h"
 #include <mutex>
 
-#define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels
+#define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels: frames per block of a large batch ...
+// ... and of a small one (round 4: blocks of four frames ran 13 -> 21 us (k_pose_fwd) and 21 -> 36 us (k_chain_bwd) from one frame to
+// eight; a frame per block - the kernels take the count from blockDim - keeps a handful of frames at the one-frame latency)
+#ifndef SMALL_BATCH_FRAMES
+#define SMALL_BATCH_FRAMES 256
+#endif
+static inline int frames_per_block(int B) { return B <= SMALL_BATCH_FRAMES ? 1 : FRAMES_PER_BLOCK; }
 
 __device__ __forceinline__ void vertex_upstream(const float *__restrict__ d_verts_b, const float *sDJ,
                                                 const int *__restrict__ colptr, const int *__restrict__ row,
@@ -127,7 +133,7 @@ struct PoseArgs {
 __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) {
     extern __shared__ float smem[];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * FRAMES_PER_BLOCK + wid;
+    const int b = blockIdx.x * (int)(blockDim.x >> 6) + wid;
     const bool live = b < a.B;
     const int J = a.J;
     float *sG = smem + (size_t)wid * J * 15;  // (J,12) world transforms
@@ -587,8 +593,9 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
         a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;
         a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
         a.propagate = in->propagate_scaling;
-        const size_t lds = (size_t)FRAMES_PER_BLOCK * J * 15 * sizeof(float);
-        hipLaunchKernelGGL(k_pose_fwd, dim3(ceil_div(B, FRAMES_PER_BLOCK)), dim3(64 * FRAMES_PER_BLOCK), lds, stream, a);
+        const int fpb = frames_per_block(B);
+        const size_t lds = (size_t)fpb * J * 15 * sizeof(float);
+        hipLaunchKernelGGL(k_pose_fwd, dim3(ceil_div(B, fpb)), dim3(64 * fpb), lds, stream, a);
         SMIL_LAUNCH_CHECK();
     }
     const float *v_skin = out->v_shaped;
@@ -767,7 +774,7 @@ struct ChainBwdArgs {
 __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArgs a) {
     extern __shared__ float smem[];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * FRAMES_PER_BLOCK + wid;
+    const int b = blockIdx.x * (int)(blockDim.x >> 6) + wid;
     const bool live = b < a.B;
     const int J = a.J;
     float *sG = smem + (size_t)wid * J * 30;  // (J,12) world transforms
@@ -918,7 +925,7 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
             __syncthreads();
             if ((int)threadIdx.x < a.nB_used) {
                 float r = 0.f;
-                for (int w = 0; w < FRAMES_PER_BLOCK; ++w) r += smem[(size_t)w * J * 30 + threadIdx.x];
+                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += smem[(size_t)w * J * 30 + threadIdx.x];
                 beta_row_store(a.beta, threadIdx.x, r);
             }
         }
@@ -1530,7 +1537,8 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.jreg_shape = js ? m->jreg_shape : nullptr;
         a.d_beta_frame = js ? dbeta_frame_all : nullptr; a.nB_used = nBu_all;
         a.beta = bsum;
-        const int chain_blocks = ceil_div(B, FRAMES_PER_BLOCK);
+        const int fpb = frames_per_block(B);
+        const int chain_blocks = ceil_div(B, fpb);
         if (beta_shared && js) { a.beta.rows = g->beta_rows + (size_t)rows_used * nBu_all; rows_used += chain_blocks; }
         if (beta_shared && up) { a.beta.n_all = rows_used; a.beta.ctr = m->sync_ctr; }  // (the fused route ends here: this kernel finishes the sum)
         a.d_posefeat = d_posefeat;
@@ -1541,8 +1549,8 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.B = B; a.J = J; a.max_depth = m->max_depth; a.nS = nS;
         a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
         a.propagate = in->propagate_scaling; a.use_scale = use_scale;
-        const size_t lds = (size_t)FRAMES_PER_BLOCK * J * 30 * sizeof(float);
-        hipLaunchKernelGGL(k_chain_bwd, dim3(ceil_div(B, FRAMES_PER_BLOCK)), dim3(64 * FRAMES_PER_BLOCK), lds, stream, a);
+        const size_t lds = (size_t)fpb * J * 30 * sizeof(float);
+        hipLaunchKernelGGL(k_chain_bwd, dim3(chain_blocks), dim3(64 * fpb), lds, stream, a);
         SMIL_LAUNCH_CHECK();
     }
     if (g->d_logscale && in->logscale_shared) {

@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include <atomic>
 #include <mutex>
 
 #define FRAMES_PER_BLOCK 4  // one wavefront per frame in the chain kernels: frames per block of a large batch ...
@@ -1488,7 +1489,11 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         do { \
             if (wide) { \
                 auto kern = k_lbs_bwd_ndc<NBT, false, NDC_BWD_THREADS_WIDE>; \
-                SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                static std::atomic<int> lds_allowed{0};  /* (once per variant and size: not a stream operation, kept out of replays) */ \
+                if (lds_allowed.load() < (int)lds) { \
+                    SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    lds_allowed.store((int)lds); \
+                } \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(NDC_BWD_THREADS_WIDE), lds, stream, a); \
             } else { \
                 hipLaunchKernelGGL((k_lbs_bwd_ndc<NBT, true, NDC_BWD_THREADS>), dim3(grid), dim3(NDC_BWD_THREADS), lds, stream, a); \

@@ -131,6 +131,10 @@ struct PoseArgs {
     int B, J, max_depth, nS, logscale_shared, btrans_shared, propagate, use_scale;
 };
 
+// NJ = joints per lane (J <= 64 NJ: the skin table's 8-bit bone ids bound J by 256).  Round 4: everything a joint reads from memory -
+// rotation, scale, offset to its parent - is requested BEFORE the chain is walked and waits in registers; the level loop touches LDS only.
+// (With the loads inside it every level of the chain was a memory round trip of its own: 13 us for ONE frame.)
+template <int NJ>
 __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) {
     extern __shared__ float smem[];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -141,70 +145,86 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_pose_fwd(PoseArgs a) 
     float *sIS = sG + J * 12;                  // (J,3) inverse scales
     const float *Jr = a.J_rest + (size_t)(a.nS == 1 ? 0 : (live ? b : 0)) * J * 3;
 
+    int dep[NJ], par[NJ];
+    float Rq[NJ][9], Sq[NJ][3], Tq[NJ][3], Jq[NJ][3];
+    const bool jt = live && a.joints_static && a.joints_trans;
+    const float t0 = jt ? a.joints_trans[3 * b] : 0.f, t1 = jt ? a.joints_trans[3 * b + 1] : 0.f, t2 = jt ? a.joints_trans[3 * b + 2] : 0.f;
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const int j = lane + WAVE * q;
+        dep[q] = -1; par[q] = 0;
+        if (live && j < J) {
+            dep[q] = a.depth[j];
+            if (a.Rs_in) {
+                for (int i = 0; i < 9; ++i) Rq[q][i] = a.Rs_in[((size_t)b * J + j) * 9 + i];
+            } else {
+                const float *th = a.theta + ((size_t)b * J + j) * 3;
+                const float *mk = a.theta_mask ? a.theta_mask + 3 * j : nullptr;
+                rodrigues_fwd(mk ? th[0] * mk[0] : th[0], mk ? th[1] * mk[1] : th[1], mk ? th[2] * mk[2] : th[2], Rq[q]);
+            }
+            Sq[q][0] = Sq[q][1] = Sq[q][2] = 1.f;
+            if (a.use_scale) {
+                const float *ls = a.logscale + ((size_t)(a.logscale_shared ? 0 : b) * J + j) * 3;
+                Sq[q][0] = expf(ls[0]); Sq[q][1] = expf(ls[1]); Sq[q][2] = expf(ls[2]);
+            }
+            Jq[q][0] = Jr[3 * j]; Jq[q][1] = Jr[3 * j + 1]; Jq[q][2] = Jr[3 * j + 2];
+            Tq[q][0] = Tq[q][1] = Tq[q][2] = 0.f;
+            if (dep[q] > 0) {
+                const int p = par[q] = a.parents[j];
+                Tq[q][0] = Jq[q][0] - Jr[3 * p]; Tq[q][1] = Jq[q][1] - Jr[3 * p + 1]; Tq[q][2] = Jq[q][2] - Jr[3 * p + 2];
+                if (a.btrans) {
+                    const float *bt = a.btrans + ((size_t)(a.btrans_shared ? 0 : b) * J + j) * 3;
+                    Tq[q][0] += bt[0]; Tq[q][1] += bt[1] * -1.0f; Tq[q][2] += bt[2];  // y flipped (batch_lbs.py:148)
+                }
+            }
+        }
+    }
+
     for (int d = 0; d <= a.max_depth; ++d) {
-        if (live) {
-            for (int j = lane; j < J; j += WAVE) {
-                if (a.depth[j] != d) continue;
-                float R[9];
-                if (a.Rs_in) {
-                    for (int i = 0; i < 9; ++i) R[i] = a.Rs_in[((size_t)b * J + j) * 9 + i];
-                } else {
-                    const float *th = a.theta + ((size_t)b * J + j) * 3;
-                    const float *mk = a.theta_mask ? a.theta_mask + 3 * j : nullptr;
-                    rodrigues_fwd(mk ? th[0] * mk[0] : th[0], mk ? th[1] * mk[1] : th[1], mk ? th[2] * mk[2] : th[2], R);
-                }
-                if (a.Rs)
-                    for (int i = 0; i < 9; ++i) a.Rs[((size_t)b * J + j) * 9 + i] = R[i];
-                float S[3] = {1.f, 1.f, 1.f};
-                if (a.use_scale) {
-                    const float *ls = a.logscale + ((size_t)(a.logscale_shared ? 0 : b) * J + j) * 3;
-                    S[0] = expf(ls[0]); S[1] = expf(ls[1]); S[2] = expf(ls[2]);
-                }
-                sIS[3 * j + 0] = 1.0f / S[0]; sIS[3 * j + 1] = 1.0f / S[1]; sIS[3 * j + 2] = 1.0f / S[2];
-                float G[12];
-                if (d == 0) {
-                    // root: rotation only, own scale never applied (batch_lbs.py:151)
-                    G[0] = R[0]; G[1] = R[1]; G[2] = R[2]; G[3] = Jr[3 * j + 0];
-                    G[4] = R[3]; G[5] = R[4]; G[6] = R[5]; G[7] = Jr[3 * j + 1];
-                    G[8] = R[6]; G[9] = R[7]; G[10] = R[8]; G[11] = Jr[3 * j + 2];
-                } else {
-                    const int p = a.parents[j];
-                    float t[3] = {Jr[3 * j] - Jr[3 * p], Jr[3 * j + 1] - Jr[3 * p + 1], Jr[3 * j + 2] - Jr[3 * p + 2]};
-                    if (a.btrans) {
-                        const float *bt = a.btrans + ((size_t)(a.btrans_shared ? 0 : b) * J + j) * 3;
-                        t[0] += bt[0]; t[1] += bt[1] * -1.0f; t[2] += bt[2];  // y flipped (batch_lbs.py:148)
-                    }
-                    float L[9];
-                    for (int m = 0; m < 3; ++m) {
-                        const float isp = a.propagate ? 1.0f : sIS[3 * p + m];
-                        for (int n = 0; n < 3; ++n) L[3 * m + n] = (isp * R[3 * m + n]) * S[n];
-                    }
-                    const float *P = sG + 12 * p;
-                    for (int m = 0; m < 3; ++m) {
-                        const float p0 = P[4 * m], p1 = P[4 * m + 1], p2 = P[4 * m + 2], p3 = P[4 * m + 3];
-                        G[4 * m + 0] = p0 * L[0] + p1 * L[3] + p2 * L[6];
-                        G[4 * m + 1] = p0 * L[1] + p1 * L[4] + p2 * L[7];
-                        G[4 * m + 2] = p0 * L[2] + p1 * L[5] + p2 * L[8];
-                        G[4 * m + 3] = p0 * t[0] + p1 * t[1] + p2 * t[2] + p3;
-                    }
-                }
-                for (int i = 0; i < 12; ++i) sG[12 * j + i] = G[i];
-                // outputs
-                const size_t o = ((size_t)b * J + j);
-                float *Go = a.G + o * 12, *Ao = a.A + o * 12;
-                const float jx = Jr[3 * j], jy = Jr[3 * j + 1], jz = Jr[3 * j + 2];
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            if (dep[q] != d) continue;
+            const int j = lane + WAVE * q;
+            const float *R = Rq[q], *S = Sq[q], *t = Tq[q];
+            if (a.Rs)
+                for (int i = 0; i < 9; ++i) a.Rs[((size_t)b * J + j) * 9 + i] = R[i];
+            sIS[3 * j + 0] = 1.0f / S[0]; sIS[3 * j + 1] = 1.0f / S[1]; sIS[3 * j + 2] = 1.0f / S[2];
+            float G[12];
+            const float jx = Jq[q][0], jy = Jq[q][1], jz = Jq[q][2];
+            if (d == 0) {
+                // root: rotation only, own scale never applied (batch_lbs.py:151)
+                G[0] = R[0]; G[1] = R[1]; G[2] = R[2]; G[3] = jx;
+                G[4] = R[3]; G[5] = R[4]; G[6] = R[5]; G[7] = jy;
+                G[8] = R[6]; G[9] = R[7]; G[10] = R[8]; G[11] = jz;
+            } else {
+                const int p = par[q];
+                float L[9];
                 for (int m = 0; m < 3; ++m) {
-                    Go[4 * m] = G[4 * m]; Go[4 * m + 1] = G[4 * m + 1]; Go[4 * m + 2] = G[4 * m + 2]; Go[4 * m + 3] = G[4 * m + 3];
-                    Ao[4 * m] = G[4 * m]; Ao[4 * m + 1] = G[4 * m + 1]; Ao[4 * m + 2] = G[4 * m + 2];
-                    // A_t = G_t - G_R J   (batch_lbs.py:192-195)
-                    Ao[4 * m + 3] = G[4 * m + 3] - (G[4 * m] * jx + G[4 * m + 1] * jy + G[4 * m + 2] * jz);
+                    const float isp = a.propagate ? 1.0f : sIS[3 * p + m];
+                    for (int n = 0; n < 3; ++n) L[3 * m + n] = (isp * R[3 * m + n]) * S[n];
                 }
-                a.new_J[o * 3 + 0] = G[3]; a.new_J[o * 3 + 1] = G[7]; a.new_J[o * 3 + 2] = G[11];
-                if (a.joints_static) {
-                    const float t0 = a.joints_trans ? a.joints_trans[3 * b] : 0.f, t1 = a.joints_trans ? a.joints_trans[3 * b + 1] : 0.f,
-                                t2 = a.joints_trans ? a.joints_trans[3 * b + 2] : 0.f;
-                    a.joints_static[o * 3 + 0] = G[3] + t0; a.joints_static[o * 3 + 1] = G[7] + t1; a.joints_static[o * 3 + 2] = G[11] + t2;
+                const float *P = sG + 12 * p;
+                for (int m = 0; m < 3; ++m) {
+                    const float p0 = P[4 * m], p1 = P[4 * m + 1], p2 = P[4 * m + 2], p3 = P[4 * m + 3];
+                    G[4 * m + 0] = p0 * L[0] + p1 * L[3] + p2 * L[6];
+                    G[4 * m + 1] = p0 * L[1] + p1 * L[4] + p2 * L[7];
+                    G[4 * m + 2] = p0 * L[2] + p1 * L[5] + p2 * L[8];
+                    G[4 * m + 3] = p0 * t[0] + p1 * t[1] + p2 * t[2] + p3;
                 }
+            }
+            for (int i = 0; i < 12; ++i) sG[12 * j + i] = G[i];
+            // outputs
+            const size_t o = ((size_t)b * J + j);
+            float *Go = a.G + o * 12, *Ao = a.A + o * 12;
+            for (int m = 0; m < 3; ++m) {
+                Go[4 * m] = G[4 * m]; Go[4 * m + 1] = G[4 * m + 1]; Go[4 * m + 2] = G[4 * m + 2]; Go[4 * m + 3] = G[4 * m + 3];
+                Ao[4 * m] = G[4 * m]; Ao[4 * m + 1] = G[4 * m + 1]; Ao[4 * m + 2] = G[4 * m + 2];
+                // A_t = G_t - G_R J   (batch_lbs.py:192-195)
+                Ao[4 * m + 3] = G[4 * m + 3] - (G[4 * m] * jx + G[4 * m + 1] * jy + G[4 * m + 2] * jz);
+            }
+            a.new_J[o * 3 + 0] = G[3]; a.new_J[o * 3 + 1] = G[7]; a.new_J[o * 3 + 2] = G[11];
+            if (a.joints_static) {
+                a.joints_static[o * 3 + 0] = G[3] + t0; a.joints_static[o * 3 + 1] = G[7] + t1; a.joints_static[o * 3 + 2] = G[11] + t2;
             }
         }
         __syncthreads();
@@ -596,7 +616,12 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
         a.propagate = in->propagate_scaling;
         const int fpb = frames_per_block(B);
         const size_t lds = (size_t)fpb * J * 15 * sizeof(float);
-        hipLaunchKernelGGL(k_pose_fwd, dim3(ceil_div(B, fpb)), dim3(64 * fpb), lds, stream, a);
+        SMIL_REQUIRE(J <= 4 * WAVE, "smil_lbs_forward: J=%d exceeds the 256 joints the pose kernels hold in registers", J);
+        const dim3 pg(ceil_div(B, fpb)), pb(64 * fpb);
+        if (J <= WAVE) hipLaunchKernelGGL(k_pose_fwd<1>, pg, pb, lds, stream, a);
+        else if (J <= 2 * WAVE) hipLaunchKernelGGL(k_pose_fwd<2>, pg, pb, lds, stream, a);
+        else if (J <= 3 * WAVE) hipLaunchKernelGGL(k_pose_fwd<3>, pg, pb, lds, stream, a);
+        else hipLaunchKernelGGL(k_pose_fwd<4>, pg, pb, lds, stream, a);
         SMIL_LAUNCH_CHECK();
     }
     const float *v_skin = out->v_shaped;
@@ -771,7 +796,9 @@ struct ChainBwdArgs {
 };
 
 // Reverse walk of the kinematic chain, one wavefront per frame, LDS accumulators for the gradients
-// that flow child -> parent.
+// that flow child -> parent.  NJ = joints per lane; as in k_pose_fwd everything a joint reads from memory waits in registers before
+// the walk starts (round 4: the walk was a memory round trip per level, 21 us for one frame).
+template <int NJ>
 __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArgs a) {
     extern __shared__ float smem[];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -808,11 +835,46 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
             }
         }
     }
+    int dep[NJ], par[NJ];
+    float Rq[NJ][9], Sq[NJ][3], ISq[NJ][3], Tq[NJ][3], THq[NJ][3];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const int j = lane + WAVE * q;
+        dep[q] = -1; par[q] = 0;
+        if (live && j < J) {
+            const size_t o = fb * J + j;
+            dep[q] = a.depth[j];
+            for (int k = 0; k < 3; ++k) { Sq[q][k] = 1.f; ISq[q][k] = 1.f; Tq[q][k] = 0.f; THq[q][k] = 0.f; }
+            for (int i = 0; i < 9; ++i) Rq[q][i] = 0.f;
+            if (a.d_theta && a.theta) {
+                const float *th = a.theta + o * 3;
+                const float *mk = a.theta_mask ? a.theta_mask + 3 * j : nullptr;
+                THq[q][0] = mk ? th[0] * mk[0] : th[0]; THq[q][1] = mk ? th[1] * mk[1] : th[1]; THq[q][2] = mk ? th[2] * mk[2] : th[2];
+            }
+            if (dep[q] > 0) {
+                const int p = par[q] = a.parents[j];
+                for (int i = 0; i < 9; ++i) Rq[q][i] = a.Rs[o * 9 + i];
+                if (ls) {
+                    Sq[q][0] = expf(ls[3 * j]); Sq[q][1] = expf(ls[3 * j + 1]); Sq[q][2] = expf(ls[3 * j + 2]);
+                    if (!a.propagate) {
+                        ISq[q][0] = 1.0f / expf(ls[3 * p]); ISq[q][1] = 1.0f / expf(ls[3 * p + 1]); ISq[q][2] = 1.0f / expf(ls[3 * p + 2]);
+                    }
+                }
+                Tq[q][0] = Jr[3 * j] - Jr[3 * p]; Tq[q][1] = Jr[3 * j + 1] - Jr[3 * p + 1]; Tq[q][2] = Jr[3 * j + 2] - Jr[3 * p + 2];
+                if (a.btrans) {
+                    const float *bt = a.btrans + ((size_t)(a.btrans_shared ? 0 : fb) * J + j) * 3;
+                    Tq[q][0] += bt[0]; Tq[q][1] -= bt[1]; Tq[q][2] += bt[2];
+                }
+            }
+        }
+    }
     __syncthreads();
     for (int d = a.max_depth; d >= 0; --d) {
-        if (live) {
-            for (int j = lane; j < J; j += WAVE) {
-                if (a.depth[j] != d) continue;
+        {
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                if (dep[q] != d) continue;
+                const int j = lane + WAVE * q;
                 const size_t o = fb * J + j;
                 float dG[12];
                 for (int i = 0; i < 12; ++i) dG[i] = sdG[12 * j + i];
@@ -823,21 +885,8 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                         sdJ[3 * j + m] += dG[4 * m + 3];
                     }
                 } else {
-                    const int p = a.parents[j];
-                    float R[9];
-                    for (int i = 0; i < 9; ++i) R[i] = a.Rs[o * 9 + i];
-                    float S[3] = {1.f, 1.f, 1.f}, isp[3] = {1.f, 1.f, 1.f};
-                    if (ls) {
-                        S[0] = expf(ls[3 * j]); S[1] = expf(ls[3 * j + 1]); S[2] = expf(ls[3 * j + 2]);
-                        if (!a.propagate) {
-                            isp[0] = 1.0f / expf(ls[3 * p]); isp[1] = 1.0f / expf(ls[3 * p + 1]); isp[2] = 1.0f / expf(ls[3 * p + 2]);
-                        }
-                    }
-                    float t[3] = {Jr[3 * j] - Jr[3 * p], Jr[3 * j + 1] - Jr[3 * p + 1], Jr[3 * j + 2] - Jr[3 * p + 2]};
-                    if (a.btrans) {
-                        const float *bt = a.btrans + ((size_t)(a.btrans_shared ? 0 : fb) * J + j) * 3;
-                        t[0] += bt[0]; t[1] -= bt[1]; t[2] += bt[2];
-                    }
+                    const int p = par[q];
+                    const float *R = Rq[q], *S = Sq[q], *isp = ISq[q], *t = Tq[q];
                     float L[9];
                     for (int m = 0; m < 3; ++m)
                         for (int n = 0; n < 3; ++n) L[3 * m + n] = (isp[m] * R[3 * m + n]) * S[n];
@@ -889,10 +938,8 @@ __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArg
                 if (a.d_Rs_out)
                     for (int i = 0; i < 9; ++i) a.d_Rs_out[o * 9 + i] = dR[i];
                 if (a.d_theta && a.theta) {
-                    const float *th = a.theta + o * 3;
-                    const float *mk = a.theta_mask ? a.theta_mask + 3 * j : nullptr;
                     float dth[3];
-                    rodrigues_bwd(mk ? th[0] * mk[0] : th[0], mk ? th[1] * mk[1] : th[1], mk ? th[2] * mk[2] : th[2], dR, dth);
+                    rodrigues_bwd(THq[q][0], THq[q][1], THq[q][2], dR, dth);
                     a.d_theta[o * 3] = dth[0]; a.d_theta[o * 3 + 1] = dth[1]; a.d_theta[o * 3 + 2] = dth[2];
                 }
             }
@@ -1555,7 +1602,12 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.logscale_shared = in->logscale_shared; a.btrans_shared = in->btrans_shared;
         a.propagate = in->propagate_scaling; a.use_scale = use_scale;
         const size_t lds = (size_t)fpb * J * 30 * sizeof(float);
-        hipLaunchKernelGGL(k_chain_bwd, dim3(chain_blocks), dim3(64 * fpb), lds, stream, a);
+        SMIL_REQUIRE(J <= 4 * WAVE, "smil_lbs_backward: J=%d exceeds the 256 joints the chain kernels hold in registers", J);
+        const dim3 cg(chain_blocks), cb(64 * fpb);
+        if (J <= WAVE) hipLaunchKernelGGL(k_chain_bwd<1>, cg, cb, lds, stream, a);
+        else if (J <= 2 * WAVE) hipLaunchKernelGGL(k_chain_bwd<2>, cg, cb, lds, stream, a);
+        else if (J <= 3 * WAVE) hipLaunchKernelGGL(k_chain_bwd<3>, cg, cb, lds, stream, a);
+        else hipLaunchKernelGGL(k_chain_bwd<4>, cg, cb, lds, stream, a);
         SMIL_LAUNCH_CHECK();
     }
     if (g->d_logscale && in->logscale_shared) {

@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     // per tile: entries << 32 | cost (counted), or a touched-tile bitmap when the image has too many tiles; behind it the tiles'
     // list cursors
     extern __shared__ __align__(16) unsigned long long tcnt64[];
+    TSETUP_INIT
     const int n = blockIdx.x;
     const int V = q.V, F = q.F, S = q.S, tiles_x = q.tiles_x;
     // the fused entry point's per-image initialisation rides along (saves a 100 MB memset and a copy launch per iteration):
@@ -320,6 +321,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     if (threadIdx.x == 0) { s_ncut = 0u; s_unclipped = 0u; }
     for (int i = threadIdx.x; i < FT - F; i += blockDim.x) q.tbox[(size_t)n * FT + F + i] = 0x0000FFFFu;  // (ids F .. FT-1: empty unless a cut face fills them)
     __syncthreads();
+    TSETUP(1)
     float *const xv_n = q.clip.xv + (size_t)n * CLIP_VX * 3;
     int *const xf_n = q.clip.xf + (size_t)n * CLIP_FX * 3;
     // one face (an original one or the front part of a cut one): validity, blurred pixel box -> tile box, cost / entry per tile
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
                         if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it; one list entry
                             const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
                             const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
-                            atomicAdd(&tcnt64[t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));
+                            HOOK_SETUP_COUNT(atomicAdd(&tcnt64[t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));)
                         } else {
                             atomicOr(&tbits[t >> 5], 1u << (t & 31));
                         }
@@ -411,6 +413,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
             q.gbox[(size_t)n * n_groups + grp] = (uint32_t)gx0 | ((uint32_t)gy0 << 8) | ((uint32_t)gx1 << 16) | ((uint32_t)gy1 << 24);
     }
     __syncthreads();
+    TSETUP(2)
     // the faces that cross the plane: cut c owns the new vertices 2c, 2c + 1 and the front-part faces FP + 2c, FP + 2c + 1
     const uint32_t n_cut = min(s_ncut, (uint32_t)CLIP_CUTS);
     for (uint32_t c = threadIdx.x; c < n_cut; c += blockDim.x) {
@@ -446,6 +449,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         }
     }
     __syncthreads();  // the front parts' tile boxes are in place (written by whichever thread cut their face)
+    TSETUP(3)
     if (threadIdx.x < CLIP_FX) {  // their group boxes
         const uint32_t box = n_cut ? q.tbox[(size_t)n * FT + FP + threadIdx.x] : 0x0000FFFFu;
         int gx0 = box & 0xFF, gy0 = (box >> 8) & 0xFF, gx1 = (box >> 16) & 0xFF, gy1 = box >> 24;
@@ -466,10 +470,21 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     // sqrt(sigma): a kept record of probability p = sigmoid(-+r^2 / sigma) adds at most 2 r p alpha |g| / sigma to an end point,
     // alpha <= 1 - p, and r p (1 - p) <= 0.197 sqrt(sigma) for every r (maximum of sqrt(u) s(u) (1 - s(u)), u = r^2 / sigma);
     // a face has at most its blurred pixel box of records; a vertex has at most max_valence faces.
-    if (my_px) atomicMax(&s_maxpx, my_px);
-    if (my_zext > 0.f) atomicMax(&s_zext, __float_as_uint(my_zext));  // (non-negative floats order like their bit patterns)
-    if (my_straddle) atomicAdd(&s_straddle, my_straddle);
+    {  // over the wave first, then one LDS atomic per wave (1 024 lanes on one LDS word took 16 k cycles of a one-image launch's 103 k)
+        uint32_t zb = __float_as_uint(my_zext);  // (non-negative floats order like their bit patterns)
+        for (int o = 32; o > 0; o >>= 1) {
+            my_px = max(my_px, (uint32_t)__shfl_xor((int)my_px, o, WAVE));
+            zb = max(zb, (uint32_t)__shfl_xor((int)zb, o, WAVE));
+            my_straddle += (uint32_t)__shfl_xor((int)my_straddle, o, WAVE);
+        }
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            if (my_px) atomicMax(&s_maxpx, my_px);
+            if (zb) atomicMax(&s_zext, zb);
+            if (my_straddle) atomicAdd(&s_straddle, my_straddle);
+        }
+    }
     __syncthreads();
+    TSETUP(4)
     if (threadIdx.x == 0 && q.img_bound) {
         const float bound = 1.02f * 0.4f * (float)q.max_valence * (float)s_maxpx;
         q.img_bound[n] = bound;
@@ -506,12 +521,14 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     const uint32_t incl = (uint32_t)wave_scan_add((int)my_ents);
     if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) s_ents[threadIdx.x / WAVE] = incl;
     __syncthreads();
+    TSETUP(5)
     uint32_t ent_off = incl - my_ents;
     for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) ent_off += s_ents[w];
     if (threadIdx.x == blockDim.x - 1) s_binned = (counted && q.list_cap != 0u && ent_off + my_ents <= q.list_cap) ? 1u : 0u;
     const int part = n % N_PARTS;
     if (threadIdx.x < N_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&q.ctr->n_class[part][threadIdx.x], s_cnt[threadIdx.x]) : 0u;
     __syncthreads();
+    TSETUP(6)
     const bool binned = s_binned != 0u;
 #pragma unroll
     for (int k = 0; k < N_CLASSES; ++k) off[k] += s_base[k];
@@ -536,6 +553,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     }
     if (!binned) return;  // (block-uniform)
     __syncthreads();
+    TSETUP(7)
     // pass 2: every face to the lists of the tiles of its box (its own tile box and depth range come back from L1 / L2)
     uint2 *const lists = q.lists + (size_t)n * q.list_cap;
     // (consecutive faces cover the same tiles: their entries take consecutive slots, so a wave's stores land in few cache lines;
@@ -548,6 +566,8 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         for (int ty = ty0; ty <= ty1; ++ty)
             for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
     }
+    TSETUP(8)
+    TSETUP_REPORT
 }
 
 // ---------------------------------------------------------------------------------------------

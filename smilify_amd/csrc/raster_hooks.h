@@ -23,4 +23,8 @@
 #define HOOK_EXTRA_VALU(pc)
 #define HOOK_ARGS_FIELDS
 #define HOOK_HOST_LAUNCH_SETUP(a, stream)
+#define TSETUP_INIT
+#define TSETUP(k)
+#define TSETUP_REPORT
+#define HOOK_SETUP_COUNT(stmt) stmt
 #endif

@@ -109,3 +109,25 @@ static inline void raster_dbg_report(unsigned long long *&dbg_out) {
 #else
 #define HOOK_HOST_LAUNCH_SETUP(a, stream) a.dbg = nullptr; a.stop_after = 99; a.force_split = -1; HOOK_HOST_EXPERIMENT(a, stream)
 #endif
+
+// -DDBG_SETUP_TIMERS: marks inside k_raster_setup (block 0, thread 0; device printf at the end of the kernel): where one image's
+// setup time goes.  Timing experiments only.
+#ifdef DBG_SETUP_TIMERS
+#define TSETUP_INIT long long tsu_[12]; for (int k_ = 0; k_ < 12; ++k_) tsu_[k_] = 0; tsu_[0] = clock64();
+#define TSETUP(k) if (blockIdx.x == 0 && threadIdx.x == 0) tsu_[k] = clock64();
+#define TSETUP_REPORT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[dbg setup] cycles after start: zero+init %lld  pass1 %lld  cuts %lld  bounds %lld  classes+prefix %lld  global atomics %lld  items %lld  pass2 %lld\n", \
+    tsu_[1] - tsu_[0], tsu_[2] - tsu_[0], tsu_[3] - tsu_[0], tsu_[4] - tsu_[0], tsu_[5] - tsu_[0], tsu_[6] - tsu_[0], tsu_[7] - tsu_[0], tsu_[8] - tsu_[0]);
+#else
+#define TSETUP_INIT
+#define TSETUP(k)
+#define TSETUP_REPORT
+#endif
+
+// -DABL_SETUP_NOCOUNT: k_raster_setup without the per-(face, tile) LDS atomics of its counting pass (garbage work lists: timing only)
+#ifdef ABL_SETUP_NOCOUNT
+#define HOOK_SETUP_COUNT(stmt)
+#elif defined(ABL_SETUP_COUNT32)  // a 32-bit add of the entry alone (no cost: garbage classes, timing only)
+#define HOOK_SETUP_COUNT(stmt) atomicAdd(reinterpret_cast<uint32_t *>(&tcnt64[t]) + 1, 1u);
+#else
+#define HOOK_SETUP_COUNT(stmt) stmt
+#endif

@@ -410,10 +410,12 @@ struct SkinProjectArgs {
     int nnz_lds;                        // regressor entries staged in LDS (all of them, or 0: read from memory)
 };
 
-__global__ void __launch_bounds__(FWD_FUSED_THREADS, FWD_MIN_WAVES) k_skin_project_fwd(SkinProjectArgs a) {
+// NT threads per frame: FWD_FUSED_THREADS (two workgroups per CU), or twice that for a batch that leaves CUs idle anyway (round 4)
+template <int NT>
+__global__ void __launch_bounds__(NT, FWD_MIN_WAVES) k_skin_project_fwd(SkinProjectArgs a) {
     extern __shared__ float smem[];
     const int V = a.V, J = a.J, views = a.cam.views;
-    constexpr int NT = FWD_FUSED_THREADS, NW = NT / WAVE;
+    constexpr int NW = NT / WAVE;
     float *vL = smem;                              // (V,3) posed vertices of the frame: what the joint regressor gathers from (models with
                                                    // static joints keep none: any mesh size fits - round 4, the mouse)
     float *sA = smem + (((a.regress ? 3 * V : 0) + 3) & ~3);  // (J,12)
@@ -649,7 +651,10 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
         const size_t lds = fwd_fused_lds_bytes(m, cam->views);
         const int cus = device_cu_count();
         const int per_cu = std::max(1, std::min(FWD_MIN_WAVES / 2, (int)(device_limits().lds_cu / lds)));
-        hipLaunchKernelGGL(k_skin_project_fwd, dim3(std::min(B, std::max(1, cus) * per_cu)), dim3(FWD_FUSED_THREADS), lds, stream, a);
+        if (B <= std::max(1, cus))  // at most a frame per CU: 1024 threads per frame, fewer vertices (and round trips) per thread
+            hipLaunchKernelGGL(k_skin_project_fwd<2 * FWD_FUSED_THREADS>, dim3(B), dim3(2 * FWD_FUSED_THREADS), lds, stream, a);
+        else
+            hipLaunchKernelGGL(k_skin_project_fwd<FWD_FUSED_THREADS>, dim3(std::min(B, std::max(1, cus) * per_cu)), dim3(FWD_FUSED_THREADS), lds, stream, a);
         SMIL_LAUNCH_CHECK();
         return SMIL_OK;
     }
@@ -1439,8 +1444,8 @@ struct NdcUpstream {
 
 #define NDC_BWD_THREADS_WIDE 1024  // the one-workgroup-per-CU form for meshes whose vertex state does not fit twice
 // vp_lds: the skinned-from vertices are staged next to the gradient (24 instead of 12 bytes per vertex)
-static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views, bool vp_lds) {
-    const int waves = (vp_lds ? NDC_BWD_THREADS : NDC_BWD_THREADS_WIDE) / WAVE;
+static size_t ndc_bwd_lds_bytes(const SmilModel *m, int views, bool vp_lds, int threads = 0) {
+    const int waves = (threads ? threads : (vp_lds ? NDC_BWD_THREADS : NDC_BWD_THREADS_WIDE)) / WAVE;
     return ((size_t)(vp_lds ? 6 : 3) * m->V + 4 + 15 * m->J + 3 * m->bone_slots + 17 * views + waves * 12) * sizeof(float);
 }
 // 1: two workgroups of 512 threads per CU, all vertex state in LDS; 2: one workgroup of 1024 threads with the vertex gradient in LDS
@@ -1526,9 +1531,12 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int form = ndc_bwd_form(m, up->cam->views);
         SMIL_REQUIRE(form != 0, "smil_lbs_backward_ndc: V=%d does not fit the fused kernel's LDS (ask smil_lbs_backward_ndc_supported first)", V);
         const bool wide = form == 2;
-        const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views, !wide);
         const int cus = device_cu_count();
-        const int per_cu = wide ? 1 : std::max(1, std::min(2, (int)(device_limits().lds_cu / lds)));
+        // a batch that leaves CUs idle anyway (at most a frame per CU) takes 1024 threads per frame: fewer vertices per thread, fewer
+        // dependent memory round trips per phase (round 4: 25 us for one frame were ~11 round trips)
+        const bool few = !wide && B <= std::max(1, cus);
+        const size_t lds = ndc_bwd_lds_bytes(m, up->cam->views, !wide, few ? NDC_BWD_THREADS_WIDE : 0);
+        const int per_cu = (wide || few) ? 1 : std::max(1, std::min(2, (int)(device_limits().lds_cu / lds)));
         const int grid = std::min(B, std::max(1, cus) * per_cu);
         a.beta = bsum;
         if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; }
@@ -1538,6 +1546,14 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
                 auto kern = k_lbs_bwd_ndc<NBT, false, NDC_BWD_THREADS_WIDE>; \
                 static std::atomic<int> lds_allowed{0};  /* (once per variant and size: not a stream operation, kept out of replays) */ \
                 if (lds_allowed.load() < (int)lds) { \
+                    SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    lds_allowed.store((int)lds); \
+                } \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(NDC_BWD_THREADS_WIDE), lds, stream, a); \
+            } else if (few) { \
+                auto kern = k_lbs_bwd_ndc<NBT, true, NDC_BWD_THREADS_WIDE>; \
+                static std::atomic<int> lds_allowed{0}; \
+                if (lds > 64 * 1024 && lds_allowed.load() < (int)lds) { \
                     SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                     lds_allowed.store((int)lds); \
                 } \

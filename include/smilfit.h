@@ -221,7 +221,7 @@ size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
  * stream): [0] faces that cross z_clip (one or two vertices nearer than znear / 2): cut at the plane like pytorch3d's
  * clip_faces, which p3d_renderer.py:36-47 leaves on - the front part is rendered as one or two extra triangles whose new
  * vertices hand their gradient back to the cut edge's end points (interpolation coefficients held constant; no gradient on
- * the depths).  [1] touched 8x8 tiles.  [2] faces that cross the plane beyond the capacity of the per-image clip tables - 256 cut faces per
+ * the depths).  [1] touched 8x8 tiles.  [2] faces that cross the plane beyond the capacity of the per-image clip tables - 1024 cut faces per
  * image, each with up to two front-part triangles and two new vertices: rendered whole, or not at all when a vertex is nearer than 1e-8 - the one case in which a call still deviates.
  * [3] reserved. */
 int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream, uint32_t *out4);

@@ -663,7 +663,7 @@ class SMALFitter(nn.Module):
         """Faces of the most recent silhouette launch with one or two vertices nearer than ``z_clip = znear / 2``.  They are cut
         at the plane like pytorch3d's ``clip_faces`` does (left on by the reference's settings, p3d_renderer.py:36-47): the
         part in front is rendered.  A non-zero count still deserves a look - the mesh has reached the camera - so the first
-        one warns; faces beyond the per-image clip tables (256 cut faces per image) are rendered unclipped and always
+        one warns; faces beyond the per-image clip tables (1024 cut faces per image) are rendered unclipped and always
         reported.  Synchronises the stream (call it between stages, not per iteration)."""
         if self.device_model._ws is None:
             return 0

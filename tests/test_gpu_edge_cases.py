@@ -264,7 +264,7 @@ def test_sliced_launches_equal_one_launch(tables, monkeypatch):
     got_fwd = eng.silhouette_forward(dm, ndc, S)
     torch.testing.assert_close(got_fwd, ref_fwd, rtol=0, atol=1e-6)
     torch.testing.assert_close(got[2], ref[2], rtol=0, atol=1e-6)
-    torch.testing.assert_close(got[0], ref[0], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got[0], ref[0], rtol=1e-5, atol=1e-6)  # (an image's loss is summed over its tiles by float atomics)
     assert dm._last_slice == 3  # (the second pair of calls really was cut: 3 + 3 + 1 images)
     # (seven images accumulate in float atomics: order noise of the largest contributions shows on components that cancel)
     torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=2e-6 * float(ref[1].abs().max()))

@@ -46,7 +46,7 @@ if args.quick:
     print(f"images {N}  time/launch {dt*1e3:.3f} ms  {dt/N*1e6:.2f} us/image  [SMIL_RESIDENT={os.environ.get('SMIL_RESIDENT')} SMIL_WRAP={os.environ.get('SMIL_WRAP')}]")
     sys.exit(0)
 ws = dm._ws
-FT = (dm.F + 63) // 64 * 64 + 512  # rows of the per-image face tables (raster.hip: faces_padded(F) + CLIP_FX)
+FT = (dm.F + 63) // 64 * 64 + 2048  # rows of the per-image face tables (raster.hip: faces_padded(F) + CLIP_FX)
 off = ((N * FT * 4 + 255) // 256) * 256
 ctr = ws[off:off + 128].view(torch.int32).cpu().numpy().reshape(8, 4).sum(0)  # (partition, cost class) counters
 n_work = int(ctr[:4].sum())

@@ -167,6 +167,7 @@ struct RasterArgs {
     // entries per workgroup
     Rec3 *srec;
     int list_stride;         // entries of slist / slist2 per workgroup
+    HOOK_ARGS_FIELDS         // (instrumented builds: timer buffer)
 };
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
@@ -756,7 +757,10 @@ struct alignas(16) TileLds {
     uint16_t bstart[1 << SEL_BITS];// first list position of every depth bucket of the near-to-far list
     uint32_t unit, kmin, knear, list_total, rec_count, cmp_count, overflow, walked, rmax2_bits, pad_[3];
 };
-constexpr int R_LDS = ((160 * 1024 / TILE_WG_PER_CU - 512 - (int)sizeof(TileLds)) / 12) / WAVE * WAVE;
+#ifndef LDS_SLACK
+#define LDS_SLACK 512
+#endif
+constexpr int R_LDS = ((160 * 1024 / TILE_WG_PER_CU - LDS_SLACK - (int)sizeof(TileLds)) / 12) / WAVE * WAVE;
 static_assert(R_LDS >= 1024, "no room for records");
 struct alignas(16) TileShared {
     TileLds t;
@@ -963,6 +967,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
     unsigned int xcc;  // the XCD this workgroup runs on: which partition it drains first
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= (unsigned int)(N_PARTS - 1);
+    TT_INIT
 
     // a record by its index in the tile's stream: the first R_LDS live in LDS, the excess in the workgroup's spill stream
     auto load_rec = [&](uint32_t idx) -> RecV {
@@ -993,6 +998,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                                : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
         const uint4 it = items[item_at];
         const uint32_t code = it.x;
+        TT(0)
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);  // (lane = pixel, in every wave)
@@ -1041,6 +1047,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
             kmin = sh.kmin; kmax = sh.knear; list_total = (int)sh.list_total;
         }
         if (list_total <= 0) continue;  // (workgroup-uniform; a queued tile owns at least one face)
+        TT(1)
         const bool may_truncate = list_total > K;
         // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
         // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
@@ -1090,6 +1097,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
             }
         }
 
+        TT(2)
         // Sub-tiles: runs of `span` pixels (lane order), only for tiles whose records would overflow even the spill stream.
         // Start from an estimate (a quarter of the pairs pixel x face exist) and halve whenever pass 1 finds that the records
         // do not fit; span * list_total <= REC_CAP always fits.
@@ -1110,6 +1118,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
             if (tid < 8) sh.progress[tid] = tid < NW ? tid : 0x7FFFFFFF;
             if (tid == 0) { sh.rec_count = 0u; sh.overflow = 0u; sh.walked = 0u; sh.cmp_count = 0u; sh.rmax2_bits = 0u; }
             __syncthreads();
+            TT(3)
 
             // ---------------- pass 1: every pair inside a face's pixel box, once --------------------------------
             // Wave w walks chunks w, w + NW, ... of the list.  Pixels that cannot keep any further record ("closed"): they
@@ -1173,6 +1182,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                     const int off = incl - cf;          // first pair of this face in the chunk's pair list
                     const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
                     packed |= off;                      // off <= DCHUNK * 32
+                    TSTAT(2, 2 * n_pairs)
                     // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
                     // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
                     // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
@@ -1270,12 +1280,15 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                     atomicMax(&sh.walked, (uint32_t)walked_end);
                 }
             }
+            TT(4)
             __syncthreads();  // also: spilled records of other waves are visible from here on
+            TT(5)
             if (sh.overflow) {  // workgroup-uniform: try again with half the pixels
                 span >>= 1;
                 continue;
             }
             const int n_rec = (int)sh.rec_count;
+            if (wv == 0) { TSTAT(0, 1) TSTAT(1, list_total) TSTAT(3, n_rec) TSTAT(5, max(n_rec - R_LDS, 0)) }
             const int n_walked = (int)sh.walked;  // list positions [0, n_walked) may own records
 
             // All records of the (sub-)tile, RU per thread and step: the ones in LDS, then the spilled ones.  body(r, first index,
@@ -1328,6 +1341,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
             if (any_trunc)
                 for (int i_ = tid; i_ < HIST_WORDS; i_ += NT) sh.hist[i_] = 0u;
             __syncthreads();
+            TT(6)
             // One sweep over all records.  A record of a pixel that is not truncated, or whose first digit is below the
             // pixel's chosen one, is kept for certain: its log goes to the pixel's sum.  One inside the chosen digit has its
             // index appended to the selection list and its second digit counted; one above it is dropped.
@@ -1373,8 +1387,10 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                 if (lane == 0 && rmax2 > 0.f) atomicMax(&sh.rmax2_bits, __float_as_uint(rmax2));
             }
             __syncthreads();
+            TT(7)
             if (any_trunc) {
                 const int n_cmp_all = (int)sh.cmp_count;
+                if (wv == 0) { TSTAT(4, n_cmp_all) }
                 const bool walk_all = n_cmp_all > CMP_CAP;          // the list overflowed: the sweeps below walk every record
                 const int n_cmp = walk_all ? n_rec : n_cmp_all;
                 // a sweep over the selection list, two records per thread and step; fn(record, valid)
@@ -1486,6 +1502,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                 });
                 __syncthreads();
             }
+            TT(8)
             const double plog_px = sh.plog[lane];
             const float alpha = exp2f((float)plog_px);
 
@@ -1519,6 +1536,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
             // the fixed-point bound below either, or a tile of empty pixels sets the resolution for its one contributing pixel)
             const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS) && (plog_px != 0.0);
             const bool any_split = __ballot(tie_cut != 0x7FFFFFFF) != 0ull;  // a pixel whose tie group at the K-th depth is cut by face id
+            TT(9)
             if (MODE != MODE_FWD && __ballot(active) != 0ull) {  // (workgroup-uniform: every wave holds the same per-pixel values)
                 float *dn = a.d_ndc + (size_t)n * a.V * 2;
                 // Fixed point for the LDS accumulators.  One accumulator component receives at most one record per pixel,
@@ -1561,6 +1579,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                         }
                     }
                     __syncthreads();
+                    TT(10)
                     for_records([&](const RecV (&r)[RU], int g0, int end) {
                         float4 pg[RU];
                         float2 pa[RU], pb[RU], pc[RU];
@@ -1620,6 +1639,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                         }
                     });
                     __syncthreads();
+                    TT(11)
                     // flush: unpack, one global atomic per touched vertex component
 #pragma unroll
                     for (int s = 0; s < WSLOTS; ++s) {
@@ -1643,10 +1663,13 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                     }
                 }
             }
+            TT(12)
             p_lo += span;
         }
     }
+    TT(13)
     }  // next partition
+    TT_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1784,6 +1807,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
+    HOOK_HOST_LAUNCH_SETUP(a, stream)
     a.sil = nullptr; a.grad_sil = nullptr; a.target = nullptr; a.target_u8 = nullptr; a.pix_scale = nullptr; a.loss_img = nullptr;
     a.d_ndc = nullptr;
     return SMIL_OK;

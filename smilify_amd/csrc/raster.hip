@@ -753,7 +753,7 @@ struct alignas(16) TileLds {
     float2 pixt[WAVE];             // pixel centre (px, py) in NDC
     uint2 psel[WAVE];              // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
     uint32_t bcnt[1 << SEL_BITS];  // sort: bucket counters / cursors
-    int progress[8];               // pass 1: wave w has finished all its chunks below this chunk index
+    int progress[(NW + 3) / 4 * 4];  // pass 1: wave w has finished all its chunks below this chunk index
     uint16_t bstart[1 << SEL_BITS];// first list position of every depth bucket of the near-to-far list
     uint32_t unit, kmin, knear, list_total, rec_count, cmp_count, overflow, walked, rmax2_bits, pad_[3];
 };
@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
             }
             if (may_truncate)
                 for (int i_ = tid; i_ < HIST_WORDS; i_ += NT) sh.hist[i_] = 0u;
-            if (tid < 8) sh.progress[tid] = tid < NW ? tid : 0x7FFFFFFF;
+            if (tid < (NW + 3) / 4 * 4) sh.progress[tid] = tid < NW ? tid : 0x7FFFFFFF;
             if (tid == 0) { sh.rec_count = 0u; sh.overflow = 0u; sh.walked = 0u; sh.cmp_count = 0u; sh.rmax2_bits = 0u; }
             __syncthreads();
             TT(3)
@@ -1147,8 +1147,13 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                 for (int c0 = c_first; c0 < list_total; c0 += CSTRIDE) {
                     if (may_truncate) {
                         // every chunk below `done` has been finished by its wave
-                        const int4 pa = *reinterpret_cast<const int4 *>(&sh.progress[0]), pb = *reinterpret_cast<const int4 *>(&sh.progress[4]);
-                        const int done = __builtin_amdgcn_readfirstlane(min(min(min(pa.x, pa.y), min(pa.z, pa.w)), min(min(pb.x, pb.y), min(pb.z, pb.w))));
+                        int done_ = 0x7FFFFFFF;
+#pragma unroll
+                        for (int q_ = 0; q_ < (NW + 3) / 4; ++q_) {
+                            const int4 pa = *reinterpret_cast<const int4 *>(&sh.progress[4 * q_]);
+                            done_ = min(done_, min(min(pa.x, pa.y), min(pa.z, pa.w)));
+                        }
+                        const int done = __builtin_amdgcn_readfirstlane(done_);
                         const int done_pos = done >= 0x7FFFFFFF / DCHUNK ? 0x7FFFFFFF : done * DCHUNK;
                         // digit of the first unfinished list position = number of buckets that start at or before it, minus one
                         const int d0 = __popcll(__ballot(lane < (1 << b1) && (int)sh.bstart[lane] <= done_pos)) - 1;

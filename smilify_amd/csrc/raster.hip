@@ -61,13 +61,35 @@
 #ifndef SEL_BITS
 #define SEL_BITS 5
 #endif
-//      SEL_BITS            // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel); the first digit - the one
-                            // pass 1 counts and the closing rule works with - has the same width and layout
+//      SEL_BITS            // radix-select digit width (two 16-bit counts per LDS word, 16 words per pixel)
+#ifndef SEL1_BITS
+#define SEL1_BITS 6
+#endif
+//      SEL1_BITS           // width of the FIRST digit, the one pass 1 counts and the closing rule works with: 64 buckets in the same
+                            // 16 words per pixel as four 8-bit counts that stop at SAT8 (a count only ever matters up to K <= 128)
+#define SAT8 160u           // a byte takes no further increment from here on; at most 63 more arrive with the instruction that crosses it
+#ifndef DGROUP
+#define DGROUP 4            // 64-record rows per buffer in the dense walks (two buffers)
+#endif
+#ifndef KGROUP
+#define KGROUP 4            // 64-key rows per buffer in the selection sweeps (two buffers)
+#endif
+#ifndef SELR
+#define SELR 6              // compact records a lane holds once the selection runs in registers (the stream is then at most SELR * 64 long)
+#endif
 #ifndef REC_CAP
-#define REC_CAP 65536       // pair records one (sub-)tile may produce (the first R_LDS of them live in LDS, the rest in the spill stream)
+#define REC_CAP 65536       // pair records one (sub-)tile may produce
 #endif
 #define REC_PAD 64          // slack so that a clamped read stays inside the allocation
+#ifndef RESIDENT_PER_CU
+#define RESIDENT_PER_CU 16
+#endif
+//      RESIDENT_PER_CU     // single-wave workgroups per CU: what 128 VGPRs and 9.9 KB of LDS per workgroup allow (measured 10 ... 14: every
+                            // further workgroup still shortens the launch)
 
+#ifndef WAVES_PER_SIMD
+#define WAVES_PER_SIMD 4     // what the tile kernel's register budget is set for: RESIDENT_PER_CU / 4
+#endif
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
 // Instrumentation hooks (phase timers, work counters, cut-off / wrap experiments): empty in libsmilfit.so.  `make variant` builds the
@@ -84,9 +106,14 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 #ifndef PACKED_MIN_IMAGES
 #define PACKED_MIN_IMAGES 64  // from this many images per launch the fused entry point packs its gradient atomics (see image_fx_scale)
 #endif
-#define CLASS_T0 65536
+#ifndef CLASS_T0
+#define CLASS_T0 65536        // class 0 can be dealt out in pieces (SPLIT0_LOG)
+#endif
 #define CLASS_T1 16384
 #define CLASS_T2 4096
+#ifndef SPLIT0_LOG
+#define SPLIT0_LOG 0          // log2 of the pieces every class-0 tile is dealt out in (0: whole; with near-to-far lists and closing the
+#endif                        // tiles with the longest lists finish early, and pieces only repeat their list walk: measured 2 -> 0: mouse -9 %)
 #define COUNT_TILES_MAX 4096  // per-tile cost / entry counts and list cursors live in LDS (12 bytes per tile); larger images (S > 512) queue
                               // everything in the last class and build their lists in the tile kernel
 // XCD-aware dealing.  Each of the 8 XCDs of an MI355X has its own 4 MB L2, and the tiles of one image read the same
@@ -102,7 +129,11 @@ struct RasterCounters {
     unsigned int unclipped;   // ... except these: beyond the per-image clip tables, rendered whole or dropped
 };
 
-struct Rec3 { uint32_t a, b, c; };  // one 12-byte record of the spill stream: loaded / stored as one dwordx3
+struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
+// Per list position of the current tile, left by pass 1 (which has them in registers) for pass 3: the face's projected vertices
+// and its vertex ids.  Pass 3 used to fetch them per group of 64 faces through the chain list -> face -> vertex: three dependent
+// memory round trips per group and 28 % of pass 3 (profiles/r4_pass3_timers.txt).  Vertices as three float2 arrays, see stage_faces.
+struct TriIds { int a, b, c; };
 
 // clip_faces (pytorch3d renderer/mesh/clip.py, as MeshRasterizer applies it with z_clip_value = znear / 2; the reference leaves that
 // default on, p3d_renderer.py:36-47): a face with one or two vertices nearer than z_clip is cut at the plane and its front part
@@ -161,13 +192,20 @@ struct RasterArgs {
     const uint2 *lists;      // (N, list_cap) tile lists binned by the setup kernel: {face id, bits of its nearest vertex depth}
     uint32_t list_cap;
     uint2 *slist;            // the current tile's faces when it builds its list itself (ascending id; same entry layout) ...
-    uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may truncate
-    // pair records beyond the R_LDS a workgroup keeps in LDS, 12 bytes each: {depth bits, pixel | list position << 6 | inside << 22 |
-    // closest edge << 23, signed squared distance to the closest edge (pass 3 recomputes the closest point itself)}; REC_CAP + REC_PAD
-    // entries per workgroup
+    uint32_t *slist2;        // ... and the ids the tile walks: near to far by the first radix digit of that depth when the tile may
+                             // truncate (the sort reads the depths it needs from slist instead of gathering them per face)
+    uint32_t *scfirst;       // F / DCHUNK + 2: first record of every chunk from the 128th on (the others live in registers)
+    float2 *sxy;             // (3, list_stride) projected vertices v0 / v1 / v2 of the tile's faces by list position ...
+    TriIds *sid;             // (list_stride) ... and their vertex ids
+    // record streams, REC_CAP + REC_PAD entries each (structure of arrays: every sweep reads only what it needs)
+    // pair records, 12 bytes each in ONE stream per workgroup (an append or a sweep step then touches one contiguous run of
+    // memory instead of three): {depth bits, pixel | list position << 6 | inside << 22 | closest edge << 23, signed squared
+    // distance to the closest edge (pass 3 recomputes the closest point itself)}
     Rec3 *srec;
-    int list_stride;         // entries of slist / slist2 per workgroup
-    HOOK_ARGS_FIELDS         // (instrumented builds: timer buffer)
+    // records that survive the first selection digit: {key = depth bits - tile minimum, meta, log2 of the blend factor}
+    Rec3 *crec;
+    int list_stride, n_cf;   // entries of slist / scfirst per workgroup
+    HOOK_ARGS_FIELDS         // (instrumented builds: counter buffer, cut-off phase, forced split)
 };
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
@@ -202,10 +240,12 @@ __device__ __forceinline__ uint32_t byte_offset(uint32_t i) {
 }
 template <typename T>
 __device__ __forceinline__ T &at(T *base, uint32_t i) {
+    i = HOOK_WRAP_IDX(i);
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset<T>(i));
 }
 template <typename T>
 __device__ __forceinline__ const T &at(const T *base, uint32_t i) {
+    i = HOOK_WRAP_IDX(i);
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset<T>(i));
 }
 
@@ -705,85 +745,55 @@ __global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__res
 // ---------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------
-// Round 5: ONE workgroup of TILE_WAVES waves per 8x8 tile, and the tile's (face, pixel) records never leave the CU.
-//   * the waves split the tile's face list chunk by chunk (wave w takes chunks w, w + NW, ...: each stages its own chunk in its
-//     own slice of LDS and sweeps its pairs exactly as the single-wave kernel did);
-//   * every accepted pair is appended to ONE record stream in LDS (three 4-byte arrays: depth bits, meta, signed squared
-//     distance; one returning LDS atomic per sweep step reserves the run).  What does not fit (R_LDS records: a tile whose 64
-//     pixels all hold K = 100 records has ~7 500) spills into a per-workgroup stream in memory - only the excess, and the
-//     sweeps below read both parts;
-//   * per-pixel depth histograms, log sums and thresholds are shared in LDS; blend, radix select and the gradient sweep read the
-//     records from LDS with all waves; the selection walks a list of 16-bit record indices (the records inside their pixel's
-//     threshold digit) instead of a second record stream;
-//   * the gradient sweep accumulates per (face, vertex) for a WINDOW of GWIN faces of the list at a time (accumulators and the
-//     window's projected vertices live where the waves staged their chunks), then flushes one atomic per touched vertex.
-// The closing rule needs no barrier: a wave publishes how far it has walked (progress[w]); digits of the near-to-far list that
-// lie entirely below the slowest wave's position are final.
-#ifndef TILE_WAVES
-#define TILE_WAVES 6
+#ifndef GCHUNK
+#define GCHUNK 64            // faces whose gradient accumulators are live in pass 3 (a multiple of WAVE)
 #endif
-#ifndef TILE_WG_PER_CU
-#define TILE_WG_PER_CU 2
+#ifndef GCOPIES
+#define GCOPIES 2
 #endif
-#define NW TILE_WAVES
-#define NT (NW * WAVE)
-#define HIST_WORDS ((1 << SEL_BITS) / 2 * WAVE)
-#define GWIN ((NW * 4096 / 48) / WAVE * WAVE)  // faces per gradient window: 24 B of vertices + 24 B of accumulators each
-#define CMP_CAP (NW * 2048)                    // 16-bit record indices the selection list holds (beyond: it walks every record)
-#ifndef RU
-#define RU 4                                   // records per thread and step of a record sweep (loads in flight together)
-#endif
-static_assert((TILE_WG_PER_CU * NW) % 4 == 0, "whole waves per SIMD");
-
-struct alignas(16) WaveLds {       // private to one wave during pass 1
-    float rec[DCHUNK * FSTR];      // staged face records of its current chunk
-    int start[WAVE];               // 2048-bit map of the pairs that start a face's run
-    uint2 rank[DCHUNK];            // packed boxes of the chunk's non-empty faces, by rank
-};
-static_assert(sizeof(WaveLds) == 4096, "WaveLds layout");
-struct alignas(16) TileLds {
+//      GCOPIES              // private copies of those accumulators (measured: 1 -> 2 copies -3 %, 4 copies lose it again to zeroing and flushing)
+struct alignas(16) DenseLds {
     union {
-        WaveLds wv[NW];                                                     // pass 1
-        uint16_t cmp[CMP_CAP];                                              // select: records inside their pixel's threshold digit
-        struct { float2 fv[GWIN * 3]; unsigned long long gacc[GWIN * 3]; }; // pass 3: the window's vertices and accumulators
+        float rec[DCHUNK * FSTR];    // pass 1: staged face records
+        struct {
+            // pass 3: gradient accumulators of GCHUNK faces x 3 vertices, (x, y) packed as two 32-bit fixed-point numbers
+            // in one 64-bit word so that one ds_add_u64 adds both; GCOPIES private copies indexed by lane & (GCOPIES - 1)
+            // keep the consecutive lanes of one face's run of records off each other's address (measured: the four
+            // 13-way conflicting ds_add_f64 per record this replaces were more than half of pass 3)
+            unsigned long long gacc[GCOPIES][GCHUNK * 3];
+            double plog[WAVE];       // pass 2: sum of log2(1 - p_k) (fp64: ds_add_f64 runs at full rate on gfx950,
+                                     //         ds_add_f32 at ~3 cycles per active lane)
+            float4 pgrad[WAVE];      // after pass 1: {gradient coefficient, threshold depth bits, tie cut (face id), -}
+        };
     };
-    uint32_t hist[HIST_WORDS];     // [bucket / 2][pixel], two 16-bit counts per word
-    double plog[WAVE];             // sum of log2(1 - p_k) over the kept records of a pixel
-    float4 pgrad[WAVE];            // {gradient coefficient, threshold depth bits, tie cut (face id), -}
-    float2 pixt[WAVE];             // pixel centre (px, py) in NDC
-    uint2 psel[WAVE];              // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
-    uint32_t bcnt[1 << SEL_BITS];  // sort: bucket counters / cursors
-    int progress[(NW + 3) / 4 * 4];  // pass 1: wave w has finished all its chunks below this chunk index
-    uint16_t bstart[1 << SEL_BITS];// first list position of every depth bucket of the near-to-far list
-    uint32_t unit, kmin, knear, list_total, rec_count, cmp_count, overflow, walked, rmax2_bits, pad_[3];
+    // select: [bucket / 2][pixel], two 16-bit counts per word; the first digit is counted by pass 1
+    uint32_t hist[(1 << SEL_BITS) / 2 * WAVE];
+    float2 pixt[WAVE];               // pass 1: pixel centre (px, py) in NDC
+    uint2 psel[WAVE];                // select: {prefix of the wanted key, rank wanted among the keys sharing it (0: none)}
+    int start[WAVE];                 // pass 1: 2048-bit map of the pairs that start a face's run (list phase: bucket counters)
+    uint16_t bstart[1 << SEL1_BITS]; // first list position of every depth bucket of the near-to-far list (clamped to 65535)
 };
-#ifndef LDS_SLACK
-#define LDS_SLACK 512
-#endif
-constexpr int R_LDS = ((160 * 1024 / TILE_WG_PER_CU - LDS_SLACK - (int)sizeof(TileLds)) / 12) / WAVE * WAVE;
-static_assert(R_LDS >= 1024, "no room for records");
-struct alignas(16) TileShared {
-    TileLds t;
-    uint32_t rk[R_LDS];  // depth bits
-    uint32_t rm[R_LDS];  // pixel | list position << 6 | inside << 22 | closest edge << 23
-    float rs[R_LDS];     // signed squared distance to the closest edge
-};
-static_assert(sizeof(TileShared) * TILE_WG_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
+static_assert(sizeof(DenseLds) * RESIDENT_PER_CU <= 160 * 1024, "the resident workgroups of a CU must fit its 160 KB of LDS");
 
+// Record-stream accesses: written once, read once or twice, never shared between workgroups (non-temporal forms measured 12 % slower
+// in round 2: the streams do live on L2 / Infinity Cache hits between pass 1 and the sweeps).
 template <typename T> __device__ __forceinline__ T ld_stream(const T *base, uint32_t i) { return at(base, i); }
 template <typename T> __device__ __forceinline__ void st_stream(T *base, uint32_t i, T v) { at(base, i) = v; }
 
-// Lanes of ONE wave exchange data through LDS without s_barrier, but the compiler must not forward a lane's own store to its
-// later load, and the LDS queue must have drained.  Unlike __syncthreads() this does not wait for outstanding global accesses.
+// Single-wave workgroups: lanes exchange data through LDS without s_barrier, but the compiler must not forward a lane's
+// own store to its later load, and the LDS queue must have drained.  Unlike __syncthreads() this does NOT wait for
+// outstanding global stores (vmcnt), which in pass 1 would stall every sweep step on the previous step's record stores.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global).  Also the range of the nearest /
+// farthest vertex depth over those faces: every pair depth lies inside it (a convex combination of the face's vertex
+// depths), which fixes the radix-select digits before pass 1 starts.  Depths are positive: the bit patterns order like
+// the values.
 __device__ __forceinline__ bool box_has(uint32_t b, int tx, int ty) {
     const int tx0 = b & 0xFF, ty0 = (b >> 8) & 0xFF, tx1 = (b >> 16) & 0xFF, ty1 = b >> 24;
     return (tx >= tx0) && (tx <= tx1) && (ty >= ty0) && (ty <= ty1);
 }
 
-// Ordered list of the faces whose tile box contains (tx,ty), written to `list` (global) by ONE wave: the path of images whose
-// lists the setup kernel could not bin.  Also the range of the nearest / farthest vertex depth over those faces.
 #ifndef LGROUP
 #define LGROUP 8  // 64-face groups whose tile boxes / depth ranges are requested together by the list build
 #endif
@@ -835,12 +845,55 @@ __device__ __forceinline__ int build_list(const RasterArgs &a, int n, int tx, in
     return cnt;
 }
 
-// Staging of a chunk of DCHUNK = 32 faces by the 64 lanes of one wave: lanes l and l + 32 share face l.  The LOW lane builds the
-// affine forms (rows 0-2 of the record) and the pixel ROWS the face's blurred box covers inside the open part of the tile; the
-// HIGH lane the edge data (rows 3-6) and the pixel COLUMNS; the columns then cross over (one ds_bpermute each) and the low lane
-// leaves with the face's pair count `cf` and the word pairs decode their pixel from.  Both lanes load the same nine vertex floats
-// (one transaction).  Pixel index i (flipped axis) has centre -1 + (2i+1)/S: centres inside [lo, hi] are ceil(v_lo) .. floor(v_hi)
-// with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding (a superset; eval_pair applies the exact test).
+// Near-to-far order for the tile's list: a counting sort of the faces by the first radix digit (the same digit the
+// records' depths are histogrammed by) of their NEAREST vertex depth.  A record's depth is at least its face's nearest
+// vertex depth, so once every face of digit <= d has been processed the per-pixel record counts of digits <= d are final:
+// pass 1 uses that to stop collecting records for pixels that already hold K nearer ones (the reference keeps the K = 100
+// nearest per pixel, p3d_renderer.py:42-47), and to leave the tile when no pixel is open any more.
+// Order inside a bucket is arbitrary; depth ties between records are broken by face id, which the records' list position
+// recovers through `out`.  bstart[d] = first position of bucket d.
+__device__ __forceinline__ void sort_list_near_to_far(const uint2 *list, uint32_t *out, int n, uint32_t kmin, int shift1, int b1,
+                                                      DenseLds &lds, int lane) {
+    const int n_buckets = 1 << b1;
+    lds.start[lane] = 0;
+    __syncthreads();
+    auto digit_of = [&](const uint2 &e) { return (int)(((e.y - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
+    // (four rows per step: the loads of a step are in flight together - at small launches a tile's time is its chain of
+    // memory round trips)
+    for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = at(list, (uint32_t)min(i0 + u * WAVE + lane, n - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * WAVE + lane < n) atomicAdd(&lds.start[digit_of(e[u])], 1);
+    }
+    __syncthreads();
+    const int c = lane < n_buckets ? lds.start[lane] : 0;
+    const int incl = wave_scan_add(c);
+    __syncthreads();
+    if (lane < n_buckets) lds.bstart[lane] = (uint16_t)min(incl - c, 65535);
+    lds.start[lane] = incl - c;  // running cursor of every bucket
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = at(list, (uint32_t)min(i0 + u * WAVE + lane, n - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * WAVE + lane < n) out[atomicAdd(&lds.start[digit_of(e[u])], 1)] = e[u].x;
+    }
+    __syncthreads();
+}
+
+// Staging of a chunk of DCHUNK = 32 faces by all 64 lanes: lanes l and l + 32 share face l.  The LOW lane builds the affine
+// forms (rows 1-3 of the record) and the pixel ROWS the face's blurred box covers inside the open part of the tile; the
+// HIGH lane the bounding box (row 0), the edge data (rows 4-7) and the pixel COLUMNS; the columns then cross over (one
+// ds_bpermute each) and the low lane leaves with the face's pair count `cf` and the word pairs decode their pixel from.
+// Both lanes load the same nine vertex floats (one transaction); the face's vertex indices (i0, i1, i2) come from the
+// caller, which fetched them while the previous chunk was being evaluated.  Pixel index i (flipped axis) has centre -1 + (2i+1)/S:
+// centres inside [lo, hi] are ceil(v_lo) .. floor(v_hi) with v = ((x+1) S - 1)/2; 0.01 px of slack covers the float rounding
+// (a superset; eval_pair applies the exact test).
 static_assert(2 * DCHUNK == WAVE, "two lanes per staged face");
 struct Tri9 { float x0, y0, z0, x1, y1, z1, x2, y2, z2; };
 // the nine vertex floats of a lane's face (both lanes of a face load the same: one transaction), through the clip tables
@@ -848,9 +901,10 @@ __device__ __forceinline__ Tri9 load_tri(const RasterArgs &a, const float *__res
     const float *p0 = vertex_ptr(vn, xv_n, a.V, i0), *p1 = vertex_ptr(vn, xv_n, a.V, i1), *p2 = vertex_ptr(vn, xv_n, a.V, i2);
     return Tri9{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2]};
 }
-__device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv, int m, float *rec, int lane, float cx, float cy,
-                                            float fS, int tx, int ty, int ox0, int ox1, int oy0, int oy1,
-                                            unsigned long long open_px, int &cf, int &packed2) {
+__device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv, int i0, int i1, int i2, int m,
+                                            float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
+                                            int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2, float2 *__restrict__ sxy,
+                                            TriIds *__restrict__ sid, int c0, int list_stride) {
     const int slot = lane & (DCHUNK - 1);
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
@@ -859,7 +913,12 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv,
         const float x1 = tv.x1, y1 = tv.y1, z1 = tv.z1;
         const float x2 = tv.x2, y2 = tv.y2, z2 = tv.z2;
         float4 *r = reinterpret_cast<float4 *>(rec + slot * FSTR);
+        // The tile's vertex table for pass 3: three arrays of float2 (v0, v1, v2 by list position) and the vertex ids, so that every
+        // store instruction writes whole runs of bytes (one 24-byte structure per face, stored as 16 + 8 bytes, cost 0.45 ms per
+        // cfg2b launch in partial-line writes; this form 0.1): v0 from the low lanes and v1 from the high lanes in one instruction
+        at(sxy, (uint32_t)((hi ? list_stride : 0) + c0 + slot)) = hi ? make_float2(x1, y1) : make_float2(x0, y0);
         if (!hi) {
+            at(sid, (uint32_t)(c0 + slot)) = TriIds{i0, i1, i2};
             // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
             const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
             // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
@@ -881,7 +940,8 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv,
             r[3] = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
             r[4] = make_float4(e01x, e02x, e01y, e02y);
             r[5] = make_float4(rl01, rl02, e12x, e12y);
-            r[6] = make_float4(rl12, 0.f, 0.f, 0.f);
+            r[6] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
+            at(sxy, (uint32_t)(2 * list_stride + c0 + slot)) = make_float2(x2, y2);  // (the table, see above)
             const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - xi_hi - tx * TILE, ox0);
             b1 = min(a.S - 1 - xi_lo - tx * TILE, ox1);
@@ -927,7 +987,8 @@ __device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b,
 #pragma unroll
     for (int w_ = 0; w_ < (1 << SEL_BITS) / 2; ++w_) hw[w_] = hist[w_ * WAVE + lane];  // (all reads in flight together)
     // Running sums c_k are non-decreasing: the chosen bucket is the number of c_k below `need`, the keys in lower buckets the largest
-    // such c_k, and the chosen bucket ends at the first c_k that reaches `need`.  Arithmetic selects only.
+    // such c_k, and the chosen bucket ends at the first c_k that reaches `need`.  Arithmetic selects only (as a chain of `if`s this
+    // was thirty-two exec-masked branches per call).
     int c = 0, sel = 0, below = 0, first_ge = 0x7FFFFFFF;
 #pragma unroll
     for (int k = 0; k < (1 << SEL_BITS); ++k) {
@@ -948,49 +1009,193 @@ __device__ __forceinline__ int pick_digit(const uint32_t *hist, int lane, int b,
     return c;
 }
 
-struct RecV { uint32_t z, mt; float sd; };
+// The same for the first digit, whose histogram holds four 8-bit counts per word ([bucket / 4][pixel]) that stop growing at
+// SAT8 > K: the cumulative counts below the chosen digit are exact (they are below `need` <= K), a count that reached SAT8
+// only ever compares as "more than K".
+__device__ __forceinline__ int pick_digit8(const uint32_t *hist, int lane, int b, uint32_t &pre, int &need, int &n_eq) {
+    int cum = 0, sel = 0, cnt_sel = 0, all = 0;
+    bool found = false;
+#pragma unroll
+    for (int w_ = 0; w_ < (1 << SEL1_BITS) / 4; ++w_) {
+        const uint32_t hw = hist[w_ * WAVE + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = (int)((hw >> (8 * q)) & 0xFFu);
+            all += h;
+            if (!found && cum + h >= need) { sel = 4 * w_ + q; cnt_sel = h; found = true; }
+            cum += found ? 0 : h;
+        }
+    }
+    if (need > 0 && found) {
+        pre = (pre << b) | (uint32_t)sel;
+        need -= cum;
+        n_eq = cnt_sel;
+    } else {
+        need = 0;
+        n_eq = 0;
+    }
+    return all;
+}
+
+// One radix-select sweep over `n_rec` (key, meta) pairs: among the keys of pixel p whose bits above `nbits` equal
+// psel[p].x, histogram the next `b` bits (psel[p].y == 0: pixel not taking part; key 0xFFFFFFFF: record not taking part).
+template <typename KeyFn>
+__device__ __forceinline__ void select_sweep(DenseLds &lds, const Rec3 *__restrict__ crec, int n_rec, int nbits, int b,
+                                             int lane, uint32_t pre, int need, KeyFn key_of) {
+    const int shift = nbits - b;
+    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+    __syncthreads();
+    auto load_keys = [&](uint32_t (&kk)[KGROUP], uint32_t (&mt)[KGROUP], int g0) {
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_rec - 1);  // unsigned 32-bit: SGPR base + VGPR offset addressing
+            mt[u] = at(crec, idx).b;
+            kk[u] = key_of(idx, mt[u]);
+        }
+    };
+    auto count_keys = [&](const uint32_t (&kk)[KGROUP], const uint32_t (&mt)[KGROUP], int g0) {
+        uint2 ps[KGROUP];  // all LDS gathers first: one latency, not one per row
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) ps[u] = lds.psel[mt[u] & 63u];
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t pxl = mt[u] & 63u;
+            const bool hit = (g0 + u * WAVE + lane < n_rec) & (ps[u].y > 0u) & ((kk[u] >> nbits) == ps[u].x) & (kk[u] != 0xFFFFFFFFu);
+            const uint32_t bucket = (kk[u] >> shift) & ((1u << b) - 1u);
+            if (hit) atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+        }
+    };
+    if (n_rec > 0) {  // double-buffered: the next KGROUP rows are in flight while this one is counted
+        uint32_t ka[KGROUP], ma[KGROUP], kb[KGROUP], mb[KGROUP];
+        load_keys(ka, ma, 0);
+        for (int g0 = 0; g0 < n_rec; g0 += 2 * KGROUP * WAVE) {
+            load_keys(kb, mb, g0 + KGROUP * WAVE);
+            count_keys(ka, ma, g0);
+            load_keys(ka, ma, g0 + 2 * KGROUP * WAVE);
+            count_keys(kb, mb, g0 + KGROUP * WAVE);
+        }
+    }
+    __syncthreads();
+}
+
+// One refinement step of the radix select over the compact stream, which SHRINKS as it goes.  Among the records of pixel p
+// (still selecting: psel[p].y > 0) the bits of the key above `nbits` are compared with the prefix psel[p].x chosen so far:
+//   below it  -> the record lies in a lower bucket of the digit picked last: it is among the K nearest for certain, its log
+//                factor goes to the pixel's sum and the record leaves the stream;
+//   equal     -> it stays (compacted IN PLACE: the write position never passes the read position, and every lane has
+//                loaded its record before any lane of the same step stores) and its next `b` bits are histogrammed;
+//   above     -> dropped.
+// Returns the number of records left.  Every later sweep thus reads only the records that are still undecided (a tenth per
+// digit) instead of the whole compact stream, and the final pass only sees the last bucket.
+__device__ __forceinline__ int refine_sweep(DenseLds &lds, Rec3 *crec, int n_rec, int nbits, int b,
+                                            int lane, uint32_t pre, int need) {
+    const int shift = nbits - b;
+    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+    __syncthreads();
+    int n_out = 0;
+    struct CRec { uint32_t kk, mt; float lf; };
+    auto load_recs = [&](CRec (&r)[KGROUP], int g0) {
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_rec - 1);
+            const Rec3 q = at(crec, idx);
+            r[u].kk = q.a; r[u].mt = q.b; r[u].lf = __uint_as_float(q.c);
+        }
+    };
+    auto sift_recs = [&](const CRec (&r)[KGROUP], int g0) {
+        uint2 ps[KGROUP];  // all LDS gathers first: one latency, not one per row
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) ps[u] = lds.psel[r[u].mt & 63u];
+#pragma unroll
+        for (int u = 0; u < KGROUP; ++u) {
+            const uint32_t pxl = r[u].mt & 63u;
+            const bool live = (g0 + u * WAVE + lane < n_rec) & (ps[u].y > 0u);
+            const uint32_t top = r[u].kk >> nbits;
+            const bool sure = live & (top < ps[u].x), stay = live & (top == ps[u].x);
+            if (sure & (r[u].lf != 0.f)) atomicAdd(&lds.plog[pxl], (double)r[u].lf);
+            const unsigned long long sm = __ballot(stay);
+            const uint32_t slot = (uint32_t)n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+            if (stay) {
+                at(crec, slot) = Rec3{r[u].kk, r[u].mt, __float_as_uint(r[u].lf)};
+                const uint32_t bucket = (r[u].kk >> shift) & ((1u << b) - 1u);
+                atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+            }
+            n_out += __popcll(sm);
+        }
+    };
+    if (n_rec > 0) {  // double-buffered: the next KGROUP rows are in flight while this one is sifted
+        CRec ra[KGROUP], rb[KGROUP];
+        load_recs(ra, 0);
+        for (int g0 = 0; g0 < n_rec; g0 += 2 * KGROUP * WAVE) {
+            load_recs(rb, g0 + KGROUP * WAVE);
+            sift_recs(ra, g0);
+            load_recs(ra, g0 + 2 * KGROUP * WAVE);
+            sift_recs(rb, g0 + KGROUP * WAVE);
+        }
+    }
+    __syncthreads();
+    return n_out;
+}
 
 template <int MODE>
-__global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(RasterArgs a) {
-    __shared__ TileShared shm;
-    TileLds &sh = shm.t;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    WaveLds &wl = sh.wv[wv];
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs a) {
+    __shared__ DenseLds lds;
+    const int lane = threadIdx.x;
     uint2 *const slist = a.slist + (size_t)blockIdx.x * a.list_stride;
     uint32_t *const slist2 = a.slist2 + (size_t)blockIdx.x * a.list_stride;
-    Rec3 *const srec = a.srec + (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    uint32_t *const scfirst = a.scfirst + (size_t)blockIdx.x * a.n_cf;
+    float2 *const sxy = a.sxy + (size_t)blockIdx.x * 3 * a.list_stride;
+    TriIds *const sid = a.sid + (size_t)blockIdx.x * a.list_stride;
+    const size_t rec0 = (size_t)blockIdx.x * (REC_CAP + REC_PAD);
+    Rec3 *const srec = a.srec + rec0, *const crec = a.crec + rec0;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int K = a.K;
     const int n_tiles = a.tiles_x * a.tiles_x;
+    unsigned int n_items_all = 0;
+    for (int q = 0; q < N_PARTS; ++q)
+        for (int c = 0; c < N_CLASSES; ++c) n_items_all += a.ctr->n_class[q][c];
+    // With fewer tiles than workgroups (a handful of images) every tile is dealt out as 2, 4 or 8 runs of pixels, so that
+    // the launch finishes in a fraction of one tile's serial time.  Round 4, from a sweep over 1 ... 64 images x workgroups per CU x
+    // pieces (profiles/r4_small_launches.txt): the launch is fastest with ~2.3 pieces per WORKING workgroup and about 1.2 pieces per
+    // resident slot in all (8-pixel pieces - a whole list walk for one row of pixels - only while even they number under 0.6 per
+    // slot); the workgroups beyond that leave at once - a one-image launch runs on 512 of them, not on 4 096 that queue for the same
+    // ticket counter.
+    const unsigned int slots = gridDim.x;
+    const unsigned int split_log = HOOK_SPLIT_LOG(
+        n_items_all * 8u <= slots * 5u / 8u ? 3u : (n_items_all * 4u <= slots * 5u / 4u ? 2u : (n_items_all * 2u <= slots * 5u / 4u ? 1u : 0u)));
+    {
+        const unsigned int working = max(slots / 8u, (n_items_all << split_log) * 7u / 16u);
+        if (blockIdx.x >= working) return;  // (workgroup-uniform, before any barrier)
+    }
+    // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
+    // near to far) - and is, like the others, when the launch has workgroups to spare.
+    const unsigned int split0_log = SPLIT0_LOG > split_log ? SPLIT0_LOG : split_log;
     const float fS = (float)a.S;
     unsigned int xcc;  // the XCD this workgroup runs on: which partition it drains first
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= (unsigned int)(N_PARTS - 1);
-    TT_INIT
 
-    // a record by its index in the tile's stream: the first R_LDS live in LDS, the excess in the workgroup's spill stream
-    auto load_rec = [&](uint32_t idx) -> RecV {
-        if (idx < (uint32_t)R_LDS) return RecV{shm.rk[idx], shm.rm[idx], shm.rs[idx]};
-        const Rec3 q = ld_stream(srec, idx - (uint32_t)R_LDS);
-        return RecV{q.a, q.b, __uint_as_float(q.c)};
-    };
-
+    TIMERS_INIT
     for (unsigned int turn = 0; turn < N_PARTS; ++turn) {
     const unsigned int part = (xcc + turn) & (unsigned int)(N_PARTS - 1);
     const unsigned int nc0 = a.ctr->n_class[part][0], nc1 = a.ctr->n_class[part][1], nc2 = a.ctr->n_class[part][2], nc3 = a.ctr->n_class[part][3];
     const unsigned int n_items = nc0 + nc1 + nc2 + nc3;
+    const unsigned int units0 = nc0 << split0_log;
+    const unsigned int n_units = units0 + ((n_items - nc0) << split_log);
     const uint4 *const items = a.items + (size_t)part * 2u * a.item_cap;
-    while (n_items > 0u) {
-        __syncthreads();  // the previous tile has finished with every shared word
-        if (tid == 0) {
-            sh.unit = atomicAdd(&a.ctr->deal[part].next, 1u);
-            sh.kmin = 0x7F7FFFFFu;
-            sh.knear = 0u;
-        }
-        __syncthreads();
-        const unsigned int item = sh.unit;
-        if (item >= n_items) break;  // (workgroup-uniform)
+    while (n_units > 0u) {
+        unsigned int unit = 0;
+        TSUB(0)
+        if (lane == 0) unit = atomicAdd(&a.ctr->deal[part].next, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= n_units) break;
+        TUNIT_START
+        const bool heavy = unit < units0;
+        const unsigned int sl = heavy ? split0_log : split_log, u_ = heavy ? unit : unit - units0;
+        const unsigned int item = (u_ >> sl) + (heavy ? 0u : nc0);
+        const int p_begin = (int)(u_ & ((1u << sl) - 1u)) * (WAVE >> sl), p_end = p_begin + (WAVE >> sl);
         // heaviest class first
         const uint32_t item_at = item < nc0 ? item
                                : item < nc0 + nc1 ? a.item_cap - 1u - (item - nc0)
@@ -998,10 +1203,9 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                                : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
         const uint4 it = items[item_at];
         const uint32_t code = it.x;
-        TT(0)
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-        const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);  // (lane = pixel, in every wave)
+        const int xo = tx * TILE + (lane & 7), yo = ty * TILE + (lane >> 3);
         const bool in_img = xo < a.S && yo < a.S;
         const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
         const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
@@ -1009,514 +1213,503 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
         const int *const xf_n = a.clip.xf + (size_t)n * CLIP_FX * 3;
         const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
 
-        // ---------------- list: the faces whose blurred box reaches this tile ----------------------------------
-        // binned by the setup kernel (any order), or found here through the tile boxes of the 64-face groups (ascending id, by
-        // wave 0) when the image's lists did not fit.  Every depth of the tile lies between the nearest vertex of its nearest
-        // face and the farthest vertex of any: the binned entries carry the nearest depth only, and farthest <= nearest + (largest
-        // depth extent of a face of the image, from the setup kernel with the work item) bounds the other end.
-        uint32_t kmin, kmax;
+        uint32_t kmin, kmax;  // bounds of the depth keys of this tile
+        // the faces whose blurred box reaches this tile: binned by the setup kernel (any order), or found here through the tile
+        // boxes of the 64-face groups (ascending id) when the image's lists did not fit
+        const uint2 td = make_uint2(it.y, it.z);
+        const bool binned = td.y != 0xFFFFFFFFu;  // (wave-uniform)
+        TSUB(1)
+        const uint2 *const list_src = binned ? a.lists + (size_t)n * a.list_cap + td.x : slist;
         int list_total;
-        const bool binned = it.z != 0xFFFFFFFFu;  // (workgroup-uniform)
-        const uint2 *const list_src = binned ? a.lists + (size_t)n * a.list_cap + it.y : slist;
         if (binned) {
-            list_total = (int)it.z;
+            // every depth of the tile lies between the nearest vertex of its nearest face and the farthest vertex of any: the entries
+            // carry the nearest depth only (8 bytes), and farthest <= nearest + (largest depth extent of a face of the image, from
+            // the setup kernel with the work item) bounds the other end - an upper bound is all the key range needs
+            list_total = (int)td.y;
             uint32_t lo = 0x7F7FFFFFu, hi = 0u;
-            for (int i0 = 0; i0 < list_total; i0 += 2 * NT) {
-                uint2 e[2];
+            for (int i0 = 0; i0 < list_total; i0 += 4 * WAVE) {
+                uint2 e[4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) e[u] = at(list_src, (uint32_t)min(i0 + u * NT + tid, list_total - 1));
+                for (int u = 0; u < 4; ++u) e[u] = at(list_src, (uint32_t)min(i0 + u * WAVE + lane, list_total - 1));
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { lo = min(lo, e[u].y); hi = max(hi, e[u].y); }
+                for (int u = 0; u < 4; ++u) { lo = min(lo, e[u].y); hi = max(hi, e[u].y); }
             }
             for (int o = 32; o > 0; o >>= 1) {
                 lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, WAVE));
                 hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, WAVE));
             }
-            if (lane == 0) { atomicMin(&sh.kmin, lo); atomicMax(&sh.knear, hi); }
-            __syncthreads();
-            kmin = sh.kmin;
+            kmin = lo;
             // (rounded up twice: the extent was a rounded difference, the sum rounds again)
-            kmax = __float_as_uint((__uint_as_float(sh.knear) + __uint_as_float(it.w) * 1.000001f) * 1.0000005f) + 1u;
+            kmax = __float_as_uint((__uint_as_float(hi) + __uint_as_float(it.w) * 1.000001f) * 1.0000005f) + 1u;
         } else {
-            if (wv == 0) {
-                uint32_t lo, hi;
-                const int cnt = build_list(a, n, tx, ty, slist, lane, lo, hi);
-                if (lane == 0) { sh.kmin = lo; sh.knear = hi; sh.list_total = (uint32_t)cnt; }
-            }
-            __syncthreads();  // (also: wave 0's list stores are visible to the loads below)
-            kmin = sh.kmin; kmax = sh.knear; list_total = (int)sh.list_total;
+            list_total = build_list(a, n, tx, ty, slist, lane, kmin, kmax);
         }
-        if (list_total <= 0) continue;  // (workgroup-uniform; a queued tile owns at least one face)
-        TT(1)
         const bool may_truncate = list_total > K;
+        TSUB(2)
         // radix select on key = depth bits - kmin, which lies in [0, kmax - kmin]: `nbits0` significant bits, of which the
         // first digit takes the top SEL_BITS (so it always spreads over at least half of its buckets)
         const uint32_t krange = kmax - kmin;
         const int nbits0 = krange ? 32 - __clz(krange) : 0;
-        const int b1 = min(SEL_BITS, nbits0), shift1 = nbits0 - b1;
-        // Tiles that may truncate walk their faces NEAR TO FAR: a counting sort of the list by the first radix digit (the digit
-        // the records' depths are histogrammed by) of each face's NEAREST vertex depth.  A record's depth is at least its face's
-        // nearest vertex depth, so once every face of digit <= d has been processed the per-pixel record counts of digits <= d
-        // are final: pass 1 stops collecting records for pixels that already hold K nearer ones (the reference keeps the K = 100
-        // nearest per pixel, p3d_renderer.py:42-47).  Order inside a bucket is arbitrary; bstart[d] = first position of bucket d.
-        // The others walk the list as it is.
-        const uint32_t *const lw = may_truncate ? slist2 : reinterpret_cast<const uint32_t *>(list_src);
-        const int lsh = may_truncate ? 0 : 1;
-        auto face_at = [&](int pos) { return (int)lw[(uint32_t)pos << lsh]; };
+        const int b1 = min(SEL1_BITS, nbits0), shift1 = nbits0 - b1;
+        __syncthreads();  // the list stores are visible to the loads below
+        // tiles that may truncate walk their faces near to far (see sort_list_near_to_far); the others keep the id order
+        const uint32_t *const lst = slist2;
         if (may_truncate) {
-            const int n_buckets = 1 << b1;
-            auto digit_of = [&](const uint2 &e) { return (int)(((e.y - kmin) >> shift1) & (uint32_t)(n_buckets - 1)); };
-            if (tid < (1 << SEL_BITS)) sh.bcnt[tid] = 0u;
+            sort_list_near_to_far(list_src, slist2, list_total, kmin, shift1, b1, lds, lane);
+        } else {  // at most K faces: the order of the list is kept
+            for (int i = lane; i < list_total; i += WAVE) slist2[i] = at(list_src, (uint32_t)i).x;
             __syncthreads();
-            for (int i0 = 0; i0 < list_total; i0 += 2 * NT) {
-                uint2 e[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) e[u] = at(list_src, (uint32_t)min(i0 + u * NT + tid, list_total - 1));
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (i0 + u * NT + tid < list_total) atomicAdd(&sh.bcnt[digit_of(e[u])], 1u);
-            }
-            __syncthreads();
-            if (wv == 0) {
-                const int c = lane < n_buckets ? (int)sh.bcnt[lane] : 0;
-                const int incl = wave_scan_add(c);
-                lds_fence();
-                if (lane < (1 << SEL_BITS)) {
-                    sh.bstart[lane] = (uint16_t)min(lane < n_buckets ? incl - c : 65535, 65535);
-                    sh.bcnt[lane] = (uint32_t)(incl - c);  // running cursor of every bucket
-                }
-            }
-            __syncthreads();
-            for (int i0 = 0; i0 < list_total; i0 += 2 * NT) {
-                uint2 e[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) e[u] = at(list_src, (uint32_t)min(i0 + u * NT + tid, list_total - 1));
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (i0 + u * NT + tid < list_total) slist2[atomicAdd(&sh.bcnt[digit_of(e[u])], 1u)] = e[u].x;
-            }
         }
+        TMARK(0)
+        TSUB(3)
+        HOOK_STOP_AFTER(0, continue)
 
-        TT(2)
-        // Sub-tiles: runs of `span` pixels (lane order), only for tiles whose records would overflow even the spill stream.
-        // Start from an estimate (a quarter of the pairs pixel x face exist) and halve whenever pass 1 finds that the records
-        // do not fit; span * list_total <= REC_CAP always fits.
-        int span = WAVE;
+        // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
+        // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
+        int span = p_end - p_begin;
         while (span > 1 && (long long)span * list_total > 4ll * REC_CAP) span >>= 1;
-        for (int p_lo = 0; p_lo < WAVE;) {
+        for (int p_lo = p_begin; p_lo < p_end;) {
             const bool mine = lane >= p_lo && lane < p_lo + span;  // this lane's pixel belongs to the sub-tile
             const int sy0 = p_lo >> 3, sy1 = (p_lo + span - 1) >> 3;                       // its rows ...
             const int sx0 = span >= 8 ? 0 : (p_lo & 7), sx1 = span >= 8 ? 7 : ((p_lo & 7) + span - 1);  // ... and columns
-            __syncthreads();  // (the sorted list is in place; the previous sub-tile has finished with the shared words)
-            if (wv == 0) {
-                // pixels outside the image or the sub-tile get a position no bbox can contain
-                const float px = (in_img && mine) ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
-                sh.pixt[lane] = make_float2(px, py);
-            }
+            // pixels outside the image or the sub-tile get a position no bbox can contain
+            const float px = (in_img && mine) ? pix_to_ndc(a.S - 1 - xo, a.S) : 3.0e38f, py = pix_to_ndc(a.S - 1 - yo, a.S);
+            lds.pixt[lane] = make_float2(px, py);
             if (may_truncate)
-                for (int i_ = tid; i_ < HIST_WORDS; i_ += NT) sh.hist[i_] = 0u;
-            if (tid < (NW + 3) / 4 * 4) sh.progress[tid] = tid < NW ? tid : 0x7FFFFFFF;
-            if (tid == 0) { sh.rec_count = 0u; sh.overflow = 0u; sh.walked = 0u; sh.cmp_count = 0u; sh.rmax2_bits = 0u; }
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
-            TT(3)
 
             // ---------------- pass 1: every pair inside a face's pixel box, once --------------------------------
-            // Wave w walks chunks w, w + NW, ... of the list.  Pixels that cannot keep any further record ("closed"): they
-            // already hold K records in depth digits that are final, i.e. below the digit of the first list position that some
-            // wave has not finished yet.  Lane = pixel keeps its count of final records (every wave its own copy).
-            {
-                int final_digits = 0, final_cnt = 0;
-                unsigned long long open_px = __ballot(in_img && mine);
-                int ox0 = sx0, ox1 = sx1, oy0 = sy0, oy1 = sy1;  // bounding box of the open pixels
-                int walked_end = 0;
-                constexpr int CSTRIDE = NW * DCHUNK;
-                const int c_first = wv * DCHUNK;
-                // The staging loads form a chain list entry -> vertex indices -> vertex coordinates, fetched ahead: while chunk k
-                // of this wave is evaluated the vertices of its chunk k + 1, the indices of k + 2 and the list entries of k + 3
-                // are in flight.
-                const int slot_ = lane & (DCHUNK - 1);
-                auto list_at = [&](int c) { return face_at(min(c + slot_, list_total - 1)); };
-                int f_nx = 0, ia = 0, ib = 0, ic = 0, ja = 0, jb = 0, jc = 0;
-                Tri9 tv_nx = Tri9{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (c_first < list_total) {  // (wave-uniform)
-                    f_nx = list_at(c_first + 2 * CSTRIDE);
-                    { const int f_ = list_at(c_first); ja = face_vertex(a.faces, xf_n, a.F, f_, 0); jb = face_vertex(a.faces, xf_n, a.F, f_, 1); jc = face_vertex(a.faces, xf_n, a.F, f_, 2); }
-                    { const int f_ = list_at(c_first + CSTRIDE); ia = face_vertex(a.faces, xf_n, a.F, f_, 0); ib = face_vertex(a.faces, xf_n, a.F, f_, 1); ic = face_vertex(a.faces, xf_n, a.F, f_, 2); }
-                    tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);
+            int vbase = 0;  // records written so far (wave-uniform)
+            bool fits = true;
+            // Pixels that cannot keep any further record ("closed"): they already hold K records in depth digits that are
+            // final, i.e. below the digit of the first face not yet processed.  Lane = pixel keeps its count of final records.
+            int final_digits = 0, final_cnt = 0;
+            unsigned long long open_px = __ballot(in_img && mine);
+            int ox0 = sx0, ox1 = sx1, oy0 = sy0, oy1 = sy1;  // bounding box of the open pixels
+            int chunks_done = 0;
+            // first record of every chunk (pass 3 walks the records group by group): lane c of `cst0` / `cst1` holds the start of chunk c /
+            // 64 + c - a register read in pass 3 instead of a memory round trip per group; chunks from 128 on (lists beyond 4096 faces)
+            // go through memory
+            uint32_t cst0 = 0u, cst1 = 0u;
+            auto set_chunk_start = [&](int c, uint32_t v) {  // (c, v wave-uniform)
+                if (c < WAVE) cst0 = lane == c ? v : cst0;
+                else if (c < 2 * WAVE) cst1 = lane == c - WAVE ? v : cst1;
+                else if (lane == 0) scfirst[c] = v;
+            };
+            auto chunk_start = [&](int c) -> uint32_t {
+                if (c < WAVE) return (uint32_t)__builtin_amdgcn_readlane((int)cst0, c);
+                if (c < 2 * WAVE) return (uint32_t)__builtin_amdgcn_readlane((int)cst1, c - WAVE);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)scfirst[c]);
+            };
+            // The staging loads form a chain list entry -> vertex indices -> vertex coordinates.  The first two links are
+            // fetched ahead: while chunk k is evaluated the indices of chunk k + 1 and the list entries of chunk k + 2 are in
+            // flight (four registers), so a chunk starts with one memory round trip instead of three.
+            const int slot_ = lane & (DCHUNK - 1);
+            auto list_at = [&](int c) { return (int)lst[min(c + slot_, list_total - 1)]; };
+            // (round 4: one more link ahead - the VERTICES of chunk k + 1 are requested before chunk k is evaluated and wait in nine
+            // registers, so a chunk starts with the drain of the previous sweep's stores only, not with a vertex fetch behind it)
+            int f_nx = list_at(2 * DCHUNK);
+            int ia, ib, ic;      // vertex ids of chunk k + 1 ...
+            int ja, jb, jc;      // ... and of chunk k
+            Tri9 tv_nx;          // vertices of chunk k (requested one chunk ahead)
+            { const int f_ = list_at(0); ja = face_vertex(a.faces, xf_n, a.F, f_, 0); jb = face_vertex(a.faces, xf_n, a.F, f_, 1); jc = face_vertex(a.faces, xf_n, a.F, f_, 2); }
+            { const int f_ = list_at(DCHUNK); ia = face_vertex(a.faces, xf_n, a.F, f_, 0); ib = face_vertex(a.faces, xf_n, a.F, f_, 1); ic = face_vertex(a.faces, xf_n, a.F, f_, 2); }
+            tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);
+            for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
+                if (may_truncate) {
+                    // digit of this chunk's first face = number of buckets that start at or before it, minus one
+                    const int d0 = __popcll(__ballot(lane < (1 << b1) && (int)lds.bstart[lane] <= c0)) - 1;
+                    if (d0 > final_digits) {  // wave-uniform: digits [final_digits, d0) have just become final
+                        for (int d = final_digits; d < d0; ++d)
+                            final_cnt += (int)((lds.hist[(d >> 2) * WAVE + lane] >> (8 * (d & 3))) & 0xFFu);
+                        final_digits = d0;
+                        open_px &= ~__ballot(final_cnt >= K);
+                        if (open_px == 0ull) break;  // every pixel of the (sub-)tile is closed: the remaining faces are all farther
+                        unsigned int cols = 0u;
+                        oy0 = 8; oy1 = -1;
+                        for (int y = 0; y < TILE; ++y) {
+                            const unsigned int row = (unsigned int)(open_px >> (8 * y)) & 0xFFu;
+                            cols |= row;
+                            if (row) { oy0 = min(oy0, y); oy1 = y; }
+                        }
+                        ox0 = (int)__builtin_ctz(cols); ox1 = 31 - (int)__builtin_clz(cols);
+                    }
                 }
-                for (int c0 = c_first; c0 < list_total; c0 += CSTRIDE) {
+                const int m = min(DCHUNK, list_total - c0);
+                int cf, packed2, packed = 0;
+                const int i0 = ja, i1 = jb, i2 = jc;
+                const Tri9 tv = tv_nx;                       // this chunk's vertices (in flight since the chunk before)
+                ja = ia; jb = ib; jc = ic;
+                tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);  // chunk c0 + DCHUNK
+                ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + 2 DCHUNK
+                f_nx = list_at(c0 + 3 * DCHUNK);
+                stage_faces(a, tv, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy, sid, c0, a.list_stride);
+                set_chunk_start(c0 / DCHUNK, (uint32_t)vbase);
+                chunks_done = c0 / DCHUNK + 1;
+                lds_fence();
+                HOOK_STOP_AFTER(1, continue)
+                const int incl = wave_scan_add(cf);
+                const int off = incl - cf;          // first pair of this face in the chunk's pair list
+                const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
+                packed |= off;                      // off <= DCHUNK * 32
+                if (vbase + 2 * n_pairs > REC_CAP) { fits = false; break; }  // wave-uniform (n_pairs lanes of two pixels each)
+                STAT(20, 2 * n_pairs)
+                // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
+                // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
+                // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
+                // (start bits at or below its lane) - 1, two v_mbcnt and one ds_bpermute away.
+                const unsigned long long nonempty = __ballot(cf > 0);
+                STAT(31, __popcll(nonempty))  // staged faces that have any open pixel in their box
+                lds.start[lane] = 0;
+                lds_fence();
+                if (cf > 0) {
+                    atomicOr(reinterpret_cast<uint32_t *>(lds.start) + (off >> 5), 1u << (off & 31));
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nonempty >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nonempty, 0u));
+                    lds.psel[rank] = make_uint2((uint32_t)packed | ((uint32_t)lane << 13), (uint32_t)packed2);
+                }
+                lds_fence();
+                const uint32_t fl_lo = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane) & 63];
+                const uint32_t fl_hi = reinterpret_cast<const uint32_t *>(lds.start)[(2 * lane + 1) & 63];
+                const uint2 pk_rank = lds.psel[lane & (DCHUNK - 1)];
+                lds_fence();
+                TSTAGE_MARK
+                uint32_t carry = 0;                 // faces started before this step
+                for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
+                    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)fl_lo, q0 >> 6), whi = (uint32_t)__builtin_amdgcn_readlane((int)fl_hi, q0 >> 6);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+                    const uint32_t own = ((wlo & lane_lo) | (whi & lane_hi)) ? 1u : 0u;
+                    const int r = min((int)(carry + below + own) - 1, DCHUNK - 1);
+                    carry += (uint32_t)(__popc(wlo) + __popc(whi));
+                    const bool valid = q0 + lane < n_pairs;
+                    const uint32_t pk = (uint32_t)__shfl((int)pk_rank.x, max(r, 0), WAVE), pk2 = (uint32_t)__shfl((int)pk_rank.y, max(r, 0), WAVE);
+                    const int fs = (int)((pk >> 13) & (DCHUNK - 1));
+                    const uint32_t rr = (uint32_t)(q0 + lane) - (pk & 0x1FFFu);
+                    // rr < 32 and the reciprocal has 17 bits: a 24-bit multiply (full rate) is exact.  Spelled in assembly because
+                    // hipcc widens __umul24 here to the quarter-rate v_mul_lo_u32 (it cannot see the range of rr)
+                    uint32_t rr_inv;
+                    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rr_inv) : "v"(rr), "v"(pk2 & 0x1FFFFu));
+                    const uint32_t dy = rr_inv >> 16;
+                    const int pp = (int)((__umul24(dy, (pk2 >> 17) & 3u) + rr + (pk2 >> 20)) & 31u);  // pixel pair: pixels 2 pp, 2 pp + 1
+                    const int p = 2 * pp;
+                    const float4 pc = *reinterpret_cast<const float4 *>(&lds.pixt[p]);   // (px, py) of both pixels: one 16-byte read
+                    const FaceRows fr = load_face_rows(lds.rec + fs * FSTR);
+                    PairEval2 e;
+                    eval_pair2(fr, pc.x - cx, pc.z - cx, pc.y - cy, a.blur, e);
+                    HOOK_EXTRA_VALU(pc)
+                    const uint32_t open2 = (uint32_t)(open_px >> p) & 3u;
+                    const bool cand0 = valid && e.cand0 && (open2 & 1u), cand1 = valid && e.cand1 && (open2 & 2u);
+                    const unsigned long long cm0 = __ballot(cand0), cm1 = __ballot(cand1);
+                    if ((cm0 | cm1) == 0ull) continue;
+                    // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
+                    // ... and never nearer than the face's nearest vertex (rounding of the convex combination), so that a record's
+                    // digit is at least its face's: the closing rule above relies on it
+                    uint32_t zb0 = 0x7F61B1E6u, zb1 = 0x7F61B1E6u;  // (3.0e38f: tiles that cannot truncate carry no depths)
                     if (may_truncate) {
-                        // every chunk below `done` has been finished by its wave
-                        int done_ = 0x7FFFFFFF;
-#pragma unroll
-                        for (int q_ = 0; q_ < (NW + 3) / 4; ++q_) {
-                            const int4 pa = *reinterpret_cast<const int4 *>(&sh.progress[4 * q_]);
-                            done_ = min(done_, min(min(pa.x, pa.y), min(pa.z, pa.w)));
-                        }
-                        const int done = __builtin_amdgcn_readfirstlane(done_);
-                        const int done_pos = done >= 0x7FFFFFFF / DCHUNK ? 0x7FFFFFFF : done * DCHUNK;
-                        // digit of the first unfinished list position = number of buckets that start at or before it, minus one
-                        const int d0 = __popcll(__ballot(lane < (1 << b1) && (int)sh.bstart[lane] <= done_pos)) - 1;
-                        if (d0 > final_digits) {  // wave-uniform: digits [final_digits, d0) have just become final
-                            for (int d = final_digits; d < d0; ++d)
-                                final_cnt += (int)((sh.hist[(d >> 1) * WAVE + lane] >> (16 * (d & 1))) & 0xFFFFu);
-                            final_digits = d0;
-                            open_px &= ~__ballot(final_cnt >= K);
-                            if (open_px == 0ull) break;  // every pixel of the (sub-)tile is closed: the remaining faces are all farther
-                            unsigned int cols = 0u;
-                            oy0 = 8; oy1 = -1;
-                            for (int y = 0; y < TILE; ++y) {
-                                const unsigned int row = (unsigned int)(open_px >> (8 * y)) & 0xFFu;
-                                cols |= row;
-                                if (row) { oy0 = min(oy0, y); oy1 = y; }
-                            }
-                            ox0 = (int)__builtin_ctz(cols); ox1 = 31 - (int)__builtin_clz(cols);
+                        const f32x2 z2 = pair_depth2(fr, e);
+                        const float zf = fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w);
+                        zb0 = min(max(__float_as_uint(vmax_raw(z2.x, zf)), kmin), kmax);
+                        zb1 = min(max(__float_as_uint(vmax_raw(z2.y, zf)), kmin), kmax);
+                    }
+                    // both records of a lane go next to each other (left pixel first): the stream stays in face-major, row-major
+                    // order, the order one pair per lane produced
+                    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm1,
+                                            __builtin_amdgcn_mbcnt_hi((uint32_t)(cm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm0, 0u))));
+                    const uint32_t slot0 = (uint32_t)vbase + before, slot1 = slot0 + (cand0 ? 1u : 0u);
+                    const uint32_t meta = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
+                    if (cand0) {
+                        st_stream(srec, slot0, Rec3{zb0, meta | (e.inside0 ? 1u << 22 : 0u) | e.ebits0, __float_as_uint(e.sd.x)});
+                        if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
+                            const uint32_t bucket = ((zb0 - kmin) >> shift1) & ((1u << b1) - 1u);
+                            uint32_t *const hw = &lds.hist[(bucket >> 2) * WAVE + p];
+                            const uint32_t sh = 8u * (bucket & 3u);
+                            if (((*hw >> sh) & 0xFFu) < SAT8) atomicAdd(hw, 1u << sh);
                         }
                     }
-                    const int m = min(DCHUNK, list_total - c0);
-                    int cf, packed2, packed = 0;
-                    const Tri9 tv = tv_nx;                       // this chunk's vertices (in flight since the chunk before)
-                    ja = ia; jb = ib; jc = ic;
-                    tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);  // this wave's next chunk
-                    ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);
-                    f_nx = list_at(c0 + 3 * CSTRIDE);
-                    stage_faces(a, tv, m, wl.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2);
-                    walked_end = c0 + m;
-                    lds_fence();
-                    const int incl = wave_scan_add(cf);
-                    const int off = incl - cf;          // first pair of this face in the chunk's pair list
-                    const int n_pairs = __builtin_amdgcn_readlane(incl, 63);
-                    packed |= off;                      // off <= DCHUNK * 32
-                    TSTAT(2, 2 * n_pairs)
-                    // pair -> face.  Every non-empty face sets the bit of its first pair in a 2048-bit map (64 words in LDS) and
-                    // leaves its packed box at its rank among the non-empty faces.  Lane i then keeps words 2i, 2i+1 - the start
-                    // bits of sweep step i - and the packed box of rank i; in step i a pair's face is (starts before the step) +
-                    // (start bits at or below its lane) - 1, two v_mbcnt and one ds_bpermute away.
-                    const unsigned long long nonempty = __ballot(cf > 0);
-                    wl.start[lane] = 0;
-                    lds_fence();
-                    if (cf > 0) {
-                        atomicOr(reinterpret_cast<uint32_t *>(wl.start) + (off >> 5), 1u << (off & 31));
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nonempty >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nonempty, 0u));
-                        wl.rank[rank] = make_uint2((uint32_t)packed | ((uint32_t)lane << 13), (uint32_t)packed2);
-                    }
-                    lds_fence();
-                    const uint32_t fl_lo = reinterpret_cast<const uint32_t *>(wl.start)[(2 * lane) & 63];
-                    const uint32_t fl_hi = reinterpret_cast<const uint32_t *>(wl.start)[(2 * lane + 1) & 63];
-                    const uint2 pk_rank = wl.rank[lane & (DCHUNK - 1)];
-                    lds_fence();
-                    uint32_t carry = 0;                 // faces started before this step
-                    bool full = false;
-                    for (int q0 = 0; q0 < n_pairs; q0 += WAVE) {
-                        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)fl_lo, q0 >> 6), whi = (uint32_t)__builtin_amdgcn_readlane((int)fl_hi, q0 >> 6);
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
-                        const uint32_t own = ((wlo & lane_lo) | (whi & lane_hi)) ? 1u : 0u;
-                        const int r = min((int)(carry + below + own) - 1, DCHUNK - 1);
-                        carry += (uint32_t)(__popc(wlo) + __popc(whi));
-                        const bool valid = q0 + lane < n_pairs;
-                        const uint32_t pk = (uint32_t)__shfl((int)pk_rank.x, max(r, 0), WAVE), pk2 = (uint32_t)__shfl((int)pk_rank.y, max(r, 0), WAVE);
-                        const int fs = (int)((pk >> 13) & (DCHUNK - 1));
-                        const uint32_t rr = (uint32_t)(q0 + lane) - (pk & 0x1FFFu);
-                        // rr < 32 and the reciprocal has 17 bits: a 24-bit multiply (full rate) is exact.  Spelled in assembly because
-                        // hipcc widens __umul24 here to the quarter-rate v_mul_lo_u32 (it cannot see the range of rr)
-                        uint32_t rr_inv;
-                        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rr_inv) : "v"(rr), "v"(pk2 & 0x1FFFFu));
-                        const uint32_t dy = rr_inv >> 16;
-                        const int pp = (int)((__umul24(dy, (pk2 >> 17) & 3u) + rr + (pk2 >> 20)) & 31u);  // pixel pair: pixels 2 pp, 2 pp + 1
-                        const int p = 2 * pp;
-                        const float4 pc = *reinterpret_cast<const float4 *>(&sh.pixt[p]);   // (px, py) of both pixels: one 16-byte read
-                        const FaceRows fr = load_face_rows(wl.rec + fs * FSTR);
-                        PairEval2 e;
-                        eval_pair2(fr, pc.x - cx, pc.z - cx, pc.y - cy, a.blur, e);
-                        const uint32_t open2 = (uint32_t)(open_px >> p) & 3u;
-                        const bool cand0 = valid && e.cand0 && (open2 & 1u), cand1 = valid && e.cand1 && (open2 & 2u);
-                        const unsigned long long cm0 = __ballot(cand0), cm1 = __ballot(cand1);
-                        if ((cm0 | cm1) == 0ull) continue;
-                        // the run of this step's records in the tile's stream: one returning LDS atomic (its latency hides behind
-                        // the depth arithmetic)
-                        const uint32_t n_new = (uint32_t)(__popcll(cm0) + __popcll(cm1));
-                        uint32_t base = 0u;
-                        if (lane == 0) base = atomicAdd(&sh.rec_count, n_new);
-                        // depth: kept inside the tile's vertex-depth range, where the convex combination lives up to rounding
-                        // ... and never nearer than the face's nearest vertex (rounding of the convex combination), so that a record's
-                        // digit is at least its face's: the closing rule above relies on it
-                        uint32_t zb0 = 0x7F61B1E6u, zb1 = 0x7F61B1E6u;  // (3.0e38f: tiles that cannot truncate carry no depths)
+                    if (cand1) {
+                        st_stream(srec, slot1, Rec3{zb1, (meta + 1u) | (e.inside1 ? 1u << 22 : 0u) | e.ebits1, __float_as_uint(e.sd.y)});
                         if (may_truncate) {
-                            const f32x2 z2 = pair_depth2(fr, e);
-                            const float zf = fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w);
-                            zb0 = min(max(__float_as_uint(vmax_raw(z2.x, zf)), kmin), kmax);
-                            zb1 = min(max(__float_as_uint(vmax_raw(z2.y, zf)), kmin), kmax);
-                        }
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base + n_new > (uint32_t)REC_CAP) { full = true; break; }  // wave-uniform: not even the spill stream holds them
-                        // both records of a lane go next to each other (left pixel first)
-                        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm1,
-                                                __builtin_amdgcn_mbcnt_hi((uint32_t)(cm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm0, 0u))));
-                        const uint32_t slot0 = base + before, slot1 = slot0 + (cand0 ? 1u : 0u);
-                        const uint32_t meta = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
-                        if (cand0) {
-                            const uint32_t mt = meta | (e.inside0 ? 1u << 22 : 0u) | e.ebits0;
-                            if (slot0 < (uint32_t)R_LDS) { shm.rk[slot0] = zb0; shm.rm[slot0] = mt; shm.rs[slot0] = e.sd.x; }
-                            else st_stream(srec, slot0 - (uint32_t)R_LDS, Rec3{zb0, mt, __float_as_uint(e.sd.x)});
-                            if (may_truncate) {  // first radix digit, and with it the number of candidates of the pixel
-                                const uint32_t bucket = ((zb0 - kmin) >> shift1) & ((1u << b1) - 1u);
-                                atomicAdd(&sh.hist[(bucket >> 1) * WAVE + p], (bucket & 1u) ? 0x10000u : 1u);
-                            }
-                        }
-                        if (cand1) {
-                            const uint32_t mt = (meta + 1u) | (e.inside1 ? 1u << 22 : 0u) | e.ebits1;
-                            if (slot1 < (uint32_t)R_LDS) { shm.rk[slot1] = zb1; shm.rm[slot1] = mt; shm.rs[slot1] = e.sd.y; }
-                            else st_stream(srec, slot1 - (uint32_t)R_LDS, Rec3{zb1, mt, __float_as_uint(e.sd.y)});
-                            if (may_truncate) {
-                                const uint32_t bucket = ((zb1 - kmin) >> shift1) & ((1u << b1) - 1u);
-                                atomicAdd(&sh.hist[(bucket >> 1) * WAVE + p + 1], (bucket & 1u) ? 0x10000u : 1u);
-                            }
+                            const uint32_t bucket = ((zb1 - kmin) >> shift1) & ((1u << b1) - 1u);
+                            uint32_t *const hw = &lds.hist[(bucket >> 2) * WAVE + p + 1];
+                            const uint32_t sh = 8u * (bucket & 3u);
+                            if (((*hw >> sh) & 0xFFu) < SAT8) atomicAdd(hw, 1u << sh);
                         }
                     }
-                    lds_fence();  // rec is rewritten by the next chunk
-                    if (full) {
-                        if (lane == 0) sh.overflow = 1u;
-                        break;
-                    }
-                    if (lane == 0) sh.progress[wv] = c0 / DCHUNK + NW;  // (behind this chunk's histogram updates: LDS operations of a wave execute in order)
+                    vbase += __popcll(cm0) + __popcll(cm1);
                 }
-                if (lane == 0) {
-                    sh.progress[wv] = 0x7FFFFFFF;  // nothing left that this wave could still add to
-                    atomicMax(&sh.walked, (uint32_t)walked_end);
-                }
+                TSWEEP_MARK
+                lds_fence();  // rec is rewritten by the next chunk
             }
-            TT(4)
-            __syncthreads();  // also: spilled records of other waves are visible from here on
-            TT(5)
-            if (sh.overflow) {  // workgroup-uniform: try again with half the pixels
+            if (!fits) {  // wave-uniform: try again with half the pixels
                 span >>= 1;
+                __syncthreads();
                 continue;
             }
-            const int n_rec = (int)sh.rec_count;
-            if (wv == 0) { TSTAT(0, 1) TSTAT(1, list_total) TSTAT(3, n_rec) TSTAT(5, max(n_rec - R_LDS, 0)) }
-            const int n_walked = (int)sh.walked;  // list positions [0, n_walked) may own records
+            set_chunk_start(chunks_done, (uint32_t)vbase);  // (chunks behind an early exit hold no records)
+            STAT(21, vbase) STAT(26, 1) STAT(27, list_total) STAT(28, chunks_done) STAT(29, (list_total + DCHUNK - 1) / DCHUNK) STAT(30, __popcll(open_px))
+            __syncthreads();  // also: record stores of other lanes are visible from here on
+            TMARK(1)
+            HOOK_STOP_AFTER(1, { p_lo += span; continue; }) HOOK_STOP_AFTER(2, { p_lo += span; continue; })
 
-            // All records of the (sub-)tile, RU per thread and step: the ones in LDS, then the spilled ones.  body(r, first index,
-            // end of this part): record u of the step has index first + u * NT + tid and is valid below `end`.
-            auto for_records = [&](auto &&body) {
-                const int n_l = min(n_rec, R_LDS);
-                for (int g0 = 0; g0 < n_l; g0 += RU * NT) {
-                    RecV r[RU];
-#pragma unroll
-                    for (int u = 0; u < RU; ++u) {
-                        const int idx = min(g0 + u * NT + tid, n_l - 1);
-                        r[u] = RecV{shm.rk[idx], shm.rm[idx], shm.rs[idx]};
-                    }
-                    body(r, g0, n_l);
-                }
-                for (int g0 = R_LDS; g0 < n_rec; g0 += RU * NT) {
-                    RecV r[RU];
-#pragma unroll
-                    for (int u = 0; u < RU; ++u) {
-                        const Rec3 q = ld_stream(srec, (uint32_t)(min(g0 + u * NT + tid, n_rec - 1) - R_LDS));
-                        r[u] = RecV{q.a, q.b, __uint_as_float(q.c)};
-                    }
-                    body(r, g0, n_rec);
-                }
-            };
-
-            // ---------------- select + blend ------------------------------------------------------------------------
+            // ---------------- select + pass 2 ---------------------------------------------------------------------
             // K-th smallest depth of every pixel that has more than K candidates, and log2 of every kept blend factor summed
             // per pixel.  threshold: depth bits of the K-th smallest (0x7F800000 = +inf bits: keep everything); tie_cut: among
-            // the faces exactly at the threshold those up to this face id are kept.  Every wave computes the per-pixel values
-            // (lane = pixel) from the shared histograms, so they need no broadcast.
+            // the faces exactly at the threshold those up to this list position are kept.
             uint32_t zt_bits = 0x7F800000u;
             int tie_cut = 0x7FFFFFFF;
             uint32_t pre = 0u;
-            int need = 0, n_eq = 0, nbits = nbits0 - b1, bprev = b1;
+            int need = 0, n_eq = 0, nbits = nbits0 - b1;
             bool trunc = false;
-            if (may_truncate && n_rec > 0) {
+            if (may_truncate && vbase > 0) {
                 need = K;
-                const int tot = pick_digit(sh.hist, lane, b1, pre, need, n_eq);
+                const int tot = pick_digit8(lds.hist, lane, b1, pre, need, n_eq);
                 trunc = tot > K;
                 if (!trunc) need = 0;
             }
             const bool any_trunc = __ballot(trunc) != 0ull;
-            __syncthreads();  // every wave has read the first digit's histogram (and is out of pass 1's LDS)
-            if (wv == 0) {
-                sh.plog[lane] = 0.0;
-                sh.psel[lane] = make_uint2(pre, (uint32_t)need);
-            }
+            // One sweep over all records.  A record of a pixel that is not truncated, or whose first digit is below the
+            // pixel's chosen one, is kept for certain: its log goes to the pixel's sum.  One inside the chosen digit goes on
+            // to the compact stream (with its log) and has its second digit counted; one above it is dropped.
+            lds.plog[lane] = 0.0;
+            lds.psel[lane] = make_uint2(pre, (uint32_t)need);
             const int b2 = min(SEL_BITS, nbits), shift2 = nbits - b2;
             if (any_trunc)
-                for (int i_ = tid; i_ < HIST_WORDS; i_ += NT) sh.hist[i_] = 0u;
+                for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
             __syncthreads();
-            TT(6)
-            // One sweep over all records.  A record of a pixel that is not truncated, or whose first digit is below the
-            // pixel's chosen one, is kept for certain: its log goes to the pixel's sum.  One inside the chosen digit has its
-            // index appended to the selection list and its second digit counted; one above it is dropped.
-            {
-                float rmax2 = 0.f;  // largest |closest point - pixel|^2 over the records: bounds the gradient sums of pass 3
-                for_records([&](const RecV (&r)[RU], int g0, int end) {
-                    uint2 ps[RU];
+            TSUB(0)
+            int n_cmp = 0;
+            float rmax2 = 0.f;  // largest |closest point - pixel|^2 over the records: bounds the gradient sums of pass 3
+            if (vbase > 0) {
+                struct Rec { uint32_t z, mt; float sd; };
+                auto load_recs = [&](Rec (&r)[DGROUP], int g0) {
 #pragma unroll
-                    for (int u = 0; u < RU; ++u) ps[u] = sh.psel[r[u].mt & 63u];
-                    bool maybe[RU];
-                    uint32_t key[RU];
-                    uint32_t n_may = 0u;
-#pragma unroll
-                    for (int u = 0; u < RU; ++u) {
-                        const bool valid = g0 + u * NT + tid < end;
-                        key[u] = r[u].z - kmin;
-                        const uint32_t d1 = key[u] >> nbits;
-                        const bool sure = valid & ((ps[u].y == 0u) | (d1 < ps[u].x));
-                        maybe[u] = valid & (ps[u].y > 0u) & (d1 == ps[u].x);
-                        rmax2 = fmaxf(rmax2, fabsf(r[u].sd));  // (the clamped tail repeats a record: harmless)
-                        const float lf = __log2f(1.0f - face_prob(r[u].sd, a.inv_sigma_log2e));
-                        if (sure & (lf != 0.f)) atomicAdd(&sh.plog[r[u].mt & 63u], (double)lf);
-                        if (any_trunc) n_may += (uint32_t)__popcll(__ballot(maybe[u]));
-                    }
-                    if (any_trunc && n_may != 0u) {  // wave-uniform: one reservation for the step's RU rows
-                        uint32_t base = 0u;
-                        if (lane == 0) base = atomicAdd(&sh.cmp_count, n_may);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-                        for (int u = 0; u < RU; ++u) {
-                            const unsigned long long km = __ballot(maybe[u]);
-                            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                            if (maybe[u]) {
-                                if (slot < (uint32_t)CMP_CAP) sh.cmp[slot] = (uint16_t)(g0 + u * NT + tid);
-                                const uint32_t bucket = (key[u] >> shift2) & ((1u << b2) - 1u);
-                                atomicAdd(&sh.hist[(bucket >> 1) * WAVE + (r[u].mt & 63u)], (bucket & 1u) ? 0x10000u : 1u);
-                            }
-                            base += (uint32_t)__popcll(km);
-                        }
-                    }
-                });
-                rmax2 = wave_max(rmax2);
-                if (lane == 0 && rmax2 > 0.f) atomicMax(&sh.rmax2_bits, __float_as_uint(rmax2));
-            }
-            __syncthreads();
-            TT(7)
-            if (any_trunc) {
-                const int n_cmp_all = (int)sh.cmp_count;
-                if (wv == 0) { TSTAT(4, n_cmp_all) }
-                const bool walk_all = n_cmp_all > CMP_CAP;          // the list overflowed: the sweeps below walk every record
-                const int n_cmp = walk_all ? n_rec : n_cmp_all;
-                // a sweep over the selection list, two records per thread and step; fn(record, valid)
-                auto for_selected = [&](auto &&fn) {
-                    for (int j0 = 0; j0 < n_cmp; j0 += 2 * NT) {
-                        RecV r[2];
-                        bool ok[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int j = j0 + u * NT + tid;
-                            ok[u] = j < n_cmp;
-                            const int jc = min(j, n_cmp - 1);
-                            r[u] = load_rec(walk_all ? (uint32_t)jc : (uint32_t)sh.cmp[jc]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) fn(r[u], ok[u]);
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, vbase - 1);
+                        const Rec3 q = ld_stream(srec, idx);
+                        r[u].z = q.a; r[u].mt = q.b; r[u].sd = __uint_as_float(q.c);
                     }
                 };
-                if (nbits > 0) {  // second digit: counted above
-                    pick_digit(sh.hist, lane, b2, pre, need, n_eq);
-                    nbits -= b2;
-                    bprev = b2;
+                auto blend_recs = [&](const Rec (&r)[DGROUP], int g0) {
+                    uint2 ps[DGROUP];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) ps[u] = lds.psel[r[u].mt & 63u];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const bool valid = g0 + u * WAVE + lane < vbase;
+                        const uint32_t key = r[u].z - kmin, d1 = key >> nbits;
+                        const bool sure = valid & ((ps[u].y == 0u) | (d1 < ps[u].x));
+                        const bool maybe = valid & (ps[u].y > 0u) & (d1 == ps[u].x);
+                        rmax2 = fmaxf(rmax2, fabsf(r[u].sd));  // (the clamped tail repeats a record: harmless)
+                        const float lf = __log2f(1.0f - face_prob(r[u].sd, a.inv_sigma_log2e));
+                        if (sure & (lf != 0.f)) atomicAdd(&lds.plog[r[u].mt & 63u], (double)lf);
+                        STAT(45, __popcll(__ballot(sure))) STAT(46, __popcll(__ballot(valid & !sure & !maybe)))
+                        if (any_trunc) {  // wave-uniform
+                            const unsigned long long km = __ballot(maybe);
+                            const uint32_t slot = (uint32_t)n_cmp + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                            if (maybe) {
+                                at(crec, slot) = Rec3{key, r[u].mt, __float_as_uint(lf)};
+                                const uint32_t bucket = (key >> shift2) & ((1u << b2) - 1u);
+                                atomicAdd(&lds.hist[(bucket >> 1) * WAVE + (r[u].mt & 63u)], (bucket & 1u) ? 0x10000u : 1u);
+                            }
+                            n_cmp += __popcll(km);
+                        }
+                    }
+                };
+                Rec ra[DGROUP], rb[DGROUP];
+                load_recs(ra, 0);
+                for (int g0 = 0; g0 < vbase; g0 += 2 * DGROUP * WAVE) {
+                    load_recs(rb, g0 + DGROUP * WAVE);
+                    blend_recs(ra, g0);
+                    load_recs(ra, g0 + 2 * DGROUP * WAVE);
+                    blend_recs(rb, g0 + DGROUP * WAVE);
                 }
-                // The remaining digits.  The list does not shrink: a record takes part in a sweep while its key agrees with the
-                // pixel's prefix down to the digit chosen last; one that agrees above that digit and lies below it there is kept
-                // for certain (its log goes to the pixel's sum exactly once, in the sweep after that digit was chosen).
+            }
+            __syncthreads();
+            TSUB(4)
+            if (any_trunc) {
+                if (nbits > 0) {  // second digit: counted above
+                    pick_digit(lds.hist, lane, b2, pre, need, n_eq);
+                    nbits -= b2;
+                    __syncthreads();
+                }
+                // refinement through memory while the compact stream is long (it shrinks about six-fold per sweep) ...
+                while (nbits > 0 && __ballot(need > 0) != 0ull && n_cmp > SELR * WAVE) {
+                    const int b = min(SEL_BITS, nbits);
+                    n_cmp = refine_sweep(lds, crec, n_cmp, nbits, b, lane, pre, need);
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
+                    nbits -= b;
+                    __syncthreads();
+                }
+                if (n_cmp <= SELR * WAVE) {
+                // ... then IN REGISTERS (round 4): a lane takes up to SELR of the remaining records and every further step - the digits
+                // still to go, the cut of a tie group by face id, the sum of the logs that made it - runs on them with the per-pixel
+                // histograms in LDS and no memory traffic at all.  Through memory each of those three to seven sweeps over a few
+                // hundred records was two exposed round trips (the first load, the drain of the in-place stores): the selection was
+                // 9.5 % of the launch for 23 % of the records.
+                constexpr uint32_t INV = 0xFFFFFFFFu;  // record that has left the selection (keys are below 2^31)
+                uint32_t rk[SELR], rm[SELR];
+                float rl[SELR];
+#pragma unroll
+                for (int r_ = 0; r_ < SELR; ++r_) {
+                    const int idx = r_ * WAVE + lane;
+                    const Rec3 q = at(crec, (uint32_t)min(idx, max(n_cmp - 1, 0)));
+                    rk[r_] = idx < n_cmp ? q.a : INV; rm[r_] = q.b; rl[r_] = __uint_as_float(q.c);
+                }
                 while (nbits > 0 && __ballot(need > 0) != 0ull) {
                     const int b = min(SEL_BITS, nbits), shift = nbits - b;
-                    __syncthreads();  // every wave has picked from the histogram
-                    if (wv == 0) sh.psel[lane] = make_uint2(pre, (uint32_t)need);
-                    for (int i_ = tid; i_ < HIST_WORDS; i_ += NT) sh.hist[i_] = 0u;
-                    __syncthreads();
-                    for_selected([&](const RecV &r, bool ok) {
-                        const uint32_t pxl = r.mt & 63u;
-                        const uint2 ps = sh.psel[pxl];
-                        const uint32_t key = r.z - kmin, top = key >> nbits;
-                        const bool live = ok & (ps.y > 0u) & ((top >> bprev) == (ps.x >> bprev));
-                        if (live & (top < ps.x)) {
-                            const float lf = __log2f(1.0f - face_prob(r.sd, a.inv_sigma_log2e));
-                            if (lf != 0.f) atomicAdd(&sh.plog[pxl], (double)lf);
+                    lds.psel[lane] = make_uint2(pre, (uint32_t)need);
+                    for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+                    lds_fence();
+                    uint2 ps[SELR];
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_) ps[r_] = lds.psel[rm[r_] & 63u];
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_) {
+                        const uint32_t pxl = rm[r_] & 63u;
+                        const bool live = (rk[r_] != INV) & (ps[r_].y > 0u);
+                        const uint32_t top = rk[r_] >> nbits;
+                        const bool sure = live & (top < ps[r_].x), stay = live & (top == ps[r_].x);
+                        if (sure & (rl[r_] != 0.f)) atomicAdd(&lds.plog[pxl], (double)rl[r_]);
+                        if (stay) {
+                            const uint32_t bucket = (rk[r_] >> shift) & ((1u << b) - 1u);
+                            atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
                         }
-                        if (live & (top == ps.x)) {
-                            const uint32_t bucket = (key >> shift) & ((1u << b) - 1u);
-                            atomicAdd(&sh.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
-                        }
-                    });
-                    __syncthreads();
-                    pick_digit(sh.hist, lane, b, pre, need, n_eq);
+                        rk[r_] = (live & !stay) ? INV : rk[r_];  // decided either way: it leaves
+                    }
+                    lds_fence();
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
                     nbits -= b;
-                    bprev = b;
+                    lds_fence();
                 }
                 if (trunc) zt_bits = pre + kmin;
                 // `need` of the n_eq faces at the threshold are kept: the ones with the smallest face ids
                 const bool split = trunc && need < n_eq;
-                const bool any_split_sel = __ballot(split) != 0ull;
-                if (any_split_sel) {
-                    // radix select on the face id among the records whose depth equals the pixel's threshold (rare: the ids are
-                    // fetched through the list only here)
-                    __syncthreads();
-                    if (wv == 0) sh.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
+                uint32_t rf[SELR];  // face ids of the records at the threshold of a split pixel (fetched only in tiles that have one)
+#pragma unroll
+                for (int r_ = 0; r_ < SELR; ++r_) rf[r_] = INV;
+                if (__ballot(split) != 0ull) {
+                    lds.psel[lane] = make_uint2(split ? pre : INV, 0u);
+                    lds_fence();
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_)
+                        if (rk[r_] != INV && rk[r_] == lds.psel[rm[r_] & 63u].x) rf[r_] = lst[(rm[r_] >> 6) & 0xFFFFu];
                     int pbits = 32 - __clz(max(a.FT - 1, 1));
                     uint32_t ppre = 0u;
                     int pneed = split ? need : 0, peq = 0;
+                    lds_fence();
                     while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
                         const int b = min(SEL_BITS, pbits), shift = pbits - b;
-                        __syncthreads();
-                        if (wv == 0) sh.psel[lane] = make_uint2(ppre, (uint32_t)pneed);
-                        for (int i_ = tid; i_ < HIST_WORDS; i_ += NT) sh.hist[i_] = 0u;
-                        __syncthreads();
-                        for_selected([&](const RecV &r, bool ok) {
-                            const uint32_t pxl = r.mt & 63u;
-                            const uint2 ps = sh.psel[pxl];
-                            if (ok & (ps.y > 0u) & (r.z - kmin == __float_as_uint(sh.pgrad[pxl].y))) {
-                                const uint32_t fid = (uint32_t)face_at((int)((r.mt >> 6) & 0xFFFFu));
-                                if ((fid >> pbits) == ps.x) {
-                                    const uint32_t bucket = (fid >> shift) & ((1u << b) - 1u);
-                                    atomicAdd(&sh.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
-                                }
-                            }
-                        });
-                        __syncthreads();
-                        pick_digit(sh.hist, lane, b, ppre, pneed, peq);
+                        lds.psel[lane] = make_uint2(ppre, (uint32_t)pneed);
+                        for (int i_ = lane; i_ < (1 << SEL_BITS) / 2 * WAVE; i_ += WAVE) lds.hist[i_] = 0u;
+                        lds_fence();
+#pragma unroll
+                        for (int r_ = 0; r_ < SELR; ++r_) {
+                            const uint32_t pxl = rm[r_] & 63u;
+                            const uint2 ps = lds.psel[pxl];
+                            const bool hit = (rf[r_] != INV) & (ps.y > 0u) & ((rf[r_] >> pbits) == ps.x);
+                            const uint32_t bucket = (rf[r_] >> shift) & ((1u << b) - 1u);
+                            if (hit) atomicAdd(&lds.hist[(bucket >> 1) * WAVE + pxl], (bucket & 1u) ? 0x10000u : 1u);
+                        }
+                        lds_fence();
+                        pick_digit(lds.hist, lane, b, ppre, pneed, peq);
                         pbits -= b;
+                        lds_fence();
                     }
                     if (split) tie_cut = (int)ppre;
                 }
-                // the selected records that made it and have not been counted yet: below the threshold in the digit chosen last,
-                // or at the threshold up to the tie cut
+                // the records still held that made it: depth below the threshold, or at it up to the tie cut
+                lds.psel[lane] = make_uint2(trunc ? pre : 0u, (uint32_t)tie_cut);
+                lds_fence();
+#pragma unroll
+                for (int r_ = 0; r_ < SELR; ++r_) {
+                    const uint32_t pxl = rm[r_] & 63u;
+                    const uint2 ps = lds.psel[pxl];
+                    const bool keep = (rk[r_] != INV) & ((rk[r_] < ps.x) | ((rk[r_] == ps.x) & (((int)ps.y == 0x7FFFFFFF) | ((int)rf[r_] <= (int)ps.y))));
+                    if (keep & (rl[r_] != 0.f)) atomicAdd(&lds.plog[pxl], (double)rl[r_]);
+                }
+                lds_fence();
+                } else {
+                // (the compact stream never got short - thousands of records tied in their first digits: everything through memory)
+                while (nbits > 0 && __ballot(need > 0) != 0ull) {
+                    const int b = min(SEL_BITS, nbits);
+                    n_cmp = refine_sweep(lds, crec, n_cmp, nbits, b, lane, pre, need);
+                    pick_digit(lds.hist, lane, b, pre, need, n_eq);
+                    nbits -= b;
+                    __syncthreads();
+                }
+                if (trunc) zt_bits = pre + kmin;
+                // `need` of the n_eq faces at the threshold are kept: the first ones in list order
+                const bool split = trunc && need < n_eq;
+                if (__ballot(split) != 0ull) {
+                    // select on the list position among the records whose depth equals the pixel's threshold
+                    lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
+                    __syncthreads();
+                    int pbits = 32 - __clz(max(a.FT - 1, 1));  // the tie key is the face id (the list is in near-to-far order)
+                    uint32_t ppre = 0u;
+                    int pneed = split ? need : 0, peq = 0;
+                    auto pos_key = [&](uint32_t idx, uint32_t mt) {
+                        // records of other depths get the key 0xFFFFFFFF, which select_sweep ignores
+                        return at(crec, idx).a == __float_as_uint(lds.pgrad[mt & 63u].y) ? lst[(mt >> 6) & 0xFFFFu] : 0xFFFFFFFFu;
+                    };
+                    while (pbits > 0 && __ballot(pneed > 0) != 0ull) {
+                        const int b = min(SEL_BITS, pbits);
+                        select_sweep(lds, crec, n_cmp, pbits, b, lane, ppre, pneed, pos_key);
+                        pick_digit(lds.hist, lane, b, ppre, pneed, peq);
+                        pbits -= b;
+                        __syncthreads();
+                    }
+                    if (split) tie_cut = (int)ppre;
+                }
+                // the compact records still in the stream (those of the last bucket examined) that made it: depth below the
+                // threshold, or at it up to the tie cut
+                lds.pgrad[lane] = make_float4(0.f, __uint_as_float(trunc ? pre : 0u), __int_as_float(tie_cut), 0.f);
+                const bool any_split_sel = __ballot(tie_cut != 0x7FFFFFFF) != 0ull;
                 __syncthreads();
-                if (wv == 0) {
-                    sh.psel[lane] = make_uint2(trunc ? pre : 0u, trunc ? 1u : 0u);
-                    sh.pgrad[lane] = make_float4(0.f, 0.f, __int_as_float(tie_cut), 0.f);
+                for (int g0 = 0; g0 < n_cmp; g0 += DGROUP * WAVE) {
+                    uint32_t kk[DGROUP], mt[DGROUP];
+                    float lf[DGROUP];
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, n_cmp - 1);
+                        const Rec3 q = at(crec, idx);
+                        kk[u] = q.a; mt[u] = q.b; lf[u] = __uint_as_float(q.c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < DGROUP; ++u) {
+                        const float4 pg = lds.pgrad[mt[u] & 63u];
+                        const uint32_t zt_ = __float_as_uint(pg.y);
+                        // a record AT the threshold depth of a pixel whose tie group straddles K is kept up to the cut in face id
+                        // (rare: the id is fetched only then)
+                        const bool in_range = g0 + u * WAVE + lane < n_cmp;
+                        bool tie_ok = true;
+                        if (any_split_sel) {  // wave-uniform
+                            const int cut = __float_as_int(pg.z);
+                            int fid = 0;
+                            if (in_range & (kk[u] == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[(mt[u] >> 6) & 0xFFFFu];
+                            tie_ok = fid <= cut;
+                        }
+                        const bool keep = in_range & ((kk[u] < zt_) | ((kk[u] == zt_) & tie_ok));
+                        if (keep & (lf[u] != 0.f)) atomicAdd(&lds.plog[mt[u] & 63u], (double)lf[u]);
+                    }
                 }
                 __syncthreads();
-                for_selected([&](const RecV &r, bool ok) {
-                    const uint32_t pxl = r.mt & 63u;
-                    const uint2 ps = sh.psel[pxl];
-                    const uint32_t key = r.z - kmin;
-                    const bool live = ok & (ps.y > 0u) & ((key >> bprev) == (ps.x >> bprev));
-                    bool keep = live & (key < ps.x);
-                    if (live & (key == ps.x)) {
-                        const int cut = __float_as_int(sh.pgrad[pxl].z);
-                        keep = cut == 0x7FFFFFFF || face_at((int)((r.mt >> 6) & 0xFFFFu)) <= cut;
-                    }
-                    if (keep) {
-                        const float lf = __log2f(1.0f - face_prob(r.sd, a.inv_sigma_log2e));
-                        if (lf != 0.f) atomicAdd(&sh.plog[pxl], (double)lf);
-                    }
-                });
-                __syncthreads();
+                }
             }
-            TT(8)
-            const double plog_px = sh.plog[lane];
+            TMARK(2)
+            TSUB(5)
+            HOOK_STOP_AFTER(3, { p_lo += span; continue; })
+            STAT(22, n_cmp) STAT(23, __popcll(__ballot(trunc))) STAT(24, __popcll(__ballot(lds.plog[lane] != 0.0)))
+            STAT(40, any_trunc ? 1 : 0) STAT(41, may_truncate ? 1 : 0) STAT(42, any_trunc ? vbase : 0) STAT(43, may_truncate ? vbase : 0) STAT(44, __popcll(__ballot(tie_cut != 0x7FFFFFFF)))
+            const double plog_px = lds.plog[lane];
             const float alpha = exp2f((float)plog_px);
+            TMARK(3)
 
-            // ---------------- epilogue: silhouette value, loss, upstream gradient (side effects: wave 0) --------------------
+            // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
             const float silv = 1.0f - alpha;
             const bool own = in_img && mine;
             float g = 0.f;
             if (MODE == MODE_FWD) {
-                if (own && wv == 0) a.sil[pix] = silv;
+                if (own) a.sil[pix] = silv;
             } else if (MODE == MODE_BWD) {
                 if (own) g = a.grad_sil[pix];
             } else {
@@ -1526,23 +1719,22 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                     const float diff = silv - tg;
                     lsum = fabsf(diff) - fabsf(tg);  // loss_img starts at sum |0 - target|
                     g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
-                    if (a.sil && wv == 0) a.sil[pix] = silv;
+                    if (a.sil) a.sil[pix] = silv;
                 }
-                if (wv == 0) {
-                    lsum = wave_sum(lsum);
-                    if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
-                }
+                lsum = wave_sum(lsum);
+                if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
             }
 
-            // ---------------- pass 3: thread = record -------------------------------------------------
+            // ---------------- pass 3: lane = record -------------------------------------------------
             // d sil / d dist_k = -alpha p_k / sigma   (alpha = prod_j (1 - p_j); exact also when 1 - p_k == 0)
             const float coef = -g * alpha * a.inv_sigma;
             // (a pixel whose records all have 1 - p == 1 in fp32 - or that has none - hands nothing back: its coefficient must not enter
             // the fixed-point bound below either, or a tile of empty pixels sets the resolution for its one contributing pixel)
             const bool active = own && (g != 0.f) && (alpha > ALPHA_GRAD_EPS) && (plog_px != 0.0);
             const bool any_split = __ballot(tie_cut != 0x7FFFFFFF) != 0ull;  // a pixel whose tie group at the K-th depth is cut by face id
-            TT(9)
-            if (MODE != MODE_FWD && __ballot(active) != 0ull) {  // (workgroup-uniform: every wave holds the same per-pixel values)
+            TSUB(6)
+            STAT(25, __popcll(__ballot(active)))
+            if (MODE != MODE_FWD && __ballot(active) != 0ull) {
                 float *dn = a.d_ndc + (size_t)n * a.V * 2;
                 // Fixed point for the LDS accumulators.  One accumulator component receives at most one record per pixel,
                 // each of magnitude <= 2 |r| |coef_pixel| p_k max(t, 1 - t) <= 2 r_max |coef_pixel|, so no partial sum
@@ -1551,78 +1743,88 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                 // exact, and the resolution is bound / 2^30: ~1e-9 of the tile's largest possible gradient sum, below the
                 // fp32 rounding of the global atomics the sums end in.  Integer sums are order independent.
                 const float csum = wave_sum(active ? fabsf(coef) : 0.f);
-                const float bound = 2.0f * sqrtf(__uint_as_float(sh.rmax2_bits)) * csum;
+                const float bound = 2.0f * sqrtf(wave_max(rmax2)) * csum;
                 // Packed launches accumulate in the IMAGE's fixed-point scale right away (image_fx_scale: no vertex component of the
                 // image can overflow it, so no partial sum can): every contribution is rounded once, per record, and from there on
                 // all sums - LDS, flush, memory-side atomics - are integer adds, exact in any order and any grouping of faces.
                 // (an image with cut faces stays on float atomics, see k_raster_setup)
-                const bool img_fixed = MODE == MODE_FUSED && a.packed && a.clip.xcount[n] == 0u;  // (uniform)
+                const bool img_fixed = MODE == MODE_FUSED && a.packed && a.clip.xcount[n] == 0u;  // (wave-uniform)
                 const float fx_scale = img_fixed ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma)
                                        : (bound > 0.f && bound < 3.0e38f) ? exp2f(fminf(29.0f - floorf(log2f(bound)), 100.0f)) : 0.f;
                 const float fx_inv = fx_scale > 0.f ? 1.0f / fx_scale : 0.f;
-                __syncthreads();  // (the selection is done with pgrad / psel)
-                if (wv == 0) sh.pgrad[lane] = make_float4(active ? coef * fx_scale : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
+                lds.pgrad[lane] = make_float4(active ? coef * fx_scale : 0.f, __uint_as_float(zt_bits), __int_as_float(tie_cut), 0.f);
+                __syncthreads();
+                constexpr int GR = GCHUNK / DCHUNK;
+                static_assert(GCHUNK == WAVE, "pass 3: lane = face of the group");
+                const uint32_t copy_off = (uint32_t)(lane & (GCOPIES - 1)) * (GCHUNK * 3);
                 float *const xg_n = a.clip.xg + (size_t)n * CLIP_VX * 2;  // gradient rows of the image's new vertices (cut faces)
-                constexpr int WSLOTS = (GWIN + NT - 1) / NT;  // faces of a window per thread
-                for (int w0 = 0; w0 < n_walked; w0 += GWIN) {
-                    // the window's faces: vertex ids (kept for the flush) and projected vertices, from which a record's edge
-                    // parameter t is recomputed; accumulators cleared
-                    int vid[WSLOTS][3];
-                    __syncthreads();  // the previous window's flush has read its accumulators (first window: pgrad is in place)
+                // the group's projected vertices, from which a record's edge parameter t is recomputed (4 bytes less written and
+                // read per record than storing it); the table lives where the selection histograms were
+                float2 *const fv = reinterpret_cast<float2 *>(lds.hist);  // [GCHUNK][3]
+                static_assert(GCHUNK * 3 * sizeof(float2) <= sizeof(lds.hist), "the vertex table of a group lives in the histogram area");
+                TP3_START
+                for (int ch = 0; ch < chunks_done; ch += GR) {
+                    const int i_beg = (int)chunk_start(ch), i_end = (int)chunk_start(min(ch + GR, chunks_done));  // (registers: no memory round trip)
+                    if (i_beg == i_end) continue;
+                    TP3(0)
+                    // lane = face of the group: its projected vertices and vertex ids as pass 1 left them in the tile's table (one round
+                    // trip, requested together with the first records; the list -> face -> vertex chain they replace was three)
+                    const int fch = ch * DCHUNK + lane;
+                    const bool staged = fch < chunks_done * DCHUNK && fch < list_total;
+                    const uint32_t fcl = (uint32_t)min(fch, list_total - 1);
+                    const float2 tv0 = at(sxy, fcl), tv1 = at(sxy, (uint32_t)a.list_stride + fcl), tv2 = at(sxy, 2u * (uint32_t)a.list_stride + fcl);
+                    const TriIds tid = at(sid, fcl);
+                    struct GRec { uint32_t z, mt; float sd; };
+                    auto load_recs = [&](GRec (&r)[DGROUP], int g0) {
 #pragma unroll
-                    for (int s = 0; s < WSLOTS; ++s) {
-                        const int t_ = s * NT + tid;
-                        if (t_ < GWIN) {
-                            const int f_ = face_at(min(w0 + t_, list_total - 1));
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                vid[s][k] = face_vertex(a.faces, xf_n, a.F, f_, k);
-                                const float *p_ = vertex_ptr(vn, xv_n, a.V, vid[s][k]);
-                                sh.fv[t_ * 3 + k] = make_float2(p_[0], p_[1]);
-                                sh.gacc[t_ * 3 + k] = 0ull;
-                            }
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const uint32_t idx = (uint32_t)min(g0 + u * WAVE + lane, i_end - 1);  // clamped: the tail repeats the last record
+                            const Rec3 q = ld_stream(srec, idx);
+                            r[u].z = q.a; r[u].mt = q.b; r[u].sd = __uint_as_float(q.c);
                         }
-                    }
-                    __syncthreads();
-                    TT(10)
-                    for_records([&](const RecV (&r)[RU], int g0, int end) {
-                        float4 pg[RU];
-                        float2 pa[RU], pb[RU], pc[RU];
-                        uint32_t oa[RU], ob[RU];
-                        bool inw[RU];
-                        bool any_in = false;
+                    };
+                    GRec ra[DGROUP], rb[DGROUP];
+                    load_recs(ra, i_beg);
+                    fv[lane * 3 + 0] = tv0;
+                    fv[lane * 3 + 1] = tv1;
+                    fv[lane * 3 + 2] = tv2;
+                    TP3(1)
+                    for (int i_ = lane; i_ < GCOPIES * GCHUNK * 3; i_ += WAVE) (&lds.gacc[0][0])[i_] = 0ull;
+                    lds_fence();
+                    TP3(2)
+                    // One row of records per lane and step, DGROUP rows per buffer.  Straight-line code: every lane computes its record's
+                    // contribution whether it is kept or not and only the two accumulator adds are predicated, so that the LDS gathers of
+                    // all rows of a buffer are in flight together (a branch per record kept each row's gathers behind the previous row's
+                    // conflicting atomics: one exposed LDS round trip per row).
+                    auto grad_recs = [&](const GRec (&r)[DGROUP], int g0) {
+                        float4 pg[DGROUP];
+                        float2 pa[DGROUP], pb[DGROUP], pc[DGROUP];
+                        uint32_t oa[DGROUP], ob[DGROUP];
 #pragma unroll
-                        for (int u = 0; u < RU; ++u) {
-                            const uint32_t rel = ((r[u].mt >> 6) & 0xFFFFu) - (uint32_t)w0;  // list position inside the window?
-                            inw[u] = (g0 + u * NT + tid < end) & (rel < (uint32_t)GWIN);
-                            any_in |= inw[u];
-                        }
-                        if (__ballot(any_in) == 0ull) return;  // wave-uniform: none of this step's records belongs to the window
-#pragma unroll
-                        for (int u = 0; u < RU; ++u) {
+                        for (int u = 0; u < DGROUP; ++u) {
                             const uint32_t mt = r[u].mt;
-                            const uint32_t rel = min(((mt >> 6) & 0xFFFFu) - (uint32_t)w0, (uint32_t)(GWIN - 1));
-                            const uint32_t f3 = rel * 3u;
+                            const uint32_t f3 = ((mt >> 6) & (uint32_t)(GCHUNK - 1)) * 3u;  // (list position % GCHUNK) * 3
                             const uint32_t edge = mt >> 23;
                             oa[u] = f3 + (edge == 2u ? 1u : 0u); ob[u] = f3 + (edge == 0u ? 1u : 2u);  // end points of the closest edge
-                            pg[u] = sh.pgrad[mt & 63u];
-                            pa[u] = sh.fv[oa[u]]; pb[u] = sh.fv[ob[u]]; pc[u] = sh.pixt[mt & 63u];
+                            pg[u] = lds.pgrad[mt & 63u];
+                            pa[u] = fv[oa[u]]; pb[u] = fv[ob[u]]; pc[u] = lds.pixt[mt & 63u];
                         }
 #pragma unroll
-                        for (int u = 0; u < RU; ++u) {
+                        for (int u = 0; u < DGROUP; ++u) {
+                            const bool valid = g0 + u * WAVE + lane < i_end;
                             const uint32_t mt = r[u].mt;
                             const uint32_t zt_ = __float_as_uint(pg[u].y);
                             const bool inside = ((mt >> 22) & 1u) != 0u;
                             float gd = pg[u].x * face_prob(r[u].sd, a.inv_sigma_log2e);                 // scale * d L / d (signed dist)
                             gd = inside ? -gd : gd;                                               // ... / d (unsigned squared distance)
-                            bool tie_ok = true;  // (only a record at the threshold of a split tie group needs its face id)
-                            if (any_split) {  // uniform and rare: the fetch and the wait for it stay out of the common path
+                            bool tie_ok = true;  // (as in the blend: only a record at the threshold of a split tie group needs its face id)
+                            if (any_split) {  // wave-uniform and rare: the fetch and the wait for it stay out of the common path
                                 const int cut = __float_as_int(pg[u].z);
                                 int fid = 0;
-                                if (inw[u] & (r[u].z == zt_) & (cut != 0x7FFFFFFF)) fid = face_at((int)((mt >> 6) & 0xFFFFu));
+                                if (valid & (r[u].z == zt_) & (cut != 0x7FFFFFFF)) fid = (int)lst[(mt >> 6) & 0xFFFFu];
                                 tie_ok = fid <= cut;
                             }
-                            const bool keep = inw[u] & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & tie_ok));
+                            const bool keep = valid & (gd != 0.f) & ((r[u].z < zt_) | ((r[u].z == zt_) & tie_ok));
                             // closest point of that edge: clamped projection of the pixel, as eval_pair computed it (t = 0 for a
                             // degenerate edge); r = closest point - pixel
                             const float exx = pb[u].x - pa[u].x, eyy = pb[u].y - pa[u].y;
@@ -1638,43 +1840,53 @@ __global__ void __launch_bounds__(NT, TILE_WG_PER_CU * NW / 4) k_raster_tile(Ras
                             };
                             const unsigned long long ga = pack(ex - bx, ey - by), gb = pack(bx, by);
                             if (keep) {
-                                atomicAdd(&sh.gacc[oa[u]], ga);
-                                atomicAdd(&sh.gacc[ob[u]], gb);
+                                unsigned long long *acc = &lds.gacc[0][0] + copy_off;
+                                atomicAdd(acc + oa[u], ga);
+                                atomicAdd(acc + ob[u], gb);
                             }
                         }
-                    });
-                    __syncthreads();
-                    TT(11)
-                    // flush: unpack, one global atomic per touched vertex component
+                    };
+                    for (int g0 = i_beg; g0 < i_end; g0 += 2 * DGROUP * WAVE) {
+                        load_recs(rb, g0 + DGROUP * WAVE);
+                        grad_recs(ra, g0);
+                        load_recs(ra, g0 + 2 * DGROUP * WAVE);
+                        grad_recs(rb, g0 + DGROUP * WAVE);
+                    }
+                    TP3(3)
+                    lds_fence();
+                    TP3(4)
+                    if (staged) {  // flush: sum the copies, unpack, one global atomic per touched vertex component
+                        const int vi[3] = {tid.a, tid.b, tid.c};
 #pragma unroll
-                    for (int s = 0; s < WSLOTS; ++s) {
-                        const int t_ = s * NT + tid;
-                        if (t_ < GWIN && w0 + t_ < n_walked) {
+                        for (int k = 0; k < 3; ++k) {
+                            unsigned long long tot = 0ull;
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const unsigned long long tot = sh.gacc[t_ * 3 + k];
-                                if (tot == 0ull) continue;
-                                if (img_fixed) {  // uniform: the sum is already in the image's scale
-                                    atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vid[s][k], tot);
-                                    continue;
-                                }
-                                const int qy = (int)(uint32_t)tot;
-                                const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
-                                float *const row = vid[s][k] < a.V ? dn + 2 * vid[s][k] : xg_n + 2 * (vid[s][k] - a.V);  // (a vertex of a cut face's front part: its own table)
-                                if (qx != 0) atomicAdd(row, (float)qx * fx_inv);
-                                if (qy != 0) atomicAdd(row + 1, (float)qy * fx_inv);
+                            for (int c = 0; c < GCOPIES; ++c) tot += lds.gacc[c][lane * 3 + k];
+                            if (img_fixed) {  // wave-uniform: the sum is already in the image's scale
+                                if (tot != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + vi[k], tot);
+                                continue;
                             }
+                            const int qy = (int)(uint32_t)tot;
+                            const int qx = (int)(uint32_t)((tot - (unsigned long long)(long long)qy) >> 32);
+                            float *const row = vi[k] < a.V ? dn + 2 * vi[k] : xg_n + 2 * (vi[k] - a.V);  // (a vertex of a cut face's front part: its own table)
+                            if (qx != 0) atomicAdd(row, (float)qx * fx_inv);
+                            if (qy != 0) atomicAdd(row + 1, (float)qy * fx_inv);
                         }
                     }
+                    lds_fence();  // the accumulators are read before the next group clears them; unlike __syncthreads() this does
+                                  // not wait for the flush's global atomics to be acknowledged (a microsecond per group)
+                    TP3(5)
                 }
             }
-            TT(12)
+            __syncthreads();
+            TMARK(4)
+            TSUB(7)
             p_lo += span;
         }
+        TUNIT_END
     }
-    TT(13)
     }  // next partition
-    TT_FLUSH
+    TIMERS_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1695,16 +1907,21 @@ static int device_cus() {
 }
 
 static int tile_grid(int N, int tiles_x) {
-    // persistent workgroups, TILE_WG_PER_CU per CU (what their LDS allows); never more than there are tiles
-    const long long max_items = (long long)N * tiles_x * tiles_x;
-    const long long resident = (long long)device_cus() * TILE_WG_PER_CU;
+    // (a handful of images: a tile is dealt out in up to 8 runs of pixels - see split_log in the tile kernel - so the launch can use
+    // 8 workgroups per tile; before round 4 a one-image launch got 1 024 workgroups for its ~2 400 possible pieces and split in two)
+    const long long max_items = (long long)N * tiles_x * tiles_x * 8;
+    long long resident = (long long)device_cus() * RESIDENT_PER_CU;
+    HOOK_RESIDENT(resident)
     return (int)(max_items < resident ? max_items : resident);
 }
 
 // per resident workgroup: F x {face id, nearest depth} in id order (tiles of images that are not binned), F face ids in walking order,
-// and the spill stream of (REC_CAP + REC_PAD) 12-byte records (written only by tiles with more than R_LDS records)
+// F x {projected vertices (24 B), vertex ids (12 B)} by list position, F / DCHUNK + 2 chunk starts,
+// (REC_CAP + REC_PAD) x (one 12-byte record + one 12-byte compact record)
+#define N_STREAMS 6
 static inline size_t scratch_bytes(int grid, int F) {
-    return (size_t)grid * (3 * align256((size_t)F * sizeof(uint32_t)) + (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3));
+    return (size_t)grid * (12 * align256((size_t)F * sizeof(uint32_t)) + align256((size_t)(F / DCHUNK + 2) * sizeof(uint32_t)) +
+                           (size_t)(REC_CAP + REC_PAD) * N_STREAMS * sizeof(uint32_t));
 }
 
 // binned tile lists: LIST_CAP_PER_FACE entries per face and image (8 bytes each) + one depth range per tile; images with more than
@@ -1755,7 +1972,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
                  "raster: faces_per_pixel=%d outside 1..%d", rs->faces_per_pixel, SMIL_MAX_FACES_PER_PIXEL);
     SMIL_REQUIRE(rs->sigma > 0.f && rs->blur_radius >= 0.f, "raster: bad blend settings");
-    SMIL_REQUIRE(face_rows(m) < REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP - CLIP_FX - WAVE - 1);
+    SMIL_REQUIRE(face_rows(m) <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP - CLIP_FX - WAVE);
     const int tiles_x = ceil_div(S, TILE);
     SMIL_REQUIRE((double)N * tiles_x * tiles_x < 2147483647.0, "raster: N * tiles exceeds the work-item index range (2^31); launch in slices");
     char *ws = (char *)workspace;
@@ -1801,12 +2018,21 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     {
         const size_t grid = (size_t)tile_grid(N, tiles_x);
         a.list_stride = (int)(align256((size_t)FT * sizeof(uint32_t)) / sizeof(uint32_t));
+        a.n_cf = (int)(align256((size_t)(FT / DCHUNK + 2) * sizeof(uint32_t)) / sizeof(uint32_t));
         ws += 256;
         a.slist = (uint2 *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(uint2);
         a.slist2 = (uint32_t *)ws;
         ws += grid * (size_t)a.list_stride * sizeof(uint32_t);
-        a.srec = (Rec3 *)ws;
+        a.scfirst = (uint32_t *)ws;
+        ws += grid * (size_t)a.n_cf * sizeof(uint32_t);
+        a.sxy = (float2 *)ws;
+        ws += grid * (size_t)a.list_stride * 3 * sizeof(float2);
+        a.sid = (TriIds *)ws;
+        ws += grid * (size_t)a.list_stride * sizeof(TriIds);
+        const size_t stream = grid * (size_t)(REC_CAP + REC_PAD) * sizeof(Rec3);
+        a.srec = (Rec3 *)ws; ws += stream;
+        a.crec = (Rec3 *)ws;
     }
     a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT;
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
@@ -1863,7 +2089,7 @@ extern "C" int smil_profile_read(float *total_ms, int32_t *launches) {
 
 template <int MODE>
 static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
-    hipLaunchKernelGGL((k_raster_tile<MODE>), dim3(tile_grid(N, a.tiles_x)), dim3(NT), 0, stream, a);
+    hipLaunchKernelGGL((k_raster_dense<MODE>), dim3(tile_grid(N, a.tiles_x)), dim3(64), 0, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

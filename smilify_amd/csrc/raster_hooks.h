@@ -1,14 +1,26 @@
-// Instrumentation hooks of the rasteriser kernels.  The product (libsmilfit.so) compiles them to nothing; `make variant` defines
-// SMIL_INSTRUMENTED and takes the real definitions from tools/dbg/raster_hooks_dbg.h (phase timers of the tile kernel -DTILE_TIMERS,
-// phase marks / ablations of the setup kernel -DDBG_SETUP_TIMERS, -DABL_SETUP_*).
+// Instrumentation hooks of the tile kernel.  The product (libsmilfit.so) compiles them to nothing; `make variant` defines
+// SMIL_INSTRUMENTED and takes the real definitions from tools/dbg/raster_hooks_dbg.h (phase timers -DDBG_TIMERS, work counters
+// -DDBG_STATS, cut-off / wrap / resident experiments -DRASTER_EXPERIMENT, dummy VALU -DABL_EXTRA_VALU=n).
 #pragma once
 #ifdef SMIL_INSTRUMENTED
 #include "raster_hooks_dbg.h"
 #else
-#define TT_INIT
-#define TT(k)
-#define TSTAT(k, v)
-#define TT_FLUSH
+#define TIMERS_INIT
+#define TSUB(k)
+#define TMARK(k)
+#define TP3_START
+#define TP3(k)
+#define STAT(k, v)
+#define TIMERS_FLUSH
+#define TUNIT_START
+#define TUNIT_END
+#define TSTAGE_MARK
+#define TSWEEP_MARK
+#define HOOK_WRAP_IDX(i) (i)
+#define HOOK_SPLIT_LOG(x) (x)
+#define HOOK_STOP_AFTER(k, stmt)
+#define HOOK_RESIDENT(resident)
+#define HOOK_EXTRA_VALU(pc)
 #define HOOK_ARGS_FIELDS
 #define HOOK_HOST_LAUNCH_SETUP(a, stream)
 #define TSETUP_INIT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Stall / cache diagnostics of the fused tile kernel: several rocprofv3 --pmc passes (counters only, program directly after "--").
 #   tools/pmc_diag.sh <tag> <probe args...>     e.g. tools/pmc_diag.sh cfg2b --frames 4096
-# Prints the per-launch mean of every counter for k_raster_tile.
+# Prints the per-launch mean of every counter for k_raster_dense.
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/diag_$tag; rm -rf $out; mkdir -p $out
@@ -28,7 +28,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(list)
 for path in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
-        if "k_raster_tile" in r["Kernel_Name"]:
+        if "k_raster_dense" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]

@@ -22,7 +22,7 @@ for name in ("fetch", "write", "sq"):
         continue
     path = found[0]
     for r in csv.DictReader(open(path)):
-        if "k_raster_tile<2>" in r["Kernel_Name"]:
+        if "k_raster_dense<2>" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             acc["_vgpr"].append(float(r["VGPR_Count"])); acc["_lds"].append(float(r["LDS_Block_Size"])); acc["_grid"].append(float(r["Grid_Size"]))
 mean = {k: sum(v) / len(v) for k, v in acc.items()}
@@ -31,7 +31,7 @@ if missing:  # a partial set of passes must not become the bench line's `traffic
     raise SystemExit(f"pmc_summary: no rows for {missing} under {base}: all three passes of tools/pmc_traffic.sh are required")
 out_path = os.path.join(REPO, "profiles", f"{rnd}_traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-entry = {"source": f"rocprofv3 --pmc, separate passes (tools/pmc_traffic.sh {tag}); kernel k_raster_tile<2>, mean over {len(acc.get('FETCH_SIZE', []))} dispatches",
+entry = {"source": f"rocprofv3 --pmc, separate passes (tools/pmc_traffic.sh {tag}); kernel k_raster_dense<2>, mean over {len(acc.get('FETCH_SIZE', []))} dispatches",
          "images_per_launch": n_img, "FETCH_SIZE_KB": mean.get("FETCH_SIZE"), "WRITE_SIZE_KB": mean.get("WRITE_SIZE"), "fetch_correction": 2.0,
          "fetch_correction_note": "calibrated for 4 B/lane coalesced reads: profiles/r2_fetch_calib.txt (tools/dbg/fetch_calib.hip)",
          "sq": {k: v for k, v in mean.items() if k.startswith("SQ_")}, "vgpr": mean.get("_vgpr"), "lds_bytes": mean.get("_lds"), "grid": mean.get("_grid")}

@@ -173,6 +173,42 @@ def parity_check(fitter, tables, wl, sample, window):
                     "(depth, face id) tie rule, DESIGN.md section 4)"}
 
 
+def time_other_workload(key, dev, steps=5, warmup=2, frames=0, graph=False):
+    """One of the other BASELINE configurations, timed AFTER the headline region and outside it (rank 0, one GPU): the same fit
+    iteration on that configuration's own synthetic problem.  Returns ms per step, the tile kernel's average launch time from
+    HIP events, and the roofline fraction by the same definition as the headline (algorithmic bytes per launch / kernel time)."""
+    from smilify_amd import engine, model_io, synthetic
+
+    wl = WORKLOADS[key]
+    tables = model_io.load_model(os.path.join(REPO, "data", "models", wl["model"] + ".npz"))
+    n_frames, views, S = (frames or wl["frames"]), wl["views"], wl["S"]
+    fitter = synthetic.make_problem(tables, n_frames, views, S, dev, radius=wl["radius"], seed=1234, window=10)
+    fitter.begin_stage(synthetic.STAGE1_LR, fov_lr=1.0)
+    step = fitter.fit_step_graph if graph else fitter.fit_step
+    for _ in range(warmup):
+        step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)
+    torch.cuda.synchronize()
+    engine.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = engine.profile_read()
+    engine.profile_enable(False)
+    per_view, _ = algorithmic_bytes(tables.V, tables.J, S, views)
+    n_img = n_frames * views
+    launches_per_step = max(1, round(kern_n / max(steps, 1)))
+    kern_avg = kern_ms / max(kern_n, 1)
+    achieved = (n_img / launches_per_step * per_view) / (kern_avg * 1e-3) / 1e9 if kern_n else 0.0
+    out = {"workload": wl["name"] + (f" [--frames {n_frames}]" if frames else ""), "frames": n_frames, "images": n_img, "steps": steps,
+           "ms_per_step": 1000.0 * dt / steps, "frame_iters_per_s": n_frames / (dt / steps), "kernel_ms": kern_avg if kern_n else None,
+           "launches_per_step": launches_per_step, "frac": achieved / HBM_PEAK_GBS if kern_n else None}
+    del fitter
+    torch.cuda.empty_cache()
+    return out
+
+
 def relaunch_multi_gpu(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD
     process (never exec: nothing here has touched the GPU yet, and it stays that way in this process), relay its output
@@ -203,6 +239,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-gpu rehearses the multi-rank path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only; never for reported numbers)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the short runs of the other BASELINE configurations behind the headline region (default workload, one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -361,6 +399,16 @@ def main():
             out["parity_check"] = parity
         if n_cpu:
             out["cpu_baseline"] = cpu_baseline(tables, wl, sample, window)
+        if world == 1 and args.workload == "cfg2b" and not args.frames and not args.no_others:
+            # the other BASELINE configurations as the driver sees them: five steps each, after the headline's timed region and
+            # outside it (headline metric / config / dtype unchanged); the one-frame iteration is the only shape the unmodified
+            # reference can run
+            del fitter
+            torch.cuda.empty_cache()
+            others = {k: time_other_workload(k, dev) for k in ("cfg2", "cfg3", "cfg4")}
+            others["one_frame_eager"] = time_other_workload("cfg2", dev, steps=50, warmup=5, frames=1)
+            others["one_frame_graph"] = time_other_workload("cfg2", dev, steps=50, warmup=5, frames=1, graph=True)
+            out["other_workloads"] = others
         print(json.dumps(out), flush=True)
         if parity is not None and not parity["ok"]:
             print(f"bench.py: parity check FAILED: {parity}", file=sys.stderr, flush=True)

@@ -227,8 +227,13 @@ __device__ __forceinline__ float image_fx_scale(float img_bound, float pix_scale
 
 // Element i of a per-workgroup stream: uniform base pointer + 32-bit byte offset, which hipcc turns into the SGPR-base /
 // VGPR-offset form of the global load / store (a 64-bit address per lane costs two extra VALU instructions per access).
-// (12-byte elements: the index is below 2^24, so the full-rate 24-bit multiply is exact; left to itself hipcc emits the
-// quarter-rate v_mul_lo_u32, also for the shift-and-add spelling)
+// (12-byte elements: the index must be below 2^24, so that the full-rate 24-bit multiply is exact; left to itself hipcc emits the
+// quarter-rate v_mul_lo_u32, also for the shift-and-add spelling.  ONLY for per-workgroup / per-image arrays whose length the
+// host bounds - REC_CAP + REC_PAD records, list_stride entries, both checked in raster_common.  An array whose index grows with
+// the number of images must not come through here: a round-4 experiment stored its 12-byte work items this way, the index
+// reaches 16 * ceil(N / 8) * tiles = 18.9e6 > 2^24 at 2 304 images @512^2, partition 7's items landed 2^24 elements early and the
+// tile kernel read stale words as work items - the GPU abort of gpurun_out/r4/tests_itb.txt, DESIGN.md section 8.  The shipped
+// work items are 16 bytes and plainly indexed.)
 template <typename T>
 __device__ __forceinline__ uint32_t byte_offset(uint32_t i) {
     if (sizeof(T) == 12) {
@@ -1975,6 +1980,9 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(face_rows(m) <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP - CLIP_FX - WAVE);
     const int tiles_x = ceil_div(S, TILE);
     SMIL_REQUIRE((double)N * tiles_x * tiles_x < 2147483647.0, "raster: N * tiles exceeds the work-item index range (2^31); launch in slices");
+    static_assert(REC_CAP + REC_PAD < (1 << 24), "at<12-byte>() multiplies 24-bit indices");
+    SMIL_REQUIRE(face_rows(m) + 64 < (1 << 24) && (double)list_cap_of(m, S) * sizeof(uint2) < 4294967296.0,
+                 "raster: per-workgroup / per-image tables exceed the 24-bit index / 32-bit byte-offset range of at()");
     char *ws = (char *)workspace;
     const int FT = face_rows(m);
     uint32_t *tbox = (uint32_t *)ws;

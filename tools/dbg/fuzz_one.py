@@ -35,6 +35,16 @@ gs = rng.standard_normal((N, S, S)).astype(np.float32)
 print(f"seed {seed} {key} N={N} S={S} K={K} dist={dist:.2f} maxcand={ncand.max()}  pixels with candidates {int((ncand > 0).sum())}, truncated {int((ncand > K).sum())}")
 
 
+fd = np.abs(got - ref1)
+bad = np.argwhere(fd > 1e-4)
+print(f"forward: mean|d| {fd.mean():.3e}  pixels with |d| > 1e-4: {len(bad)}")
+for n_, y_, x_ in bad[:40]:
+    print(f"   ({n_},{y_},{x_}) candidates {ncand[n_, y_, x_]:4d}  oracle {ref1[n_, y_, x_]:.7f}  kernel {got[n_, y_, x_]:.7f}")
+if CLIP:
+    st = engine.raster_stats(dm, N)
+    print("raster stats:", st)
+
+
 def both(gmask):
     with render_ref.select_mode(1):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gmask, K=K)[..., :2]

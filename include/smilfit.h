@@ -120,12 +120,14 @@ typedef struct {
     const float *up_Rs;       /* (B,J,3,3) or NULL: upstream gradient on the rotation matrices the forward returned
                               (SMAL.__call__ hands Rs to its caller, smal_torch.py:367-370); flows to d_theta / d_Rs_in */
     const float *up_v_shaped; /* (nS,V,3) or NULL: upstream gradient on the returned v_shaped; flows to d_beta and d_del_v */
-    float *beta_rows;         /* scratch, 2 * B * nB_used floats: required iff shared_beta and d_beta.  The kernels leave one partial
-                              sum per block there and the last block to finish adds them in a fixed order */
+    float *beta_rows;         /* scratch, 2 * B * nB_used + 16 floats: required iff shared_beta and d_beta.  The kernels leave one partial
+                              sum per block there and the last block to finish adds them in a fixed order; the word behind the rows
+                              counts the finished blocks of THIS call (zeroed by the call on its stream: calls with different
+                              scratch may run on different streams) */
 } SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
                               logscale_shared, btrans_shared) receive the sum over frames.  All of these sums are taken in a
                               fixed order: two calls on the same inputs return the same bits (the shared shape gradient - the
-                              quantity ranks all-reduce - included, since round 4; one stream per model at a time) */
+                              quantity ranks all-reduce - included, since round 4) */
 
 int smil_lbs_backward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *saved,
                       const SmilLbsGrads *g, void *stream);

@@ -70,7 +70,6 @@ struct SmilModel {
                                   // is wave w's k-th bone, -1 behind its last
     int bone_slots = 0;
     float *posedirs = nullptr;    // (9(J-1),3V) or null
-    unsigned int *sync_ctr = nullptr;  // block counter of the "last block finishes" reductions (lbs.hip BetaSum): zero between calls
     std::vector<void *> allocations;
 };
 

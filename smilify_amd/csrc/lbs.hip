@@ -536,7 +536,12 @@ __global__ void __launch_bounds__(NT, FWD_MIN_WAVES) k_skin_project_fwd(SkinProj
 static int fwd_fused_nnz_lds(const SmilModel *m) { return (!m->static_joints && m->jreg_nnz <= FWD_REG_LDS_MAX) ? m->jreg_nnz : 0; }
 // CUs and LDS of the current device, asked once per device (the grids of the per-frame persistent kernels; what a workgroup may
 // take of the CU's LDS).  Thread-safe: one mutex-guarded table.
+#define SMIL_MAX_DEVICES 16
 struct DeviceLimits { int cus; size_t lds_block, lds_cu; };
+static int current_device_slot() {  // index of the current device into per-device tables (0 when it cannot be told)
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SMIL_MAX_DEVICES) ? dev : 0;
+}
 static DeviceLimits device_limits() {
     static std::mutex mu;
     static DeviceLimits table[16];
@@ -744,7 +749,7 @@ struct BetaSum {
     float *rows;        // this kernel's rows [gridDim.x][n] (NULL: it contributes nothing)
     const float *all;   // finishing kernel: every row of the call, [n_all][n] ...
     int n_all;
-    unsigned int *ctr;  // ... and the block counter (zero between calls); NULL in a kernel that does not finish the sum
+    unsigned int *ctr;  // ... and the call's block counter (zeroed by the call before its first kernel); NULL in a kernel that does not finish the sum
     float *out;         // (n) the gradient
     int accumulate;     // add to what `out` holds instead of overwriting it
     int n;              // shape coefficients in use
@@ -781,7 +786,6 @@ __device__ __forceinline__ void beta_sum_finish(const BetaSum &q, float *red) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && gridDim.x > 1u) *q.ctr = 0u;  // ready for the next call (stream order)
 }
 
 struct ChainBwdArgs {
@@ -1515,6 +1519,11 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
     bsum.rows = nullptr; bsum.all = g->beta_rows; bsum.n_all = 0; bsum.ctr = nullptr; bsum.out = g->d_beta;
     bsum.accumulate = g->accumulate_shared_beta ? 1 : 0; bsum.n = nBu_all;
     int rows_used = 0;
+    // The "last block finishes" counter of the shared shape gradient is a word of THIS CALL's scratch, behind its rows, zeroed on the
+    // call's stream before its first kernel: calls on different streams cannot interleave on it and a call that dies half way
+    // leaves nothing behind (round 4 kept one counter per model, reset by the finishing block).
+    unsigned int *const beta_ctr = beta_shared ? reinterpret_cast<unsigned int *>(g->beta_rows + (size_t)2 * B * nBu_all) : nullptr;
+    if (beta_shared) SMIL_HIP(hipMemsetAsync(beta_ctr, 0, sizeof(unsigned int), stream));
     const float *d_joints_up = up ? up->d_joints : g->d_joints;
     if (up) {
         LbsBwdNdcArgs a;
@@ -1540,22 +1549,24 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int grid = std::min(B, std::max(1, cus) * per_cu);
         a.beta = bsum;
         if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; }
+        const int dev_slot = current_device_slot();
 #define NDC_LAUNCH(NBT) \
         do { \
             if (wide) { \
                 auto kern = k_lbs_bwd_ndc<NBT, false, NDC_BWD_THREADS_WIDE>; \
-                static std::atomic<int> lds_allowed{0};  /* (once per variant and size: not a stream operation, kept out of replays) */ \
-                if (lds_allowed.load() < (int)lds) { \
+                static std::atomic<int> lds_allowed[SMIL_MAX_DEVICES];  /* (once per variant, size AND device - the attribute is per device; \
+                                                                          not a stream operation, kept out of replays) */ \
+                if (lds_allowed[dev_slot].load() < (int)lds) { \
                     SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                    lds_allowed.store((int)lds); \
+                    lds_allowed[dev_slot].store((int)lds); \
                 } \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(NDC_BWD_THREADS_WIDE), lds, stream, a); \
             } else if (few) { \
                 auto kern = k_lbs_bwd_ndc<NBT, true, NDC_BWD_THREADS_WIDE>; \
-                static std::atomic<int> lds_allowed{0}; \
-                if (lds > 64 * 1024 && lds_allowed.load() < (int)lds) { \
+                static std::atomic<int> lds_allowed[SMIL_MAX_DEVICES]; \
+                if (lds > 64 * 1024 && lds_allowed[dev_slot].load() < (int)lds) { \
                     SMIL_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                    lds_allowed.store((int)lds); \
+                    lds_allowed[dev_slot].store((int)lds); \
                 } \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(NDC_BWD_THREADS_WIDE), lds, stream, a); \
             } else { \
@@ -1608,7 +1619,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int fpb = frames_per_block(B);
         const int chain_blocks = ceil_div(B, fpb);
         if (beta_shared && js) { a.beta.rows = g->beta_rows + (size_t)rows_used * nBu_all; rows_used += chain_blocks; }
-        if (beta_shared && up) { a.beta.n_all = rows_used; a.beta.ctr = m->sync_ctr; }  // (the fused route ends here: this kernel finishes the sum)
+        if (beta_shared && up) { a.beta.n_all = rows_used; a.beta.ctr = beta_ctr; }  // (the fused route ends here: this kernel finishes the sum)
         a.d_posefeat = d_posefeat;
         a.d_Rs_up = g->up_Rs;
         a.parents = m->parents; a.depth = m->depth;
@@ -1638,7 +1649,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int nBu = nBu_all;
         float *dbeta_frame = dbeta_frame_all;
         BetaSum bshape = bsum;
-        if (beta_shared) { bshape.rows = g->beta_rows; bshape.n_all = B; bshape.ctr = m->sync_ctr; }  // (one row per frame; this kernel finishes the sum)
+        if (beta_shared) { bshape.rows = g->beta_rows; bshape.n_all = B; bshape.ctr = beta_ctr; }  // (one row per frame; this kernel finishes the sum)
         const int shape_threads = few_frames ? 1024 : SHAPE_BWD_THREADS;
         const size_t lds = ((size_t)J * 18 + (shape_threads / WAVE) * SHAPE_TERMS) * sizeof(float);
         hipLaunchKernelGGL(k_shape_bwd, dim3(B), dim3(shape_threads), lds, stream, g->d_verts, g->d_joints,

@@ -184,7 +184,6 @@ extern "C" int smil_model_create(const SmilModelDesc *d, SmilModel **out) {
     m->bone_slots = bone_slots;
     UP(J_static, d->static_joints ? d->J_static : (const float *)nullptr, 3 * J);
     if (d->posedirs) { UP(posedirs, d->posedirs, (size_t)9 * (J - 1) * 3 * V); }
-    { const unsigned int zeros[16] = {0}; UP(sync_ctr, zeros, 16); }
 #undef UP
     *out = m;
     return SMIL_OK;

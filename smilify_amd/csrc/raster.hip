@@ -129,6 +129,18 @@ struct RasterCounters {
     unsigned int unclipped;   // ... except these: beyond the per-image clip tables, rendered whole or dropped
 };
 
+// The tile kernel's dealing policy, shared by the kernel and the host: with fewer tiles than workgroup slots every tile is dealt out
+// as 2, 4 or 8 runs of pixels (round 4, from a sweep over 1 ... 64 images x workgroups per CU x pieces, profiles/r4_small_launches.txt:
+// the launch is fastest with ~2.3 pieces per WORKING workgroup and about 1.2 pieces per resident slot in all), and only
+// max(slots / 8, pieces x 7 / 16) workgroups take part.
+__host__ __device__ __forceinline__ unsigned int deal_split_log(unsigned int n_items, unsigned int slots) {
+    return n_items * 8u <= slots * 5u / 8u ? 3u : (n_items * 4u <= slots * 5u / 4u ? 2u : (n_items * 2u <= slots * 5u / 4u ? 1u : 0u));
+}
+__host__ __device__ __forceinline__ unsigned int deal_working(unsigned int n_items, unsigned int split_log, unsigned int slots) {
+    const unsigned int w = (n_items << split_log) * 7u / 16u;
+    return w > slots / 8u ? w : slots / 8u;
+}
+
 struct Rec3 { uint32_t a, b, c; };  // one 12-byte record: loaded / stored as one dwordx3
 // Per list position of the current tile, left by pass 1 (which has them in registers) for pass 3: the face's projected vertices
 // and its vertex ids.  Pass 3 used to fetch them per group of 64 faces through the chain list -> face -> vertex: three dependent
@@ -205,6 +217,7 @@ struct RasterArgs {
     // records that survive the first selection digit: {key = depth bits - tile minimum, meta, log2 of the blend factor}
     Rec3 *crec;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
+    unsigned int slots;      // resident workgroup slots of the device (the dealing policy's yardstick; gridDim.x <= slots)
     HOOK_ARGS_FIELDS         // (instrumented builds: counter buffer, cut-off phase, forced split)
 };
 
@@ -1167,13 +1180,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
     // resident slot in all (8-pixel pieces - a whole list walk for one row of pixels - only while even they number under 0.6 per
     // slot); the workgroups beyond that leave at once - a one-image launch runs on 512 of them, not on 4 096 that queue for the same
     // ticket counter.
-    const unsigned int slots = gridDim.x;
-    const unsigned int split_log = HOOK_SPLIT_LOG(
-        n_items_all * 8u <= slots * 5u / 8u ? 3u : (n_items_all * 4u <= slots * 5u / 4u ? 2u : (n_items_all * 2u <= slots * 5u / 4u ? 1u : 0u)));
-    {
-        const unsigned int working = max(slots / 8u, (n_items_all << split_log) * 7u / 16u);
-        if (blockIdx.x >= working) return;  // (workgroup-uniform, before any barrier)
-    }
+    const unsigned int slots = a.slots;  // (the device's resident slots; the grid may be smaller: tile_grid)
+    const unsigned int split_log = HOOK_SPLIT_LOG(deal_split_log(n_items_all, slots));
+    if (blockIdx.x >= deal_working(n_items_all, split_log, slots)) return;  // (workgroup-uniform, before any barrier)
     // The heaviest class can be dealt out in 2^SPLIT0_LOG pieces of pixels (see SPLIT0_LOG; off since the lists are walked
     // near to far) - and is, like the others, when the launch has workgroups to spare.
     const unsigned int split0_log = SPLIT0_LOG > split_log ? SPLIT0_LOG : split_log;
@@ -1911,13 +1920,29 @@ static int device_cus() {
     return cus;
 }
 
-static int tile_grid(int N, int tiles_x) {
-    // (a handful of images: a tile is dealt out in up to 8 runs of pixels - see split_log in the tile kernel - so the launch can use
-    // 8 workgroups per tile; before round 4 a one-image launch got 1 024 workgroups for its ~2 400 possible pieces and split in two)
-    const long long max_items = (long long)N * tiles_x * tiles_x * 8;
+// resident workgroup slots of the device: what the tile kernel's dealing policy (pieces per tile) is tuned against
+static long long tile_slots() {
     long long resident = (long long)device_cus() * RESIDENT_PER_CU;
     HOOK_RESIDENT(resident)
-    return (int)(max_items < resident ? max_items : resident);
+    return resident;
+}
+static int tile_grid(int N, int tiles_x) {
+    // The grid - and with it the scratch arena, 1.6 MB per workgroup - is the largest number of workgroups the policy can put to
+    // work on at most N x tiles touched tiles (the policy is piecewise monotone in the number of touched tiles: its maximum lies at
+    // the upper end of one of its four ranges), so a small launch neither starts nor pays scratch for workgroups that would leave
+    // at once: one 256^2 image gets 1 792 workgroups, one 128^2 image 896, not 4 096.
+    const long long resident = tile_slots();
+    const unsigned long long n_max = (unsigned long long)N * tiles_x * tiles_x;
+    const unsigned int slots = (unsigned int)resident;
+    unsigned int best = slots / 8u;
+    const unsigned long long ends[4] = {slots * 5ull / 64ull, slots * 5ull / 16ull, slots * 5ull / 8ull, n_max};
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long n = ends[k] < n_max ? ends[k] : n_max;
+        if (n == 0ull || n > 0x7FFFFFFull) { if (n) best = slots; continue; }
+        const unsigned int w = deal_working((unsigned int)n, deal_split_log((unsigned int)n, slots), slots);
+        best = w > best ? w : best;
+    }
+    return (int)(best < slots ? best : slots);
 }
 
 // per resident workgroup: F x {face id, nearest depth} in id order (tiles of images that are not binned), F face ids in walking order,
@@ -2042,7 +2067,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.srec = (Rec3 *)ws; ws += stream;
         a.crec = (Rec3 *)ws;
     }
-    a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT;
+    a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT; a.slots = (unsigned int)tile_slots();
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);

@@ -267,7 +267,7 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
         g["d_trans"] = f(B, 3)
     scratch = dict(d_A=f(B, J, 12), d_Jrest=f(B, J, 3), d_Rs=f(B, J, 9))
     if g["d_beta"] is not None and fl["shared_beta"]:
-        scratch["beta_rows"] = f(2 * B * fl["nB_used"])  # per-block partial sums of the shared shape gradient (added in a fixed order)
+        scratch["beta_rows"] = f(2 * B * fl["nB_used"] + 16)  # per-block partial sums of the shared shape gradient (added in a fixed order) + the call's block counter
     i = _lib.LbsInputs()
     i.B, i.shared_beta, i.nB_used = B, int(fl["shared_beta"]), fl["nB_used"]
     i.logscale_shared, i.btrans_shared = int(fl["logscale_shared"]), int(fl["btrans_shared"])

@@ -566,6 +566,9 @@ class SMALFitter(nn.Module):
             self._adam_t.fill_(self._adam_step)
         self._adam_step += 1
         g["t_mirror"] = self._adam_step
+        # (the replay's rasteriser kernels run on THIS stream, not on the one the graph was captured on: order them behind the last
+        # user of the device's shared workspace, and make the next user wait for them)
+        self.device_model._claim_workspace(g["last_launch"])
         g["graph"].replay()
         return g["objs"]
 
@@ -617,7 +620,8 @@ class SMALFitter(nn.Module):
         # keyed on the state AFTER the dry run, which may have (re)allocated the rasteriser workspace
         self._graph = dict(key=self._graph_key(weights, w_temp, window), graph=graph, objs=objs, t_mirror=self._adam_step,
                            graph_adam=graph_adam, shared_block=shared_block, grads=grads,
-                           ws=self.device_model._ws)  # (the graph's kernels hold raw pointers into this workspace tensor)
+                           ws=self.device_model._ws,  # (the graph's kernels hold raw pointers into this workspace tensor)
+                           last_launch=self.device_model.__dict__.get("_last_launch", 0))
         return self._graph
 
     def fit_step_graph_ranks(self, weights, w_temp: float, window: Optional[int], rank: int, world: int, group, shared_grad_hook,
@@ -652,6 +656,7 @@ class SMALFitter(nn.Module):
             self._adam_t.fill_(self._adam_step)
         self._adam_step += 1
         g["t_mirror"] = self._adam_step
+        self.device_model._claim_workspace(g["last_launch"])  # (as in fit_step_graph: the replay is ordered on this stream)
         g["graph"].replay()
         handle = shared_grad_hook(g["shared_block"]) if shared_grad_hook is not None else None
         if handle is not None:

@@ -83,9 +83,10 @@ def _worker(rank, world, port, n_total, window, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_exchange_and_shared_allreduce_gloo(tmp_path, world):
-    n_total, window = 50, 10
+    """world = 8 is the node size the driver's scaling run uses: eight processes, the chain of seven halo pairs, one block sum."""
+    n_total, window = (50, 10) if world < 8 else (170, 10)  # (170 frames over 8 ranks: uneven, window-aligned shards)
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_total, window, str(tmp_path)), nprocs=world, join=True)
     g = torch.Generator().manual_seed(0)

@@ -140,3 +140,45 @@ def test_full_size_properties(cfg, tables):
     key, frames, views, S, radius = cfg
     _full_size_properties(tables(key), frames, views, S, radius)
     torch.cuda.empty_cache()
+
+
+def test_config5_at_its_full_per_gpu_size(tables):
+    """BASELINE.json configs[4] as ONE GPU holds it in the weak-scaling sweep: 8192 mouse frames x 18 views @512^2 = 147 456 images
+    per fit iteration, binary targets as bytes (38.7 GB), rendered on the device.  One whole ``fit_step`` (the rasteriser cuts the
+    batch into launches that keep its workspace under 24 GB) must give finite objectives within the memory budget, and the per-image
+    silhouette losses the sliced launches return for the first 128 frames must be the ones a 128-frame call returns for them: a
+    slice is an independent launch over a window of the same tables."""
+    from smilify_amd import engine as eng
+    from smilify_amd import synthetic
+
+    key, frames, views, S, radius = "mouse", 8192, 18, 512, 4.0
+    t = tables(key)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    f = synthetic.make_problem(t, frames, views, S, DEV, radius=radius)
+    f._refresh_targets()
+    assert f._sil_dev.dtype == torch.uint8 and f._sil_dev.shape[0] == frames * views
+    f.begin_stage(synthetic.STAGE1_LR)
+    objs = f.fit_step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL)
+    assert torch.isfinite(objs).all() and float(objs[5]) > 0.0, objs  # (index 5: the silhouette term)
+    assert all(torch.isfinite(p).all() for p in (f._pose, f.trans, f.betas, f.fov))
+    # the whole batch through the rasteriser entry point, sliced, against its first 128 frames alone
+    dm = f.device_model
+    lbs = eng.lbs_forward(dm, f.betas.detach(), f._pose, trans=f.trans.detach().contiguous(), shared_beta=True, trans_after_joints=True)
+    cam = f.renderer.cameras
+    cams = eng.CameraSet(cam.R.contiguous(), cam.T.contiguous(), f.fov.detach(), None, views, S)
+    ndc, _ = eng.project(cams, lbs["verts"], want_yx=False)
+    N = frames * views
+    scale = torch.full((N,), 1.0 / (S * S), device=DEV)
+    li, dn, _ = eng.silhouette_l1_fused(dm, ndc, S, f._sil_dev, f._sil_sum, scale)
+    assert dm._last_slice < N                       # (really cut into several launches)
+    n0 = 128 * views
+    li0, dn0, _ = eng.silhouette_l1_fused(dm, ndc[:n0], S, f._sil_dev[:n0], f._sil_sum[:n0], scale[:n0])
+    np.testing.assert_allclose(li[:n0].cpu().numpy(), li0.cpu().numpy(), rtol=1e-5)
+    assert torch.isfinite(li).all() and float(li.min()) >= 0.0
+    rel = (dn[:n0] - dn0).norm().item() / (dn0.norm().item() + 1e-30)
+    assert rel < 1e-5, rel
+    peak = torch.cuda.max_memory_allocated()
+    assert peak < 200e9, f"peak device memory {peak / 1e9:.1f} GB"
+    del f, lbs, ndc, li, dn, li0, dn0
+    torch.cuda.empty_cache()

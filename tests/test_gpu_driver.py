@@ -147,6 +147,19 @@ def test_bench_launches_its_own_ranks_and_shards_like_one_rank():
     assert abs(two["final_loss"] - one["final_loss"]) <= 2e-4 * abs(one["final_loss"]), (two["final_loss"], one["final_loss"])
 
 
+def test_four_ranks_on_one_gpu_follow_one_rank():
+    """The launcher path with more than two children: ``bench.py --gpus 4 --backend gloo --share-gpu`` (four ranks on this box's one
+    GPU; the box admits at most six GPU processes at once, the test runner being one of them, so the eight-rank case runs on the
+    CPU in tests/test_distributed_cpu.py) against one rank on the same 4 x 16 frames: three interior shard boundaries with
+    both halo directions, the in-place sum of the shared block over four contributions."""
+    common = ["--workload", "tiny", "--steps", "3", "--warmup", "0", "--cpu-frames", "0"]
+    four = _run_bench("--gpus", "4", "--backend", "gloo", "--share-gpu", *common)
+    one = _run_bench("--gpus", "1", "--frames", "64", *common)
+    assert four["n_gpus"] == 4 and four["rehearsal"] is True and four["config"]["frames_per_gpu"] == 16
+    assert abs(four["value"] - 4 * 16 / (four["ms_per_step"] * 1e-3)) <= 1e-6 * four["value"]  # whole-job frames per second
+    assert abs(four["final_loss"] - one["final_loss"]) <= 2e-4 * abs(one["final_loss"]), (four["final_loss"], one["final_loss"])
+
+
 _RCCL_PROBE = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())

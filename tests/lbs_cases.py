@@ -1,6 +1,6 @@
 """Random procedural models and random calls through the fused per-frame LBS kernels (smil_lbs_forward_project,
 smil_lbs_backward_ndc), checked DIRECTLY against the CPU oracle's autograd (oracle/lbs_ref.py + oracle/render_ref.py) and
-against the separate-kernel route.  Shared by tests/test_gpu_round4.py (a dozen seeded cases under ``pytest -m gpu``) and
+against the separate-kernel route.  Shared by tests/test_gpu_lbs_fused.py (a dozen seeded cases under ``pytest -m gpu``) and
 tools/dbg/fuzz_lbs.py (as many seeds as one likes).
 
 Models: procedural tubes with 3 ... 120 joints (``wide``: up to 250 joints and 20 views), up to 4 bones per vertex, vertices that

@@ -1,19 +1,35 @@
-"""GPU tests of round 3 (``pytest -m gpu``): the skinning backward that takes its upstream gradients on the image plane
-(``smil_lbs_backward_ndc``: projection backward + skinning backward + shape backward in one kernel per frame) against the
-two-call route it replaces, which the other test files pin to the oracle and to vectors of the real reference."""
+"""GPU tests of the fused per-frame LBS kernels (``pytest -m gpu``): ``smil_lbs_forward_project`` (skinning + joint regression +
+both projections) and ``smil_lbs_backward_ndc`` (projection backward + skinning backward + shape backward from the image plane)
+against the separate-kernel route and, directly, against the CPU oracle's autograd (oracle/lbs_ref.py, oracle/render_ref.py;
+reference smal_model/smal_torch.py:240-351, batch_lbs.py:155-195); the bit-reproducible shared shape gradient."""
+import os
+import pickle
+
 import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN, vertex_probe
+from oracle import render_ref
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
 
 def _close(a, b, rtol, what):
     a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
     scale = np.abs(b).max() + 1e-30
     err = np.abs(a - b).max() / scale
     assert err < rtol, (what, err)
+
+
+class _Fixed:
+    """A camera set that claims ``n`` images whatever the caller computes (to reach the library's own check)."""
+
+    def __init__(self, cams, n):
+        self._c, self._n, self.views = cams, n, cams.views
+
+    def struct(self, _n):
+        return self._c.struct(self._n)
 
 
 @pytest.mark.parametrize("key,views,shared_beta,trans_after", [
@@ -74,7 +90,6 @@ def test_backward_from_the_image_plane_equals_projection_backward_then_skinning_
         if with_yx:
             _close(a["d_joints"], b["d_joints"], 1e-6, "d_joints")
 
-
 def test_backward_from_the_image_plane_decodes_packed_rows_and_declines_what_it_cannot_hold(tables):
     """The vertex gradient arrives as the fused rasteriser leaves it (packed 64-bit fixed point with per-image factors); a
     mesh whose per-frame gradient does not fit the workgroup's LDS is declined, and the fit iteration then takes the two-call route."""
@@ -103,7 +118,6 @@ def test_backward_from_the_image_plane_decodes_packed_rows_and_declines_what_it_
     _close(fov_a, fov_b, 2e-5, "fov")
     mouse = eng.DeviceModel(tables("mouse"), DEV)
     assert eng.lbs_backward_ndc_supported(mouse, mouse.nB, 18)  # round 4: 11 263 vertices x 12 bytes in one workgroup per CU
-
 
 @pytest.mark.parametrize("key,views,trans_after", [("stick", 1, True), ("stick", 3, False), ("synthetic", 5, True), ("synthetic_static", 2, True),
                                                    ("synthetic_static", 2, False), ("mouse", 2, True)])
@@ -135,7 +149,6 @@ def test_forward_with_projection_equals_forward_then_projection(key, views, tran
         if want["yx"]:
             _close(got["yx"], yx_ref, 1e-6, "yx")
 
-
 @pytest.mark.parametrize("views", [1, 3])
 def test_fit_iteration_is_the_same_through_either_route(views, tables):
     from smilify_amd import engine as eng
@@ -159,51 +172,6 @@ def test_fit_iteration_is_the_same_through_either_route(views, tables):
             assert gb[k] is None
             continue
         _close(ga[k], gb[k], 3e-5, k)
-
-
-@pytest.mark.parametrize("key,matrices", [("stick", False), ("synthetic", True), ("synthetic_static", False)])
-def test_gradients_flow_through_all_four_tensors_smal_returns(key, matrices, tables):
-    """SMAL.__call__ hands (verts, joints, Rs, v_shaped) to its caller (reference smal_torch.py:367-370) and torch would
-    differentiate through every one of them: a loss on Rs and v_shaped alone, and one on all four, against the oracle's autograd."""
-    from conftest import oracle_model, vertex_probe
-    from oracle import lbs_ref
-    from smilify_amd.smal_torch import SMAL
-
-    t = tables(key)
-    smal = SMAL(DEV, tables=t)
-    m = oracle_model(t)
-    B, J, nB, V = 5, t.J, t.nB, t.V
-    g = torch.Generator().manual_seed(11)
-    host = dict(beta=0.4 * torch.randn(B, nB, generator=g), theta=0.3 * torch.randn(B, J, 3, generator=g),
-                trans=0.1 * torch.randn(B, 3, generator=g), del_v=0.01 * torch.randn(B, V, 3, generator=g))
-    if matrices:
-        host["theta"] = lbs_ref.rodrigues(host["theta"].reshape(-1, 3)).view(B, J, 3, 3)
-    pR, pS = vertex_probe((B, J, 3, 3), 2), vertex_probe((B, V, 3), 3)
-    pV, pJ = vertex_probe((B, V, 3), 0), vertex_probe((B, J, 3), 1)
-    for which in ("rs_vs", "all"):
-        ref_leaves = {k: v.clone().requires_grad_() for k, v in host.items()}
-        o = lbs_ref.smal_forward(m, ref_leaves["beta"], ref_leaves["theta"], trans=ref_leaves["trans"], del_v=ref_leaves["del_v"])
-        loss = (o["Rs"] * pR).sum() + (o["v_shaped"] * pS).sum()
-        if which == "all":
-            loss = loss + (o["verts"] * pV).sum() + (o["joints"] * pJ).sum()
-        loss.backward()
-        leaves = {k: v.clone().to(DEV).requires_grad_() for k, v in host.items()}
-        verts, joints, Rs, v_shaped = smal(leaves["beta"], leaves["theta"], trans=leaves["trans"], del_v=leaves["del_v"])
-        np.testing.assert_allclose(Rs.detach().cpu().numpy(), o["Rs"].detach().numpy(), atol=2e-6)
-        np.testing.assert_allclose(v_shaped.detach().cpu().numpy(), o["v_shaped"].detach().numpy(), atol=2e-6)
-        loss = (Rs * pR.to(DEV)).sum() + (v_shaped * pS.to(DEV)).sum()
-        if which == "all":
-            loss = loss + (verts * pV.to(DEV)).sum() + (joints * pJ.to(DEV)).sum()
-        loss.backward()
-        for k in host:
-            ref = ref_leaves[k].grad
-            got = leaves[k].grad
-            if which == "rs_vs" and k == "trans":
-                assert got is None or float(got.abs().max()) == 0.0  # neither tensor depends on the translation
-                continue
-            assert got is not None, (which, k)
-            _close(got, ref, 3e-4, (which, k))
-
 
 def test_fused_entries_refuse_what_they_cannot_do(tables):
     """Loud failures instead of wrong numbers: the image-plane backward on a mesh beyond its LDS, upstream gradients in both
@@ -236,12 +204,62 @@ def test_fused_entries_refuse_what_they_cannot_do(tables):
     with pytest.raises(SmilError, match="images for"):
         eng.lbs_backward(small, lbs_s, None, None, ndc_upstream=dict(cams=_Fixed(two_views, B), d_ndc=torch.zeros(B, small.V, 2, device=DEV)))
 
+@pytest.mark.parametrize("seed,wide", [(s, False) for s in (0, 1, 2, 3, 5, 8, 13, 21)] + [(s, True) for s in (100, 101, 102, 103)])
+def test_fused_lbs_kernels_against_the_oracle(seed, wide):
+    """smil_lbs_forward_project / smil_lbs_backward_ndc directly against the CPU oracle's autograd through LBS and projection
+    (oracle/lbs_ref.py, oracle/render_ref.py; reference smal_model/smal_torch.py:240-351, batch_lbs.py:155-195): seeded random
+    models with up to 120 (wide: 250) joints, up to 20 views, static and regressed joints, shared and per-frame betas.
+    Tolerances (tests/lbs_cases.py): forward 2e-5, parameter gradients 5e-4 of the largest component; fused against separate
+    kernels 1e-6 / 3e-5."""
+    import lbs_cases
 
-class _Fixed:
-    """A camera set that claims ``n`` images whatever the caller computes (to reach the library's own check)."""
+    checks, info = lbs_cases.run_case(seed, wide)
+    assert any(w.startswith("oracle d_") for _, w, _ in checks), info
+    fails = [(w, e) for f, w, e in checks if f is not None]
+    assert not fails, (info, fails)
 
-    def __init__(self, cams, n):
-        self._c, self._n, self.views = cams, n, cams.views
+@pytest.mark.parametrize("seed,key", [(200, None), (201, None), (202, None), (203, "mouse"), (204, "mouse")])
+def test_fused_lbs_kernels_on_meshes_beyond_half_a_cu(seed, key, tables):
+    """Meshes whose per-frame vertex state (24 bytes per vertex) does not fit twice into a CU's LDS take the fused kernels' second
+    form since round 4: one workgroup of 1024 threads per CU, only the vertex gradient in LDS (12 bytes per vertex), the rest
+    vertices gathered from memory one bone-list segment ahead; the forward kernel keeps no vertex copy at all for models with
+    static joints.  Random tubes with 3 600 - 5 000 vertices and the mouse (V = 11 263, BASELINE configs 3 and 5) against the
+    CPU oracle's autograd and against the separate-kernel route (reference smal_model/smal_torch.py:320-351)."""
+    import lbs_cases
+    from smilify_amd import engine as eng
 
-    def struct(self, _n):
-        return self._c.struct(self._n)
+    t = tables(key) if key else None
+    checks, info = lbs_cases.run_case(seed, big=key is None, table=t)
+    assert info["V"] > 3500 and info["fused_bwd"] == 1, info
+    assert any(w.startswith("oracle d_") for _, w, _ in checks) and any(w.startswith("bwd d_") for _, w, _ in checks), info
+    fails = [(w, e) for f, w, e in checks if f is not None]
+    assert not fails, (info, fails)
+    if key:  # the form is chosen by the model alone: every BASELINE camera rig of the mouse is covered
+        dm = eng.DeviceModel(t, DEV)
+        assert all(eng.lbs_backward_ndc_supported(dm, dm.nB, v) for v in (1, 2, 18, 32))
+
+@pytest.mark.parametrize("key,frames,views", [("stick", 96, 2), ("mouse", 24, 3)])
+def test_the_shared_shape_gradient_is_bit_reproducible(key, frames, views, tables):
+    """Two evaluations of the same fit step return the same bits in d_betas - the one quantity ranks all-reduce (reference
+    fitter.py:236-335: ``betas`` is shared by every frame, so its gradient is a sum over frames).  Round 3 summed the frames with
+    float atomics, whose result depends on the order the blocks arrive in; since round 4 every block leaves a partial row and the
+    last block adds the rows in a fixed order (lbs.hip BetaSum).  STICK goes through the fused per-frame kernel (two workgroups per
+    CU) + chain kernel, the mouse through its one-workgroup-per-CU form; several runs, because a race would only show now and then.  (At least 64 images per
+    launch, so that the rasteriser's vertex gradients upstream are the integer-exact packed ones.)"""
+    from smilify_amd import synthetic
+
+    f = synthetic.make_problem(tables(key), frames, views, 64, DEV, radius=2.7 if key == "stick" else 4.0)
+    ref_objs, ref = f._loss_and_grads(None, synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=10)
+    ref = {k: v.clone() for k, v in ref.items() if v is not None}
+    ref_objs = ref_objs.clone()
+    assert float(ref["betas"].abs().max()) > 0
+    for _ in range(5):
+        objs, g = f._loss_and_grads(None, synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, window=10)
+        assert torch.equal(g["betas"], ref["betas"]), (g["betas"], ref["betas"])
+        # the shared scale / translation tables are sums in a fixed order as well (smil_reduce_rows)
+        for k in ("log_beta_scales", "betas_trans"):
+            if k in ref and g.get(k) is not None:
+                assert torch.equal(g[k], ref[k]), k
+        # (the fov gradient and the loss terms still end in a few float atomics per image / per block: equal to rounding)
+        np.testing.assert_allclose(g["fov"].cpu().numpy(), ref["fov"].cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(objs.cpu().numpy(), ref_objs.cpu().numpy(), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,148 @@
+"""GPU tests of the ``SMAL.__call__`` drop-in surface (``pytest -m gpu``): ``del_v`` / rotation-matrix ``theta`` / one-row
+(broadcast) inputs against vectors of the real reference, shape checks, the 35-joint hard-coded body joints, gradients through
+all four tensors the call returns (reference smal_model/smal_torch.py:198-370)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, vertex_probe
+from oracle import render_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+@pytest.mark.parametrize("key", ["stick", "mouse"])
+def test_smal_del_v_rotation_matrices_and_broadcast_inputs_match_reference(key, golden, tables):
+    """reference smal_torch.py:244-248 (del_v), :288-289 (theta given as (B,J,3,3) matrices), and the inputs torch
+    broadcasts over the batch there (trans (1,3), betas_logscale (1,J,3)): outputs and every gradient of the REAL
+    reference's autograd."""
+    from smilify_amd.smal_torch import SMAL
+
+    g = golden(f"lbs_extra_{key}")
+    smal = SMAL(DEV, tables=tables(key))
+    leaf = {n: torch.from_numpy(g[n]).to(DEV).requires_grad_() for n in ("beta", "Rs", "trans", "del_v", "ls", "bt")}
+    assert leaf["trans"].shape[0] == 1 and leaf["ls"].shape[0] == 1 and leaf["Rs"].dim() == 4
+    verts, joints, Rs_o, v_shaped = smal(leaf["beta"], leaf["Rs"], trans=leaf["trans"], del_v=leaf["del_v"], betas_logscale=leaf["ls"],
+                                         betas_trans=leaf["bt"])
+    np.testing.assert_allclose(verts.detach().cpu().numpy(), g["verts"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(joints.detach().cpu().numpy(), g["joints"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(v_shaped.detach().cpu().numpy(), g["v_shaped"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(Rs_o.detach().cpu().numpy(), g["Rs"], rtol=0, atol=1e-7)
+    loss = (verts * vertex_probe(verts.shape, 2).to(DEV)).sum() + (joints * vertex_probe(joints.shape, 3).to(DEV)).sum()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-4 * abs(float(g["loss"])) + 1e-4
+    loss.backward()
+    for n, t in leaf.items():
+        want = g[f"grad_{n}"]
+        assert t.grad is not None and tuple(t.grad.shape) == want.shape, n
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(t.grad.cpu().numpy() / scale, want / scale, rtol=0, atol=3e-4, err_msg=f"{key}/{n}")
+    # one (1,V,3) offset shared by the batch, axis-angle pose
+    dv1 = torch.from_numpy(g["b_del_v"]).to(DEV).requires_grad_()
+    v1, j1, _, _ = smal(leaf["beta"].detach(), torch.from_numpy(g["b_theta"]).to(DEV), del_v=dv1)
+    np.testing.assert_allclose(v1.detach().cpu().numpy(), g["b_verts"], rtol=1e-4, atol=5e-6)
+    ((v1 * vertex_probe(v1.shape, 4).to(DEV)).sum() + (j1 * vertex_probe(j1.shape, 5).to(DEV)).sum()).backward()
+    want = g["b_grad_del_v"]
+    np.testing.assert_allclose(dv1.grad.cpu().numpy() / np.abs(want).max(), want / np.abs(want).max(), rtol=0, atol=3e-4)
+
+def test_smal_rejects_shapes_that_would_read_past_a_buffer(tables):
+    from smilify_amd.smal_torch import SMAL
+
+    t = tables("synthetic")
+    smal = SMAL(DEV, tables=t)
+    B = 3
+    beta, theta = torch.zeros(B, t.nB, device=DEV), torch.zeros(B, t.J, 3, device=DEV)
+    for kw in (dict(trans=torch.zeros(2, 3, device=DEV)), dict(del_v=torch.zeros(2, t.V, 3, device=DEV)),
+               dict(del_v=torch.zeros(B, t.V - 1, 3, device=DEV)), dict(betas_logscale=torch.zeros(2, t.J, 3, device=DEV)),
+               dict(betas_trans=torch.zeros(B, t.J - 1, 3, device=DEV)), dict(v_template=torch.zeros(t.V + 1, 3, device=DEV))):
+        with pytest.raises(ValueError):
+            smal(beta, theta, **kw)
+    with pytest.raises(ValueError):
+        smal(torch.zeros(2, t.nB, device=DEV), theta)
+    # a custom template receives the batch-summed vertex gradient
+    vt = torch.from_numpy(t.v_template).to(DEV).requires_grad_()
+    verts, _, _, _ = smal(beta, theta, v_template=vt)
+    verts.sum().backward()
+    assert vt.grad.shape == (t.V, 3) and torch.allclose(vt.grad, torch.full_like(vt.grad, float(B)), atol=1e-4)
+
+def test_hardcoded_body_joints_of_35_joint_models():
+    """reference smal_torch.py:353-365: a 35-joint model with ignore_hardcoded_body off returns six mesh vertices behind its
+    joints (gradients flow to them like to any vertex)."""
+    from smilify_amd import config as cfgmod
+    from smilify_amd import model_io
+    from smilify_amd.smal_torch import SMAL, _HARDCODED_BODY_VERTS
+
+    t = model_io.synthetic_model(V_side=100, J=35, nB=2, seed=2)   # 3602 vertices > 3055
+    assert t.J == 35 and t.V > max(_HARDCODED_BODY_VERTS)
+    cfg = cfgmod.FitterConfig.from_tables(t, ignore_hardcoded_body=False)
+    smal = SMAL(DEV, tables=t, config=cfg)
+    beta = torch.zeros(2, t.nB, device=DEV)
+    theta = (0.1 * torch.randn(2, t.J, 3, generator=torch.Generator().manual_seed(0))).to(DEV).requires_grad_()
+    verts, joints, _, _ = smal(beta, theta)
+    assert joints.shape == (2, 41, 3)
+    assert torch.equal(joints[:, 35:], verts[:, list(_HARDCODED_BODY_VERTS)])
+    assert smal(beta, theta, get_skin=False).shape == (2, 41, 3)
+    joints[:, 35:].sum().backward()
+    assert theta.grad is not None and float(theta.grad.abs().max()) > 0
+    plain = SMAL(DEV, tables=t, config=cfgmod.FitterConfig.from_tables(t))
+    assert plain(beta, theta.detach())[1].shape == (2, 35, 3)
+
+def _close(a, b, rtol, what):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b).max() / scale
+    assert err < rtol, (what, err)
+
+class _Fixed:
+    """A camera set that claims ``n`` images whatever the caller computes (to reach the library's own check)."""
+
+    def __init__(self, cams, n):
+        self._c, self._n, self.views = cams, n, cams.views
+
+    def struct(self, _n):
+        return self._c.struct(self._n)
+
+@pytest.mark.parametrize("key,matrices", [("stick", False), ("synthetic", True), ("synthetic_static", False)])
+def test_gradients_flow_through_all_four_tensors_smal_returns(key, matrices, tables):
+    """SMAL.__call__ hands (verts, joints, Rs, v_shaped) to its caller (reference smal_torch.py:367-370) and torch would
+    differentiate through every one of them: a loss on Rs and v_shaped alone, and one on all four, against the oracle's autograd."""
+    from conftest import oracle_model, vertex_probe
+    from oracle import lbs_ref
+    from smilify_amd.smal_torch import SMAL
+
+    t = tables(key)
+    smal = SMAL(DEV, tables=t)
+    m = oracle_model(t)
+    B, J, nB, V = 5, t.J, t.nB, t.V
+    g = torch.Generator().manual_seed(11)
+    host = dict(beta=0.4 * torch.randn(B, nB, generator=g), theta=0.3 * torch.randn(B, J, 3, generator=g),
+                trans=0.1 * torch.randn(B, 3, generator=g), del_v=0.01 * torch.randn(B, V, 3, generator=g))
+    if matrices:
+        host["theta"] = lbs_ref.rodrigues(host["theta"].reshape(-1, 3)).view(B, J, 3, 3)
+    pR, pS = vertex_probe((B, J, 3, 3), 2), vertex_probe((B, V, 3), 3)
+    pV, pJ = vertex_probe((B, V, 3), 0), vertex_probe((B, J, 3), 1)
+    for which in ("rs_vs", "all"):
+        ref_leaves = {k: v.clone().requires_grad_() for k, v in host.items()}
+        o = lbs_ref.smal_forward(m, ref_leaves["beta"], ref_leaves["theta"], trans=ref_leaves["trans"], del_v=ref_leaves["del_v"])
+        loss = (o["Rs"] * pR).sum() + (o["v_shaped"] * pS).sum()
+        if which == "all":
+            loss = loss + (o["verts"] * pV).sum() + (o["joints"] * pJ).sum()
+        loss.backward()
+        leaves = {k: v.clone().to(DEV).requires_grad_() for k, v in host.items()}
+        verts, joints, Rs, v_shaped = smal(leaves["beta"], leaves["theta"], trans=leaves["trans"], del_v=leaves["del_v"])
+        np.testing.assert_allclose(Rs.detach().cpu().numpy(), o["Rs"].detach().numpy(), atol=2e-6)
+        np.testing.assert_allclose(v_shaped.detach().cpu().numpy(), o["v_shaped"].detach().numpy(), atol=2e-6)
+        loss = (Rs * pR.to(DEV)).sum() + (v_shaped * pS.to(DEV)).sum()
+        if which == "all":
+            loss = loss + (verts * pV.to(DEV)).sum() + (joints * pJ.to(DEV)).sum()
+        loss.backward()
+        for k in host:
+            ref = ref_leaves[k].grad
+            got = leaves[k].grad
+            if which == "rs_vs" and k == "trans":
+                assert got is None or float(got.abs().max()) == 0.0  # neither tensor depends on the translation
+                continue
+            assert got is not None, (which, k)
+            _close(got, ref, 3e-4, (which, k))

@@ -1,6 +1,6 @@
 """Random models and calls through the fused LBS kernels (smil_lbs_forward_project, smil_lbs_backward_ndc) against the separate
 kernels AND against the CPU oracle's autograd: tools/dbg/fuzz_lbs.py <seed0> <seed1> [wide].  The cases themselves live in
-tests/lbs_cases.py (a dozen of them run under pytest -m gpu, tests/test_gpu_round4.py)."""
+tests/lbs_cases.py (a dozen of them run under pytest -m gpu, tests/test_gpu_lbs_fused.py)."""
 import os
 import sys
 

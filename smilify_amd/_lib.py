@@ -70,7 +70,8 @@ class Cameras(Structure):
 
 
 class RasterSettings(Structure):
-    _fields_ = [("blur_radius", c_float), ("sigma", c_float), ("faces_per_pixel", c_int32), ("z_clip", c_float)]
+    _fields_ = [("blur_radius", c_float), ("sigma", c_float), ("faces_per_pixel", c_int32), ("z_clip", c_float),
+                ("tie_rule", c_int32)]
 
 
 class FitConfig(Structure):

@@ -218,6 +218,9 @@ struct RasterArgs {
     Rec3 *crec;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned int slots;      // resident workgroup slots of the device (the dealing policy's yardstick; gridDim.x <= slots)
+    int tie_rule;            // SmilRasterSettings.tie_rule (0: K smallest by (depth, face id); 1: the reference's queue, k_raster_tie_replay)
+    unsigned long long *tie_mask;  // tie_rule 1: per work item (same index as `items`) the pixels of the tile whose K-th depth is a
+                             // tie group that K cuts through: left out by the tile kernel, rendered by k_raster_tie_replay
     HOOK_ARGS_FIELDS         // (instrumented builds: counter buffer, cut-off phase, forced split)
 };
 
@@ -1278,6 +1281,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
         TSUB(3)
         HOOK_STOP_AFTER(0, continue)
 
+        unsigned long long tie_acc = 0ull;  // (tie_rule 1) pixels of this unit left to k_raster_tie_replay
         // Sub-tiles: runs of `span` pixels (lane order).  Start from an estimate (a quarter of the pairs pixel x face
         // exist) and halve whenever pass 1 finds that the records do not fit; span * list_total <= REC_CAP always fits.
         int span = p_end - p_begin;
@@ -1474,6 +1478,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             uint32_t pre = 0u;
             int need = 0, n_eq = 0, nbits = nbits0 - b1;
             bool trunc = false;
+            bool defer = false;  // (tie_rule 1) this pixel's tie group at the K-th depth is cut by K: k_raster_tie_replay renders it
             if (may_truncate && vbase > 0) {
                 need = K;
                 const int tot = pick_digit8(lds.hist, lane, b1, pre, need, n_eq);
@@ -1597,7 +1602,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 }
                 if (trunc) zt_bits = pre + kmin;
                 // `need` of the n_eq faces at the threshold are kept: the ones with the smallest face ids
-                const bool split = trunc && need < n_eq;
+                const bool split = trunc && need < n_eq && !a.tie_rule;
+                defer = trunc && need < n_eq && a.tie_rule;
                 uint32_t rf[SELR];  // face ids of the records at the threshold of a split pixel (fetched only in tiles that have one)
 #pragma unroll
                 for (int r_ = 0; r_ < SELR; ++r_) rf[r_] = INV;
@@ -1653,7 +1659,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 }
                 if (trunc) zt_bits = pre + kmin;
                 // `need` of the n_eq faces at the threshold are kept: the first ones in list order
-                const bool split = trunc && need < n_eq;
+                const bool split = trunc && need < n_eq && !a.tie_rule;
+                defer = trunc && need < n_eq && a.tie_rule;
                 if (__ballot(split) != 0ull) {
                     // select on the list position among the records whose depth equals the pixel's threshold
                     lds.pgrad[lane] = make_float4(0.f, __uint_as_float(split ? pre : 0xFFFFFFFFu), 0.f, 0.f);
@@ -1720,7 +1727,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
 
             // ---------------- epilogue: silhouette value, loss, upstream gradient --------------------
             const float silv = 1.0f - alpha;
-            const bool own = in_img && mine;
+            const bool own = in_img && mine && !defer;
+            tie_acc |= __ballot(in_img && mine && defer);
             float g = 0.f;
             if (MODE == MODE_FWD) {
                 if (own) a.sil[pix] = silv;
@@ -1897,10 +1905,223 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             TSUB(7)
             p_lo += span;
         }
+        if (tie_acc != 0ull && lane == 0) atomicOr(&a.tie_mask[(size_t)part * 2u * a.item_cap + item_at], tie_acc);  // (pieces of one tile add their bits)
         TUNIT_END
     }
     }  // next partition
     TIMERS_FLUSH
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference tie rule (SmilRasterSettings.tie_rule = SMIL_TIE_REFERENCE_QUEUE)
+// ---------------------------------------------------------------------------------------------
+// pytorch3d's naive rasteriser keeps a pixel's K nearest fragments in an UNSORTED array: faces are visited in index order, the
+// first K candidates fill the array, and from then on a candidate nearer than the array's farthest entry replaces that entry,
+// whose successor is found by a scan for the first slot holding the largest depth (strict comparisons throughout;
+// RasterizeMeshesNaiveCudaKernel, selected by the reference with faces_per_pixel = 100 and bin_size = 0,
+// smal_fitter/p3d_renderer.py:42-47).  The K nearest by DEPTH survive whatever the order; which members of a group of EQUAL depths
+// at the K-th place survive depends on the slots the whole history put them in.  The tile kernel's rule - the smallest face ids -
+// is order independent but not that one.  With tie_rule 1 the tile kernel leaves every pixel whose tie group is cut by K to this
+// kernel (a bit per pixel and work item, `tie_mask`), which REPLAYS the reference's loop for that pixel: one wave per pixel, the
+// queue in registers (slot s = lane s % 64, register s / 64; K <= 128), every face whose tile box contains the pixel's tile
+// evaluated in index order (64 at a time, through the 64-face group boxes - the same pair arithmetic as the tile kernel, from
+// registers), the candidates fed to the queue one by one.  Then the pixel's blend, loss term and gradient from the queue's final
+// content, exactly as the tile kernel computes them from its records.  ~2 % of the truncated pixels take this path.
+__device__ __forceinline__ FaceRows face_rows_from_tri(const Tri9 &tv, float cx, float cy) {
+    const float x0 = tv.x0, y0 = tv.y0, z0 = tv.z0, x1 = tv.x1, y1 = tv.y1, z1 = tv.z1, x2 = tv.x2, y2 = tv.y2, z2 = tv.z2;
+    FaceRows q;
+    // (the expressions of stage_faces, both halves)
+    const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
+    const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
+    q.r0 = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);
+    q.r1 = make_float4(edge_fn(cx, cy, x1, y1, x2, y2) * s0, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);
+    q.r2 = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
+    const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
+    const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
+    const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
+    const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
+    const float rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
+    q.r3 = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
+    q.r4 = make_float4(e01x, e02x, e01y, e02y);
+    q.r5 = make_float4(rl01, rl02, e12x, e12y);
+    q.r6 = make_float4(rl12, 0.f, 0.f, 0.f);
+    return q;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
+    const int lane = threadIdx.x;
+    const int K = a.K;  // <= SMIL_MAX_FACES_PER_PIXEL = 128: two queue slots per lane
+    const int n_tiles = a.tiles_x * a.tiles_x;
+    const int n_groups = a.FT / WAVE;
+    unsigned int total = 0;
+    for (int q = 0; q < N_PARTS; ++q)
+        for (int c = 0; c < N_CLASSES; ++c) total += a.ctr->n_class[q][c];
+    for (unsigned int idx = blockIdx.x; idx < total; idx += gridDim.x) {  // every work item of the launch, partition by partition
+        unsigned int part = 0, item = idx;
+        for (;; ++part) {
+            unsigned int np = 0;
+            for (int c = 0; c < N_CLASSES; ++c) np += a.ctr->n_class[part][c];
+            if (item < np) break;
+            item -= np;
+        }
+        const unsigned int nc0 = a.ctr->n_class[part][0], nc1 = a.ctr->n_class[part][1], nc2 = a.ctr->n_class[part][2];
+        const uint32_t item_at = item < nc0 ? item
+                               : item < nc0 + nc1 ? a.item_cap - 1u - (item - nc0)
+                               : item < nc0 + nc1 + nc2 ? a.item_cap + (item - nc0 - nc1)
+                               : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
+        const size_t slot_i = (size_t)part * 2u * a.item_cap + item_at;
+        unsigned long long mask = a.tie_mask[slot_i];
+        if (mask == 0ull) continue;  // (wave-uniform)
+        const uint32_t code = a.items[slot_i].x;
+        const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
+        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
+        const float *vn = a.verts_ndc + (size_t)n * a.V * 3;
+        const float *const xv_n = a.clip.xv + (size_t)n * CLIP_VX * 3;
+        const int *const xf_n = a.clip.xf + (size_t)n * CLIP_FX * 3;
+        const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.FT;
+        const uint32_t *__restrict__ gbox_n = a.gbox + (size_t)n * n_groups;
+        while (mask) {
+            const int p = (int)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int xo = tx * TILE + (p & 7), yo = ty * TILE + (p >> 3);
+            const float dxp = pix_to_ndc(a.S - 1 - xo, a.S) - cx, dyp = pix_to_ndc(a.S - 1 - yo, a.S) - cy;
+            // ---- the queue: depth bits, {face | inside << 22 | closest edge << 23}, signed squared distance ----
+            uint32_t qz0 = 0u, qz1 = 0u, qm0 = 0u, qm1 = 0u;
+            float qs0 = 0.f, qs1 = 0.f;
+            int qsize = 0, qmax_idx = 0;
+            uint32_t qmax_z = 0u;  // (depths are positive: their bit patterns order like the values, and 0 is below all of them)
+            for (int g0 = 0; g0 < n_groups; g0 += WAVE) {
+                const int g = g0 + lane;
+                unsigned long long gm = __ballot(g < n_groups && box_has(gbox_n[min(g, n_groups - 1)], tx, ty));
+                while (gm) {  // the groups of 64 consecutive faces that reach the tile, in ascending order
+                    const int gi = g0 + (int)__builtin_ctzll(gm);
+                    gm &= gm - 1ull;
+                    const int f = gi * WAVE + lane;  // (< FT: gi < n_groups)
+                    bool cand = false;
+                    uint32_t zb = 0u, fl = 0u;
+                    float sd = 0.f;
+                    if (box_has(tbox_n[f], tx, ty)) {
+                        const int i0 = face_vertex(a.faces, xf_n, a.F, f, 0), i1 = face_vertex(a.faces, xf_n, a.F, f, 1), i2 = face_vertex(a.faces, xf_n, a.F, f, 2);
+                        const FaceRows fr = face_rows_from_tri(load_tri(a, vn, xv_n, i0, i1, i2), cx, cy);
+                        PairEval2 e;
+                        eval_pair2(fr, dxp, dxp, dyp, a.blur, e);
+                        cand = e.cand0;
+                        const f32x2 z2 = pair_depth2(fr, e);
+                        zb = __float_as_uint(vmax_raw(z2.x, fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w)));
+                        sd = e.sd.x;
+                        fl = (e.inside0 ? 1u << 22 : 0u) | e.ebits0;
+                    }
+                    unsigned long long cm = __ballot(cand);
+                    while (cm) {  // its candidates, in face order, one by one through the reference's queue
+                        const int l = (int)__builtin_ctzll(cm);
+                        cm &= cm - 1ull;
+                        const uint32_t z = (uint32_t)__builtin_amdgcn_readlane((int)zb, l);
+                        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)fl, l) | (uint32_t)(gi * WAVE + l);
+                        const float s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sd), l));
+                        int put = -1;
+                        if (qsize < K) {
+                            put = qsize;
+                            if (z > qmax_z) { qmax_z = z; qmax_idx = qsize; }
+                            ++qsize;
+                        } else if (z < qmax_z) {
+                            put = qmax_idx;
+                        }
+                        if (put >= 0) {  // (wave-uniform)
+                            if (lane == (put & (WAVE - 1))) {
+                                if (put < WAVE) { qz0 = z; qm0 = m; qs0 = s; } else { qz1 = z; qm1 = m; qs1 = s; }
+                            }
+                            if (qsize == K && put == qmax_idx && z < qmax_z) {
+                                // the farthest entry was replaced: the new farthest is the first slot holding the largest depth,
+                                // the replaced slot itself when nothing is strictly farther than the newcomer
+                                const uint32_t v0 = lane < min(K, WAVE) ? qz0 : 0u, v1 = lane + WAVE < K ? qz1 : 0u;
+                                const uint32_t mx = wave_max_u32(max(v0, v1));
+                                qmax_z = z;
+                                if (mx > z) {
+                                    qmax_z = mx;
+                                    const unsigned long long b0 = __ballot(v0 == mx);
+                                    qmax_idx = b0 ? (int)__builtin_ctzll(b0) : WAVE + (int)__builtin_ctzll(__ballot(v1 == mx));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- blend, loss term, upstream gradient: as the tile kernel's epilogue, for this one pixel ----
+            const bool ok0 = lane < qsize, ok1 = lane + WAVE < qsize;
+            const float lf0 = ok0 ? __log2f(1.0f - face_prob(qs0, a.inv_sigma_log2e)) : 0.f;
+            const float lf1 = ok1 ? __log2f(1.0f - face_prob(qs1, a.inv_sigma_log2e)) : 0.f;
+            const double plog_px = wave_sum_f64((double)lf0 + (double)lf1);
+            const float alpha = exp2f((float)plog_px);
+            const float silv = 1.0f - alpha;
+            const size_t pix = ((size_t)n * a.S + yo) * a.S + xo;
+            float g = 0.f;
+            if (MODE == MODE_FWD) {
+                if (lane == 0) a.sil[pix] = silv;
+            } else if (MODE == MODE_BWD) {
+                g = a.grad_sil[pix];
+            } else {
+                const float tg = a.target_u8 ? (float)a.target_u8[pix] : a.target[pix];
+                const float diff = silv - tg;
+                const float lsum = fabsf(diff) - fabsf(tg);  // loss_img starts at sum |0 - target|
+                g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+                if (lane == 0) {
+                    if (a.sil) a.sil[pix] = silv;
+                    if (lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
+                }
+            }
+            if (MODE == MODE_FWD || !((g != 0.f) && (alpha > ALPHA_GRAD_EPS) && (plog_px != 0.0))) continue;  // (wave-uniform)
+            // ---- gradient of every kept entry, straight to the vertices (no accumulators: at most K entries) ----
+            const float coef = -g * alpha * a.inv_sigma;
+            float *dn = a.d_ndc + (size_t)n * a.V * 2;
+            float *const xg_n = a.clip.xg + (size_t)n * CLIP_VX * 2;
+            const bool img_fixed = MODE == MODE_FUSED && a.packed && a.clip.xcount[n] == 0u;
+            const float fx_scale = img_fixed ? image_fx_scale(a.img_bound[n], a.pix_scale[n], a.inv_sigma) : 1.0f;
+            const float px = dxp + cx, py = dyp + cy;
+            auto entry_grad = [&](bool ok, uint32_t m, float sdv) {
+                if (!ok) return;
+                const int f = (int)(m & 0x3FFFFFu);
+                const uint32_t edge = (m >> 23) & 3u;
+                const bool inside = ((m >> 22) & 1u) != 0u;
+                const int ia = face_vertex(a.faces, xf_n, a.F, f, edge == 2u ? 1 : 0), ib = face_vertex(a.faces, xf_n, a.F, f, edge == 0u ? 1 : 2);
+                const float *pa_ = vertex_ptr(vn, xv_n, a.V, ia), *pb_ = vertex_ptr(vn, xv_n, a.V, ib);
+                const float pax = pa_[0], pay = pa_[1], pbx = pb_[0], pby = pb_[1];
+                float gd = coef * fx_scale * face_prob(sdv, a.inv_sigma_log2e);
+                gd = inside ? -gd : gd;
+                if (gd == 0.f) return;
+                const float exx = pbx - pax, eyy = pby - pay;
+                const float l2 = exx * exx + eyy * eyy;
+                const float t = __builtin_amdgcn_fmed3f((exx * (px - pax) + eyy * (py - pay)) * (l2 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l2)), 0.f, 1.f);
+                const float rx = fmaf(t, exx, pax - px), ry = fmaf(t, eyy, pay - py);
+                const float ex = 2.0f * rx * gd, ey = 2.0f * ry * gd;
+                const float bx = t * ex, by = t * ey;
+                if (img_fixed) {  // the image's packed fixed-point rows: one 64-bit integer add per end point
+                    auto pack = [](float x, float y) {
+                        const int qx = cvt_round(x), qy = cvt_round(y);
+                        return ((unsigned long long)(uint32_t)(qx + (qy >> 31)) << 32) | (unsigned long long)(uint32_t)qy;
+                    };
+                    const unsigned long long ga = pack(ex - bx, ey - by), gb = pack(bx, by);
+                    if (ga) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + ia, ga);
+                    if (gb) atomicAdd(reinterpret_cast<unsigned long long *>(dn) + ib, gb);
+                } else {
+                    float *const ra = ia < a.V ? dn + 2 * ia : xg_n + 2 * (ia - a.V), *const rb = ib < a.V ? dn + 2 * ib : xg_n + 2 * (ib - a.V);
+                    atomicAdd(ra, ex - bx); atomicAdd(ra + 1, ey - by);
+                    atomicAdd(rb, bx); atomicAdd(rb + 1, by);
+                }
+            };
+            entry_grad(ok0, qm0, qs0);
+            entry_grad(ok1, qm1, qs1);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1973,6 +2194,7 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
     // tile boxes (N,FT), counters, work lists (2, N, tiles), per-face depth ranges (N,FT), binned lists, clip tables, per-workgroup scratch
     return align256((size_t)N * FT * sizeof(uint32_t)) + align256(sizeof(RasterCounters)) +
            align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint4)) +
+           align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(unsigned long long)) +  // tie masks (tie_rule 1)
            align256((size_t)N * FT * sizeof(float2)) + align256((size_t)N * (FT / WAVE) * sizeof(uint32_t)) +
            align256((size_t)N * sizeof(float)) + align256((size_t)N * list_cap_of(m, S) * sizeof(uint2)) +
            clip_bytes(N) + 256 +
@@ -2002,6 +2224,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
                  "raster: faces_per_pixel=%d outside 1..%d", rs->faces_per_pixel, SMIL_MAX_FACES_PER_PIXEL);
     SMIL_REQUIRE(rs->sigma > 0.f && rs->blur_radius >= 0.f, "raster: bad blend settings");
+    SMIL_REQUIRE(rs->tie_rule == SMIL_TIE_DEPTH_FACE_ID || rs->tie_rule == SMIL_TIE_REFERENCE_QUEUE, "raster: tie_rule=%d is neither 0 nor 1", rs->tie_rule);
     SMIL_REQUIRE(face_rows(m) <= REC_CAP, "raster: %d faces exceed the %d a single pixel's records may hold", m->F, REC_CAP - CLIP_FX - WAVE);
     const int tiles_x = ceil_div(S, TILE);
     SMIL_REQUIRE((double)N * tiles_x * tiles_x < 2147483647.0, "raster: N * tiles exceeds the work-item index range (2^31); launch in slices");
@@ -2017,6 +2240,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     uint4 *items = (uint4 *)ws;
     const uint32_t item_cap = (uint32_t)ceil_div(N, N_PARTS) * (uint32_t)(tiles_x * tiles_x);
     ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(uint4));
+    unsigned long long *tie_mask = (unsigned long long *)ws;
+    ws += align256((size_t)2 * N_PARTS * item_cap * sizeof(unsigned long long));
     float2 *fzr = (float2 *)ws;
     ws += align256((size_t)N * FT * sizeof(float2));
     uint32_t *gbox = (uint32_t *)ws;
@@ -2034,6 +2259,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     clip.xf = (int *)ws; ws += align256((size_t)N * CLIP_FX * 12);
     clip.xcount = (uint32_t *)ws; ws += align256((size_t)N * 4);
     SMIL_HIP(hipMemsetAsync(ctr, 0, sizeof(RasterCounters), stream));
+    if (rs->tie_rule) SMIL_HIP(hipMemsetAsync(tie_mask, 0, (size_t)2 * N_PARTS * item_cap * sizeof(unsigned long long), stream));
     const float sqrt_blur = sqrtf(rs->blur_radius);
     const int n_tiles = tiles_x * tiles_x;
     {
@@ -2068,6 +2294,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.crec = (Rec3 *)ws;
     }
     a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT; a.slots = (unsigned int)tile_slots();
+    a.tie_rule = rs->tie_rule; a.tie_mask = tie_mask;
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
@@ -2124,6 +2351,11 @@ template <int MODE>
 static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
     hipLaunchKernelGGL((k_raster_dense<MODE>), dim3(tile_grid(N, a.tiles_x)), dim3(64), 0, stream, a);
 }
+// (tie_rule 1) the pixels the tile kernel left out: the reference's queue replayed, one wave per pixel
+template <int MODE>
+static void launch_tie_replay(const RasterArgs &a, hipStream_t stream) {
+    if (a.tie_rule) hipLaunchKernelGGL((k_raster_tie_replay<MODE>), dim3((unsigned int)tile_slots()), dim3(64), 0, stream, a);
+}
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,
                                        const SmilRasterSettings *rs, float *sil, void *workspace, void *stream_) {
@@ -2137,6 +2369,7 @@ extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_nd
     PROF_BEGIN(stream);
     launch_tiles<MODE_FWD>(a, N, stream);
     PROF_END(stream);
+    launch_tie_replay<MODE_FWD>(a, stream);
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -2154,6 +2387,7 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
     PROF_BEGIN(stream);
     launch_tiles<MODE_BWD>(a, N, stream);
     PROF_END(stream);
+    launch_tie_replay<MODE_BWD>(a, stream);
     SMIL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V);  // (new vertices of cut faces -> their edges' end points)
     SMIL_LAUNCH_CHECK();
@@ -2179,6 +2413,7 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     PROF_BEGIN(stream);
     launch_tiles<MODE_FUSED>(a, N, stream);
     PROF_END(stream);
+    launch_tie_replay<MODE_FUSED>(a, stream);
     SMIL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V);  // (new vertices of cut faces -> their edges' end points)
     SMIL_LAUNCH_CHECK();

@@ -160,9 +160,16 @@ class CameraSet:
         return c
 
 
-def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL) -> _lib.RasterSettings:
+TIE_RULES = {"depth_face_id": 0, "reference_queue": 1}
+
+
+def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL, tie_rule="depth_face_id") -> _lib.RasterSettings:
+    """``tie_rule``: which faces a truncated pixel keeps among equal depths at its K-th place - ``"depth_face_id"`` (default: the
+    smallest face ids, order independent) or ``"reference_queue"`` (what pytorch3d's unsorted K-queue keeps when it visits the
+    faces in index order, the reference's rasteriser: those pixels are replayed by a second kernel)."""
     rs = _lib.RasterSettings()
     rs.blur_radius, rs.sigma, rs.faces_per_pixel, rs.z_clip = blur, sigma, K, ZNEAR / 2
+    rs.tie_rule = TIE_RULES[tie_rule] if isinstance(tie_rule, str) else int(tie_rule)
     return rs
 
 

@@ -208,6 +208,45 @@ def test_truncation_rule_with_exact_ties(tables, dmodels):
     assert np.abs(got - ref1).max() < 2e-5, np.abs(got - ref1).max()
 
 
+@pytest.mark.parametrize("key,S,dist,K,rules_differ", [("synthetic", 40, 2.2, 6, False), ("stick", 64, 2.7, 100, True), ("stick", 48, 2.7, 17, True),
+                                                        ("stick", 64, 2.7, 30, True), ("mouse", 96, 4.0, 100, True)])
+def test_reference_queue_tie_rule(key, S, dist, K, rules_differ, tables, dmodels):
+    """``tie_rule="reference_queue"``: pixels whose tie group at the K-th depth is cut by K are replayed through pytorch3d's
+    unsorted K-queue in face order (RasterizeMeshesNaive, selected by p3d_renderer.py:42-47), so forward, fused loss and gradient
+    agree with the oracle's FAITHFUL queue (select_mode 0) as tightly as the default rule agrees with select_mode 1 - on scenes
+    where the two rules themselves differ."""
+    eng = _engine()
+    t, dm = tables(key), dmodels(key)
+    N = 2
+    ndc = _posed_ndc(t, N, S, dist, 7)
+    ref0, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)      # the reference's queue
+    with render_ref.select_mode(1):
+        ref1, _ = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)       # (depth, face id)
+    rs_q, rs_d = eng.raster_settings(K=K, tie_rule="reference_queue"), eng.raster_settings(K=K)
+    got_q = eng.silhouette_forward(dm, ndc.to(DEV), S, rs_q).cpu().numpy()
+    got_d = eng.silhouette_forward(dm, ndc.to(DEV), S, rs_d).cpu().numpy()
+    assert (ncand > K).mean() > 0.02
+    assert np.abs(got_d - ref1).max() < 2e-5 and np.abs(got_q - ref0).max() < 2e-5, (np.abs(got_d - ref1).max(), np.abs(got_q - ref0).max())
+    if rules_differ:  # (the two rules give different silhouettes on this scene, by up to 0.03: the line above is not vacuous)
+        assert np.abs(ref0 - ref1).max() > 5e-5
+    # gradient and fused loss under the queue rule against the oracle's default (faithful) backward
+    g = torch.Generator().manual_seed(3)
+    gsil = (torch.randn(N, S, S, generator=g) / (S * S)).contiguous()
+    want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gsil.numpy(), K=K)[..., :2]
+    d_q = eng.silhouette_backward(dm, ndc.to(DEV), S, gsil.to(DEV), rs_q).cpu().numpy()
+    err = np.abs(d_q - want) / np.abs(want).max()
+    assert err.max() < 1e-3 and np.sqrt((err ** 2).mean()) < 2e-5, (err.max(), np.sqrt((err ** 2).mean()))
+    target = (torch.from_numpy(ref0) > 0.5).float()
+    scale = torch.tensor([0.7, 1.3]) / (S * S)
+    li, d_f, sil_f = eng.silhouette_l1_fused(dm, ndc.to(DEV), S, target.to(DEV), eng.image_abs_sum(target.to(DEV)), scale.to(DEV), rs_q, want_sil=True)
+    assert np.abs(sil_f.cpu().numpy() - ref0).max() < 2e-5
+    np.testing.assert_allclose(li.cpu().numpy(), np.abs(ref0 - target.numpy()).sum(axis=(1, 2)), rtol=2e-5)
+    gs2 = (np.sign(ref0 - target.numpy()) * scale.numpy()[:, None, None]).astype(np.float32)
+    want2 = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs2, K=K)[..., :2]
+    err2 = np.abs(d_f.cpu().numpy() - want2) / np.abs(want2).max()
+    assert err2.max() < 1e-3 and np.sqrt((err2 ** 2).mean()) < 2e-5, (err2.max(), np.sqrt((err2 ** 2).mean()))
+
+
 @pytest.mark.parametrize("key,S,dist,K", [("synthetic", 48, 2.2, 100), ("synthetic", 40, 2.2, 6), ("stick", 64, 2.7, 100)])
 def test_silhouette_backward_and_fused(key, S, dist, K, tables, dmodels):
     eng = _engine()

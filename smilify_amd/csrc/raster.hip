@@ -710,7 +710,9 @@ __device__ __forceinline__ f32x2 pair_depth2(const FaceRows &q, const PairEval2 
     const f32x2 msum = m0 + m1 + m2, floor_ = splat2(1e-5f) * den;
     const f32x2 cs = {fmaxf(msum.x, floor_.x), fmaxf(msum.y, floor_.y)};
     const f32x2 rc = {__builtin_amdgcn_rcpf(cs.x), __builtin_amdgcn_rcpf(cs.y)};
-    const f32x2 pz = pk_fma(splat2(z0), m0 * rc, splat2(z1) * (m1 * rc)) + splat2(z2) * (m2 * rc);
+    // (every fused multiply-add spelled out: left to the compiler, the last one is contracted in one inlining context and not in
+    // another - k_raster_tie_replay must reproduce these depths bit for bit, or an exact tie here is no tie there)
+    const f32x2 pz = pk_fma(splat2(z2), m2 * rc, pk_fma(splat2(z0), m0 * rc, splat2(z1) * (m1 * rc)));
     // one survivor <=> the sum of the clipped weights equals their maximum (and was not lifted by the 1e-5 floor)
     const float mx0 = fmaxf(fmaxf(m0.x, m1.x), m2.x), mx1 = fmaxf(fmaxf(m0.y, m1.y), m2.y);
     const bool single0 = (msum.x == mx0) && (mx0 >= cs.x), single1 = (msum.y == mx1) && (mx1 >= cs.y);
@@ -922,6 +924,36 @@ __device__ __forceinline__ Tri9 load_tri(const RasterArgs &a, const float *__res
     const float *p0 = vertex_ptr(vn, xv_n, a.V, i0), *p1 = vertex_ptr(vn, xv_n, a.V, i1), *p2 = vertex_ptr(vn, xv_n, a.V, i2);
     return Tri9{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2]};
 }
+// The seven rows of a face record from its vertices, in two halves (stage_faces: one lane each).  Every rounding is spelled out -
+// no contraction left to the compiler (which fuses a*b - c*d one way in one inlining context and another way in the next): the
+// tile kernel and k_raster_tie_replay must get the SAME bits from the same face, or an exact depth tie in one is no tie in the other.
+__device__ __forceinline__ float edge_fx(float px, float py, float ax, float ay, float bx, float by) {
+#pragma clang fp contract(off)
+    return fmaf(px - ax, by - ay, -((py - ay) * (bx - ax)));
+}
+__device__ __forceinline__ void face_rows_lo(const Tri9 &tv, float cx, float cy, float4 &r0, float4 &r1, float4 &r2) {
+#pragma clang fp contract(off)
+    const float x0 = tv.x0, y0 = tv.y0, z0 = tv.z0, x1 = tv.x1, y1 = tv.y1, z1 = tv.z1, x2 = tv.x2, y2 = tv.y2, z2 = tv.z2;
+    // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
+    const float rcp_area = __builtin_amdgcn_rcpf(edge_fx(x2, y2, x0, y0, x1, y1) + K_EPS);
+    // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
+    const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
+    r0 = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);                                      // A0 A1 B0 B1
+    r1 = make_float4(edge_fx(cx, cy, x1, y1, x2, y2) * s0, edge_fx(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);  // C0 C1 A2 B2
+    r2 = make_float4(edge_fx(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
+}
+__device__ __forceinline__ void face_rows_hi(const Tri9 &tv, float cx, float cy, float4 &r3, float4 &r4, float4 &r5, float &rl12_out) {
+#pragma clang fp contract(off)
+    const float x0 = tv.x0, y0 = tv.y0, x1 = tv.x1, y1 = tv.y1, x2 = tv.x2, y2 = tv.y2;
+    const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
+    const float l01 = fmaf(e01x, e01x, e01y * e01y), l02 = fmaf(e02x, e02x, e02y * e02y), l12 = fmaf(e12x, e12x, e12y * e12y);
+    const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
+    const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
+    rl12_out = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
+    r3 = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
+    r4 = make_float4(e01x, e02x, e01y, e02y);
+    r5 = make_float4(rl01, rl02, e12x, e12y);
+}
 __device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv, int i0, int i1, int i2, int m,
                                             float *rec, int lane, float cx, float cy, float fS, int tx, int ty, int ox0, int ox1,
                                             int oy0, int oy1, unsigned long long open_px, int &cf, int &packed2, float2 *__restrict__ sxy,
@@ -930,9 +962,7 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv,
     const bool hi = lane >= DCHUNK;
     int b0 = 0, b1 = -1;  // low lane: box rows by0 .. by1; high lane: box columns bx0 .. bx1
     if (slot < m) {
-        const float x0 = tv.x0, y0 = tv.y0, z0 = tv.z0;
-        const float x1 = tv.x1, y1 = tv.y1, z1 = tv.z1;
-        const float x2 = tv.x2, y2 = tv.y2, z2 = tv.z2;
+        const float x0 = tv.x0, y0 = tv.y0, x1 = tv.x1, y1 = tv.y1, x2 = tv.x2, y2 = tv.y2;
         float4 *r = reinterpret_cast<float4 *>(rec + slot * FSTR);
         // The tile's vertex table for pass 3: three arrays of float2 (v0, v1, v2 by list position) and the vertex ids, so that every
         // store instruction writes whole runs of bytes (one 24-byte structure per face, stored as 16 + 8 bytes, cost 0.45 ms per
@@ -940,27 +970,15 @@ __device__ __forceinline__ void stage_faces(const RasterArgs &a, const Tri9 &tv,
         at(sxy, (uint32_t)((hi ? list_stride : 0) + c0 + slot)) = hi ? make_float2(x1, y1) : make_float2(x0, y0);
         if (!hi) {
             at(sid, (uint32_t)(c0 + slot)) = TriIds{i0, i1, i2};
-            // (only the signs of the w_i and their ratios are used: the scale's last bits do not matter)
-            const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
-            // edge function e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax), linear in p; value at the tile centre + slopes
-            const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
-            r[0] = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);                                      // A0 A1 B0 B1
-            r[1] = make_float4(edge_fn(cx, cy, x1, y1, x2, y2) * s0, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);  // C0 C1 A2 B2
-            r[2] = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
+            face_rows_lo(tv, cx, cy, r[0], r[1], r[2]);
             const float ymin = fminf(fminf(y0, y1), y2) - a.sqrt_blur, ymax = fmaxf(fmaxf(y0, y1), y2) + a.sqrt_blur;
             const int yi_lo = (int)ceilf(((ymin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), yi_hi = (int)floorf(((ymax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
             b0 = max(a.S - 1 - yi_hi - ty * TILE, oy0);
             b1 = min(a.S - 1 - yi_lo - ty * TILE, oy1);
         } else {
             const float xmin = fminf(fminf(x0, x1), x2) - a.sqrt_blur, xmax = fmaxf(fmaxf(x0, x1), x2) + a.sqrt_blur;
-            const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
-            const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
-            const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
-            const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
-            const float rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
-            r[3] = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
-            r[4] = make_float4(e01x, e02x, e01y, e02y);
-            r[5] = make_float4(rl01, rl02, e12x, e12y);
+            float rl12;
+            face_rows_hi(tv, cx, cy, r[3], r[4], r[5], rl12);
             r[6] = make_float4(rl12, __int_as_float(i0), __int_as_float(i1), __int_as_float(i2));
             at(sxy, (uint32_t)(2 * list_stride + c0 + slot)) = make_float2(x2, y2);  // (the table, see above)
             const int xi_lo = (int)ceilf(((xmin + 1.0f) * fS - 1.0f) * 0.5f - 0.01f), xi_hi = (int)floorf(((xmax + 1.0f) * fS - 1.0f) * 0.5f + 0.01f);
@@ -1928,22 +1946,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
 // registers), the candidates fed to the queue one by one.  Then the pixel's blend, loss term and gradient from the queue's final
 // content, exactly as the tile kernel computes them from its records.  ~2 % of the truncated pixels take this path.
 __device__ __forceinline__ FaceRows face_rows_from_tri(const Tri9 &tv, float cx, float cy) {
-    const float x0 = tv.x0, y0 = tv.y0, z0 = tv.z0, x1 = tv.x1, y1 = tv.y1, z1 = tv.z1, x2 = tv.x2, y2 = tv.y2, z2 = tv.z2;
     FaceRows q;
-    // (the expressions of stage_faces, both halves)
-    const float rcp_area = __builtin_amdgcn_rcpf(edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS);
-    const float s0 = rcp_area * (z1 * z2), s1 = rcp_area * (z0 * z2), s2 = rcp_area * (z0 * z1);
-    q.r0 = make_float4((y2 - y1) * s0, (y0 - y2) * s1, -(x2 - x1) * s0, -(x0 - x2) * s1);
-    q.r1 = make_float4(edge_fn(cx, cy, x1, y1, x2, y2) * s0, edge_fn(cx, cy, x2, y2, x0, y0) * s1, (y1 - y0) * s2, -(x1 - x0) * s2);
-    q.r2 = make_float4(edge_fn(cx, cy, x0, y0, x1, y1) * s2, z0, z1, z2);
-    const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
-    const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
-    const float rl01 = l01 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l01);
-    const float rl02 = l02 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l02);
-    const float rl12 = l12 <= K_EPS ? 0.f : __builtin_amdgcn_rcpf(l12);
-    q.r3 = make_float4(x0 - cx, x1 - cx, y0 - cy, y1 - cy);
-    q.r4 = make_float4(e01x, e02x, e01y, e02y);
-    q.r5 = make_float4(rl01, rl02, e12x, e12y);
+    float rl12;
+    face_rows_lo(tv, cx, cy, q.r0, q.r1, q.r2);
+    face_rows_hi(tv, cx, cy, q.r3, q.r4, q.r5, rl12);
     q.r6 = make_float4(rl12, 0.f, 0.f, 0.f);
     return q;
 }
@@ -1995,6 +2001,11 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             mask &= mask - 1ull;
             const int xo = tx * TILE + (p & 7), yo = ty * TILE + (p >> 3);
             const float dxp = pix_to_ndc(a.S - 1 - xo, a.S) - cx, dyp = pix_to_ndc(a.S - 1 - yo, a.S) - cy;
+            // (the pair arithmetic is evaluated for the pixel AND its horizontal neighbour, as the tile kernel's lanes do: with the
+            // same inputs in both halves of the packed operations the compiler folds them into a different, scalar sequence whose
+            // last bits differ - and an exact depth tie of the tile kernel's arithmetic is then no tie here)
+            const bool odd = (p & 1) != 0;
+            const float dx_even = pix_to_ndc(a.S - 1 - (xo & ~1), a.S) - cx, dx_odd = pix_to_ndc(a.S - 1 - (xo | 1), a.S) - cx;
             // ---- the queue: depth bits, {face | inside << 22 | closest edge << 23}, signed squared distance ----
             uint32_t qz0 = 0u, qz1 = 0u, qm0 = 0u, qm1 = 0u;
             float qs0 = 0.f, qs1 = 0.f;
@@ -2014,12 +2025,12 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                         const int i0 = face_vertex(a.faces, xf_n, a.F, f, 0), i1 = face_vertex(a.faces, xf_n, a.F, f, 1), i2 = face_vertex(a.faces, xf_n, a.F, f, 2);
                         const FaceRows fr = face_rows_from_tri(load_tri(a, vn, xv_n, i0, i1, i2), cx, cy);
                         PairEval2 e;
-                        eval_pair2(fr, dxp, dxp, dyp, a.blur, e);
-                        cand = e.cand0;
+                        eval_pair2(fr, dx_even, dx_odd, dyp, a.blur, e);
+                        cand = odd ? e.cand1 : e.cand0;
                         const f32x2 z2 = pair_depth2(fr, e);
-                        zb = __float_as_uint(vmax_raw(z2.x, fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w)));
-                        sd = e.sd.x;
-                        fl = (e.inside0 ? 1u << 22 : 0u) | e.ebits0;
+                        zb = __float_as_uint(vmax_raw(odd ? z2.y : z2.x, fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w)));
+                        sd = odd ? e.sd.y : e.sd.x;
+                        fl = ((odd ? e.inside1 : e.inside0) ? 1u << 22 : 0u) | (odd ? e.ebits1 : e.ebits0);
                     }
                     unsigned long long cm = __ballot(cand);
                     while (cm) {  // its candidates, in face order, one by one through the reference's queue

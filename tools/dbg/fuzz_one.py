@@ -1,5 +1,5 @@
 # one scene of tools/dbg/fuzz_raster.py taken apart pixel by pixel: which pixels carry the gradient disagreement with the oracle
-#   python tools/dbg/fuzz_one.py <seed> [clip]
+#   python tools/dbg/fuzz_one.py <seed> [clip|queue]
 import os, sys
 import numpy as np, torch
 REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -9,6 +9,8 @@ from oracle import render_ref, lbs_ref, fitter_ref
 from conftest import oracle_model
 DEV = "cuda:0"
 seed = int(sys.argv[1]); CLIP = len(sys.argv) > 2 and sys.argv[2] == "clip"
+QUEUE = len(sys.argv) > 2 and sys.argv[2] == "queue"   # tie_rule="reference_queue" against the oracle's faithful queue
+MODE, RULE = (0, "reference_queue") if QUEUE else (1, "depth_face_id")
 rng = np.random.default_rng(seed)
 key = ["synthetic", "stick", "mouse"][int(rng.integers(0, 3))]
 t = {"synthetic": model_io.synthetic_model,
@@ -27,8 +29,8 @@ theta[:, 0] = torch.from_numpy(fitter_ref.default_global_rotation()) + 0.5 * tor
 verts = lbs_ref.smal_forward(m, torch.zeros(N, t.nB), theta)["verts"]
 R, T = render_ref.look_at_view_transform(dist, float(g.initial_seed() % 60), torch.linspace(0, 300, N))
 ndc = render_ref.project_to_ndc(verts, R, T, torch.full((N,), 60.0)).contiguous()
-rs = engine.raster_settings(K=K)
-with render_ref.select_mode(1):
+rs = engine.raster_settings(K=K, tie_rule=RULE)
+with render_ref.select_mode(MODE):
     ref1, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)
 got = engine.silhouette_forward(dm, ndc.to(DEV), S, rs).cpu().numpy()
 gs = rng.standard_normal((N, S, S)).astype(np.float32)
@@ -46,7 +48,7 @@ if CLIP:
 
 
 def both(gmask):
-    with render_ref.select_mode(1):
+    with render_ref.select_mode(MODE):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gmask, K=K)[..., :2]
     gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, torch.from_numpy(gmask).to(DEV), rs).cpu().numpy()
     return want, gotg

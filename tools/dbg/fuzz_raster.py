@@ -20,6 +20,8 @@ def scene(t, N, S, dist, seed, scale=1.0):
     return render_ref.project_to_ndc(verts, R, T, torch.full((N,), 60.0)).contiguous()
 bad = 0
 CLIP = len(sys.argv) > 3 and sys.argv[3] == "clip"  # camera INSIDE the mesh's reach: faces cross z_clip and get cut (clip_faces)
+QUEUE = len(sys.argv) > 3 and sys.argv[3] == "queue"  # tie_rule="reference_queue" against the oracle's FAITHFUL queue (select_mode 0)
+MODE, RULE = (0, "reference_queue") if QUEUE else (1, "depth_face_id")
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)
     key = ["synthetic", "stick", "mouse"][int(rng.integers(0, 3))]
@@ -30,16 +32,16 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         dist = float(rng.uniform(0.05, 0.9)) * (1.5 if key == "mouse" else 1.0)
     N = int(rng.integers(1, 4))
     ndc = scene(t, N, S, dist, seed)
-    with render_ref.select_mode(1):
+    with render_ref.select_mode(MODE):
         ref1, ncand = render_ref.silhouette_forward_np(ndc.numpy(), t.faces, S, K=K)
-    got = engine.silhouette_forward(dm, ndc.to(DEV), S, engine.raster_settings(K=K)).cpu().numpy()
+    got = engine.silhouette_forward(dm, ndc.to(DEV), S, engine.raster_settings(K=K, tie_rule=RULE)).cpu().numpy()
     d1 = np.abs(got - ref1)
     # (cut faces carry vertices at |xy| up to 1e3 NDC units: fp32 cancellation on both sides; looser there)
     ok = d1.mean() < (2e-4 if CLIP else 5e-6) and np.mean(d1 > 1e-4) < (3e-2 if CLIP else 5e-3) and (CLIP or d1[ncand <= K].max(initial=0.0) < 3e-4)
     gs = torch.from_numpy(rng.standard_normal((N, S, S)).astype(np.float32))
-    with render_ref.select_mode(1):
+    with render_ref.select_mode(MODE):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy(), K=K)[..., :2]
-    gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), engine.raster_settings(K=K)).cpu().numpy()
+    gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), engine.raster_settings(K=K, tie_rule=RULE)).cpu().numpy()
     nrm = np.linalg.norm(want)
     cos = (gotg * want).sum() / (np.linalg.norm(gotg) * nrm + 1e-30) if nrm > 0 else 1.0
     ok = ok and (cos > (0.97 if CLIP else 0.99) or nrm < 1e-6) and np.isfinite(gotg).all()

@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy
 PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 1024  # 256 CUs x 4 SIMD-32: one wave64 VALU instruction occupies a SIMD's pipe for 2 cycles
-TRAFFIC_FILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")  # PMC counts per launch (tools/pmc_traffic.sh); the newest that exists is used
+TRAFFIC_FILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")  # PMC counts per launch (tools/pmc_traffic.sh); the newest that exists is used
 PARITY_TOL = 1e-4  # north star: fp32 losses within 1e-4 relative of the reference algorithm (here: its CPU oracle)
 
 
@@ -173,7 +173,7 @@ def parity_check(fitter, tables, wl, sample, window):
                     "(depth, face id) tie rule, DESIGN.md section 4)"}
 
 
-def time_other_workload(key, dev, steps=5, warmup=2, frames=0, graph=False):
+def time_other_workload(key, dev, steps=5, warmup=3, frames=0, graph=False):
     """One of the other BASELINE configurations, timed AFTER the headline region and outside it (rank 0, one GPU): the same fit
     iteration on that configuration's own synthetic problem.  Returns ms per step, the tile kernel's average launch time from
     HIP events, and the roofline fraction by the same definition as the headline (algorithmic bytes per launch / kernel time)."""

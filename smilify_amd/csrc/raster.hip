@@ -300,6 +300,9 @@ struct SetupArgs {
     uint2 *lists;       // (N, list_cap) binned tile lists: {face id, bits of its nearest vertex depth} (8 bytes: the farthest depth only ever fed the
                         // tile's depth range, and farthest <= nearest + the image's largest face extent bounds that as well)
     uint32_t list_cap;  // entries per image (0: no binning)
+    int copies;         // (round 5) per-tile counters / list cursors are kept in this many copies (1, 2 or 4: what fits 48 KB of LDS), a
+                        // face using copy (face id % copies): consecutive faces hit the same tiles, and LDS atomics of one wave
+                        // instruction on ONE address execute one after the other - the two atomic passes were two thirds of this kernel
 };
 // One workgroup per image.  Pass 1: per face validity, blurred pixel box -> tile box, depth range; per covered tile ONE LDS
 // atomic adds the face's cost and list entry (64-bit: entries << 32 | cost).  Then the touched tiles go to the work lists by cost
@@ -330,8 +333,9 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
     uint32_t *const tbits = reinterpret_cast<uint32_t *>(tcnt64);        // (!counted) touched-tile bitmap
-    uint32_t *const tcur = reinterpret_cast<uint32_t *>(tcnt64 + n_tiles);  // (counted) list cursor of every tile
-    if (counted) { for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) tcnt64[i] = 0ull; }
+    const int KC = counted ? q.copies : 1;                                   // copies of the per-tile words: [copy][tile]
+    uint32_t *const tcur = reinterpret_cast<uint32_t *>(tcnt64 + KC * n_tiles);  // (counted) list cursor of every tile and copy
+    if (counted) { for (int i = threadIdx.x; i < KC * n_tiles; i += blockDim.x) tcnt64[i] = 0ull; }
     else { for (int i = threadIdx.x; i < (n_tiles + 31) >> 5; i += blockDim.x) tbits[i] = 0u; }
     __syncthreads();
     const float *vn = q.verts_ndc + (size_t)n * V * 3;
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
                         if (counted) {  // cost of this face in this tile: its (face, pixel) pairs plus a bit for staging it; one list entry
                             const int wx = min(xo1, tx * TILE + TILE - 1) - max(xo0, tx * TILE) + 1;
                             const int wy = min(yo1, ty * TILE + TILE - 1) - max(yo0, ty * TILE) + 1;
-                            HOOK_SETUP_COUNT(atomicAdd(&tcnt64[t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));)
+                            HOOK_SETUP_COUNT(atomicAdd(&tcnt64[(fid & (KC - 1)) * n_tiles + t], (1ull << 32) | (unsigned long long)(uint32_t)(wx * wy + 8));)
                         } else {
                             atomicOr(&tbits[t >> 5], 1u << (t & 31));
                         }
@@ -526,7 +530,8 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     __syncthreads();
     auto tile_class = [&](int t) -> int {  // -1: untouched
         if (!counted) return ((tbits[t >> 5] >> (t & 31)) & 1u) ? N_CLASSES - 1 : -1;
-        const uint32_t c = (uint32_t)tcnt64[t];
+        uint32_t c = 0u;
+        for (int k = 0; k < KC; ++k) c += (uint32_t)tcnt64[k * n_tiles + t];
         return c == 0u ? -1 : (c >= CLASS_T0 ? 0 : (c >= CLASS_T1 ? 1 : (c >= CLASS_T2 ? 2 : 3)));
     };
     uint32_t mine[N_CLASSES] = {0u, 0u, 0u, 0u};
@@ -535,7 +540,8 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         const int c = tile_class(t);
 #pragma unroll
         for (int k = 0; k < N_CLASSES; ++k) mine[k] += (c == k) ? 1u : 0u;
-        if (counted) my_ents += (uint32_t)(tcnt64[t] >> 32);
+        if (counted)
+            for (int k = 0; k < KC; ++k) my_ents += (uint32_t)(tcnt64[k * n_tiles + t] >> 32);
     }
     uint32_t off[N_CLASSES];
 #pragma unroll
@@ -559,8 +565,13 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
     const uint32_t zext_bits = s_zext;  // (final since the barrier behind the atomicMax above)
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int c = tile_class(t);
-        const uint32_t e = counted ? (uint32_t)(tcnt64[t] >> 32) : 0u, first = run;
-        if (binned) tcur[t] = run;
+        uint32_t e = 0u;
+        const uint32_t first = run;
+        if (counted)
+            for (int k = 0; k < KC; ++k) {  // a tile's entries lie copy by copy inside its list
+                if (binned) tcur[k * n_tiles + t] = run + e;
+                e += (uint32_t)(tcnt64[k * n_tiles + t] >> 32);
+            }
         run += e;
         if (c < 0) continue;
         uint32_t slot = 0u;
@@ -587,8 +598,11 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         const uint2 ent = make_uint2((uint32_t)f, __float_as_uint(q.fzr[(size_t)n * FT + f].x));  // (requested with the box: one round trip)
         const int tx0 = box & 0xFF, ty0 = (box >> 8) & 0xFF, tx1 = (box >> 16) & 0xFF, ty1 = box >> 24;
         if (tx0 > tx1) continue;
+        uint32_t *const cur = tcur + (f & (KC - 1)) * n_tiles;
+        // (a fast path for boxes of at most 2 x 2 tiles - the four returning atomics issued before the four stores - measured no
+        // different, profiles/r5_experiments.md)
         for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&tcur[ty * tiles_x + tx], 1u)) = ent;
+            for (int tx = tx0; tx <= tx1; ++tx) at(lists, atomicAdd(&cur[ty * tiles_x + tx], 1u)) = ent;
     }
     TSETUP(8)
     TSETUP_REPORT
@@ -2280,8 +2294,12 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.img_bound = img_bound; q.max_valence = m->max_valence;
         q.dndc_scale = dndc_scale; q.pix_scale = pix_scale; q.inv_sigma = 1.0f / rs->sigma; q.packed = packed;
         q.lists = lists; q.list_cap = list_cap; q.clip = clip;
-        // per tile: 8 bytes of counts + 4 bytes of list cursor, or one bit
-        const size_t setup_lds = n_tiles <= COUNT_TILES_MAX ? (size_t)n_tiles * 12 : (size_t)((n_tiles + 31) / 32) * sizeof(uint32_t);
+        // per tile and copy: 8 bytes of counts + 4 bytes of list cursor (as many copies as fit 48 KB: two workgroups per CU), or one bit
+        q.copies = n_tiles * 2 * 12 <= 48 * 1024 ? 2 : 1;  // (measured: two copies -10 % STICK / -17 % mouse at 256^2, four copies -5 % / -6 %)
+#ifdef SETUP_COPIES
+        q.copies = SETUP_COPIES;
+#endif
+        const size_t setup_lds = n_tiles <= COUNT_TILES_MAX ? (size_t)n_tiles * q.copies * 12 : (size_t)((n_tiles + 31) / 32) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_raster_setup, dim3(N), dim3(SETUP_THREADS), setup_lds, stream, q);
         SMIL_LAUNCH_CHECK();
     }

@@ -6,7 +6,7 @@ for v in "$@"; do
   lib=$L/libsmilfit_$v.so; [ "$v" = main ] && lib=$L/libsmilfit.so
   out=gpurun_out/kstats/$v; rm -rf $out; mkdir -p $out
   export SMILFIT_LIB=$lib
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o k -- python3 bench.py --steps 8 --warmup 2 --cpu-frames 0 > $out/log.txt 2>&1 < /dev/null
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o k -- python3 bench.py --steps 8 --warmup 2 --cpu-frames 0 --no-others > $out/log.txt 2>&1 < /dev/null
   echo "== $v rc=$?"
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'

@@ -246,7 +246,8 @@ int smil_silhouette_backward(const SmilModel *m, const float *verts_ndc, int32_t
  * fitter.py:332-333): loss_img[n] = sum_px |sil - target|, d_ndc (N,V,2) = d(sum_n pix_scale[n] *
  * loss_img[n]) / d ndc.  target_sum[n] = sum_px target (constant, computed once by the caller) lets
  * untouched tiles skip their target read.  target is (N,S,S) fp32, or uint8 holding binary {0,1} masks when
- * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL.
+ * target_is_u8 (a quarter of the memory and read traffic).  sil_out may be NULL.  loss_img is bit-reproducible: the tiles'
+ * terms are summed as 2^-32 fixed-point integers (any order of arrival) and added to target_sum[n] once.
  * From 64 images per call on (and an 8-byte aligned d_ndc), d_ndc is accumulated as 64-bit packed fixed point in the same
  * buffer: every (face, pixel) contribution is rounded once to 2^-30 of a per-image worst-case bound (vertex valence x largest
  * face pixel box x 0.4 |pix_scale| / sqrt(sigma)) and all further sums are integer adds - independent of the order in which

@@ -199,6 +199,8 @@ struct RasterArgs {
     const float *img_bound;  // (N,) setup kernel: 0.4 x valence x largest face box (pixels), the geometric part of the bound on a vertex's gradient
     int packed;              // FUSED: d_ndc is accumulated as (x, y) fixed point packed in 64 bits (one memory-side atomic per vertex, not two)
     float *loss_img;         // FUSED (N,)
+    unsigned long long *loss_acc;  // FUSED (N,) the tiles' loss terms as 2^-32 fixed point: integer adds, the same bits in any order of
+                             // arrival (round 5; a float atomic per tile before); k_clip_backward adds the sum to loss_img afterwards
     float *d_ndc;            // (N,V,2)
     // scratch per resident workgroup
     const uint2 *lists;      // (N, list_cap) tile lists binned by the setup kernel: {face id, bits of its nearest vertex depth}
@@ -295,7 +297,7 @@ struct SetupArgs {
     uint32_t *tbox, *gbox; uint4 *items; uint32_t item_cap; float2 *fzr;
     RasterCounters *ctr;
     int V, F, S, tiles_x; float sqrt_blur, z_clip;
-    float *d_ndc_zero; const float *loss_src; float *loss_dst; float *img_bound; int max_valence;
+    float *d_ndc_zero; const float *loss_src; float *loss_dst; unsigned long long *loss_acc; float *img_bound; int max_valence;
     float *dndc_scale; const float *pix_scale; float inv_sigma; int packed;
     uint2 *lists;       // (N, list_cap) binned tile lists: {face id, bits of its nearest vertex depth} (8 bytes: the farthest depth only ever fed the
                         // tile's depth range, and farthest <= nearest + the image's largest face extent bounds that as well)
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         float2 *z = reinterpret_cast<float2 *>(q.d_ndc_zero) + (size_t)n * V;
         for (int i = threadIdx.x; i < V; i += blockDim.x) z[i] = make_float2(0.f, 0.f);
     }
-    if (q.loss_dst && threadIdx.x == 0) q.loss_dst[n] = q.loss_src[n];
+    if (q.loss_dst && threadIdx.x == 0) { q.loss_dst[n] = q.loss_src[n]; q.loss_acc[n] = 0ull; }
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
     uint32_t *const tbits = reinterpret_cast<uint32_t *>(tcnt64);        // (!counted) touched-tile bitmap
@@ -765,8 +767,11 @@ __global__ void __launch_bounds__(256) k_unpack_dndc(float *__restrict__ d_ndc, 
 // Gradient of the new vertices of cut faces back to the end points of the edges they lie on: xy_new = c_a xy_a + c_b xy_b with the
 // coefficients held constant (see ClipTables).  One workgroup per image; images without cut faces leave at once.  Images with
 // cut faces accumulate in plain floats, so these are float atomics on d_ndc (two new vertices may share an end point).
-__global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__restrict__ d_ndc, int V) {
+__global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__restrict__ d_ndc, int V, float *__restrict__ loss_img,
+                                                      const unsigned long long *__restrict__ loss_acc) {
     const int n = blockIdx.x;
+    // (fused entry point: the image's loss = what the setup kernel seeded it with + the tiles' terms, summed as integers)
+    if (loss_img && threadIdx.x == 0) loss_img[n] += (float)((double)(long long)loss_acc[n] * (1.0 / 4294967296.0));
     const uint32_t nx = c.xcount[n];
     for (uint32_t j = threadIdx.x; j < nx; j += blockDim.x) {
         const float gx = c.xg[((size_t)n * CLIP_VX + j) * 2], gy = c.xg[((size_t)n * CLIP_VX + j) * 2 + 1];
@@ -1776,7 +1781,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     if (a.sil) a.sil[pix] = silv;
                 }
                 lsum = wave_sum(lsum);
-                if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
+                if (lane == 0 && lsum != 0.f) atomicAdd(&a.loss_acc[n], (unsigned long long)(long long)rint((double)lsum * 4294967296.0));
             }
 
             // ---------------- pass 3: lane = record -------------------------------------------------
@@ -2101,7 +2106,7 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                 g = a.pix_scale[n] * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
                 if (lane == 0) {
                     if (a.sil) a.sil[pix] = silv;
-                    if (lsum != 0.f) atomicAdd(&a.loss_img[n], lsum);
+                    if (lsum != 0.f) atomicAdd(&a.loss_acc[n], (unsigned long long)(long long)rint((double)lsum * 4294967296.0));
                 }
             }
             if (MODE == MODE_FWD || !((g != 0.f) && (alpha > ALPHA_GRAD_EPS) && (plog_px != 0.0))) continue;  // (wave-uniform)
@@ -2221,7 +2226,7 @@ extern "C" size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int
            align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(uint4)) +
            align256((size_t)2 * N_PARTS * ceil_div(N, N_PARTS) * tiles * sizeof(unsigned long long)) +  // tie masks (tie_rule 1)
            align256((size_t)N * FT * sizeof(float2)) + align256((size_t)N * (FT / WAVE) * sizeof(uint32_t)) +
-           align256((size_t)N * sizeof(float)) + align256((size_t)N * list_cap_of(m, S) * sizeof(uint2)) +
+           align256((size_t)N * sizeof(float)) + align256((size_t)N * sizeof(unsigned long long)) + align256((size_t)N * list_cap_of(m, S) * sizeof(uint2)) +
            clip_bytes(N) + 256 +
            scratch_bytes(tile_grid(N, ceil_div(S, TILE)), face_rows(m));
 }
@@ -2273,6 +2278,8 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     ws += align256((size_t)N * (FT / WAVE) * sizeof(uint32_t));
     float *img_bound = (float *)ws;
     ws += align256((size_t)N * sizeof(float));
+    unsigned long long *loss_acc = (unsigned long long *)ws;
+    ws += align256((size_t)N * sizeof(unsigned long long));
     const uint32_t list_cap = list_cap_of(m, S);
     uint2 *lists = (uint2 *)ws;
     ws += align256((size_t)N * list_cap * sizeof(uint2));
@@ -2291,7 +2298,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         SetupArgs q;
         q.verts_ndc = verts_ndc; q.faces = m->faces; q.tbox = tbox; q.gbox = gbox; q.items = items; q.item_cap = item_cap; q.fzr = fzr;
         q.ctr = ctr; q.V = m->V; q.F = m->F; q.S = S; q.tiles_x = tiles_x; q.sqrt_blur = sqrt_blur; q.z_clip = rs->z_clip;
-        q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.img_bound = img_bound; q.max_valence = m->max_valence;
+        q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.loss_acc = loss_acc; q.img_bound = img_bound; q.max_valence = m->max_valence;
         q.dndc_scale = dndc_scale; q.pix_scale = pix_scale; q.inv_sigma = 1.0f / rs->sigma; q.packed = packed;
         q.lists = lists; q.list_cap = list_cap; q.clip = clip;
         // per tile and copy: 8 bytes of counts + 4 bytes of list cursor (as many copies as fit 48 KB: two workgroups per CU), or one bit
@@ -2323,7 +2330,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         a.crec = (Rec3 *)ws;
     }
     a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT; a.slots = (unsigned int)tile_slots();
-    a.tie_rule = rs->tie_rule; a.tie_mask = tie_mask;
+    a.tie_rule = rs->tie_rule; a.tie_mask = tie_mask; a.loss_acc = loss_acc;
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
@@ -2418,7 +2425,7 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
     PROF_END(stream);
     launch_tie_replay<MODE_BWD>(a, stream);
     SMIL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V);  // (new vertices of cut faces -> their edges' end points)
+    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V, (float *)nullptr, (const unsigned long long *)nullptr);  // (new vertices of cut faces -> their edges' end points)
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -2444,7 +2451,7 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     PROF_END(stream);
     launch_tie_replay<MODE_FUSED>(a, stream);
     SMIL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V);  // (new vertices of cut faces -> their edges' end points)
+    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V, loss_img, (const unsigned long long *)a.loss_acc);  // (new vertices of cut faces -> their edges' end points; the images' loss sums)
     SMIL_LAUNCH_CHECK();
     if (a.packed && !d_ndc_scale) {
         hipLaunchKernelGGL(k_unpack_dndc, dim3(N, ceil_div(m->V, 256)), dim3(256), 0, stream, d_ndc, a.img_bound, pix_scale, a.inv_sigma, m->V, a.clip.xcount);

@@ -37,14 +37,14 @@ def test_packed_gradient_atomics_match_float_atomics_and_are_reproducible(key, S
     li_a, dn_a, _ = eng.silhouette_l1_fused(dm, ndc, S, f._sil_dev, f._sil_sum, scale)          # one launch of 96: packed
     li_b, dn_b, _ = eng.silhouette_l1_fused(dm, ndc, S, f._sil_dev, f._sil_sum, scale)
     assert torch.equal(dn_a, dn_b)                                                               # bit-reproducible gradient
-    np.testing.assert_allclose(li_a.cpu().numpy(), li_b.cpu().numpy(), rtol=3e-6)                 # (the loss sums stay float atomics: ~100 tile terms per image in arrival order)
+    assert torch.equal(li_a, li_b)                                                               # ... and loss (round 5: the tiles' terms are summed as 2^-32 fixed point)
     dn_c = torch.empty_like(dn_a)
     li_c = torch.empty_like(li_a)
     for n0 in range(0, N, 32):                                                                   # three launches of 32: float atomics
         sl = slice(n0, n0 + 32)
         eng.silhouette_l1_fused(dm, ndc[sl].contiguous(), S, f._sil_dev[sl].contiguous(), f._sil_sum[sl].contiguous(),
                                 scale[sl].contiguous(), loss_img=li_c[sl], d_ndc=dn_c[sl])
-    np.testing.assert_allclose(li_a.cpu().numpy(), li_c.cpu().numpy(), rtol=3e-6)
+    np.testing.assert_allclose(li_a.cpu().numpy(), li_c.cpu().numpy(), rtol=1e-6)                 # (a launch of 32 deals its tiles in pieces: other partial sums)
     a, c = dn_a.cpu().numpy(), dn_c.cpu().numpy()
     assert np.abs(c).max() > 0
     assert np.abs(a[3]).max() == 0.0 and np.abs(c[3]).max() == 0.0

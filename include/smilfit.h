@@ -122,7 +122,7 @@ typedef struct {
     const float *up_v_shaped; /* (nS,V,3) or NULL: upstream gradient on the returned v_shaped; flows to d_beta and d_del_v */
     float *beta_rows;         /* scratch, 2 * B * nB_used + 16 floats: required iff shared_beta and d_beta.  The kernels leave one partial
                               sum per block there and the last block to finish adds them in a fixed order; the word behind the rows
-                              counts the finished blocks of THIS call (zeroed by the call on its stream: calls with different
+                              counts the finished blocks of THIS call (cleared by the call's own kernels: calls with different
                               scratch may run on different streams) */
 } SmilLbsGrads;            /* every output is overwritten; tables shared by all frames (shared_beta,
                               logscale_shared, btrans_shared) receive the sum over frames.  All of these sums are taken in a

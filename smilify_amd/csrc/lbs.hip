@@ -749,7 +749,8 @@ struct BetaSum {
     float *rows;        // this kernel's rows [gridDim.x][n] (NULL: it contributes nothing)
     const float *all;   // finishing kernel: every row of the call, [n_all][n] ...
     int n_all;
-    unsigned int *ctr;  // ... and the call's block counter (zeroed by the call before its first kernel); NULL in a kernel that does not finish the sum
+    unsigned int *ctr;  // ... and the call's block counter; NULL in a kernel that does not finish the sum
+    unsigned int *clear_ctr;  // a kernel that runs BEFORE the finishing one clears the counter (block 0; the kernel boundary orders it)
     float *out;         // (n) the gradient
     int accumulate;     // add to what `out` holds instead of overwriting it
     int n;              // shape coefficients in use
@@ -810,6 +811,7 @@ struct ChainBwdArgs {
 template <int NJ>
 __global__ void __launch_bounds__(64 * FRAMES_PER_BLOCK) k_chain_bwd(ChainBwdArgs a) {
     extern __shared__ float smem[];
+    if (a.beta.clear_ctr && blockIdx.x == 0 && threadIdx.x == 0) *a.beta.clear_ctr = 0u;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * (int)(blockDim.x >> 6) + wid;
     const bool live = b < a.B;
@@ -1169,6 +1171,7 @@ __device__ __forceinline__ void project_point_bwd(const float *cp /* 15 floats: 
 template <int NBT, bool VPL, int NT>
 __global__ void __launch_bounds__(NT, NDC_BWD_MIN_WAVES) k_lbs_bwd_ndc(LbsBwdNdcArgs a) {
     extern __shared__ float smem[];
+    if (a.beta.clear_ctr && blockIdx.x == 0 && threadIdx.x == 0) *a.beta.clear_ctr = 0u;
     const int V = a.V, J = a.J, views = a.cam.views;
     constexpr int NW = NT / WAVE;
     float *dvL = smem;                  // (V,3) the frame's vertex gradient
@@ -1516,14 +1519,14 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
     if (g->d_beta && nBu_all > 0 && !in->shared_beta) dbeta_frame_all = g->d_beta;
     SMIL_REQUIRE(!beta_shared || g->beta_rows, "smil_lbs_backward: shared betas need the beta_rows scratch (2 B nB_used floats)");
     BetaSum bsum;  // template: rows / all / n_all / ctr are set per kernel
-    bsum.rows = nullptr; bsum.all = g->beta_rows; bsum.n_all = 0; bsum.ctr = nullptr; bsum.out = g->d_beta;
+    bsum.rows = nullptr; bsum.all = g->beta_rows; bsum.n_all = 0; bsum.ctr = nullptr; bsum.clear_ctr = nullptr; bsum.out = g->d_beta;
     bsum.accumulate = g->accumulate_shared_beta ? 1 : 0; bsum.n = nBu_all;
     int rows_used = 0;
-    // The "last block finishes" counter of the shared shape gradient is a word of THIS CALL's scratch, behind its rows, zeroed on the
-    // call's stream before its first kernel: calls on different streams cannot interleave on it and a call that dies half way
-    // leaves nothing behind (round 4 kept one counter per model, reset by the finishing block).
+    // The "last block finishes" counter of the shared shape gradient is a word of THIS CALL's scratch, behind its rows, cleared by the
+    // kernel that runs before the finishing one (the fused vertex pass before the chain kernel, the chain kernel before the shape
+    // kernel): calls on different streams cannot interleave on it and a call that dies half way leaves nothing behind (round 4 kept
+    // one counter per model, reset by the finishing block), and no memset node is added to the iteration.
     unsigned int *const beta_ctr = beta_shared ? reinterpret_cast<unsigned int *>(g->beta_rows + (size_t)2 * B * nBu_all) : nullptr;
-    if (beta_shared) SMIL_HIP(hipMemsetAsync(beta_ctr, 0, sizeof(unsigned int), stream));
     const float *d_joints_up = up ? up->d_joints : g->d_joints;
     if (up) {
         LbsBwdNdcArgs a;
@@ -1548,7 +1551,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int per_cu = (wide || few) ? 1 : std::max(1, std::min(2, (int)(device_limits().lds_cu / lds)));
         const int grid = std::min(B, std::max(1, cus) * per_cu);
         a.beta = bsum;
-        if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; }
+        if (beta_shared) { a.beta.rows = g->beta_rows; rows_used = grid; a.beta.clear_ctr = beta_ctr; }
         const int dev_slot = current_device_slot();
 #define NDC_LAUNCH(NBT) \
         do { \
@@ -1620,6 +1623,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         const int chain_blocks = ceil_div(B, fpb);
         if (beta_shared && js) { a.beta.rows = g->beta_rows + (size_t)rows_used * nBu_all; rows_used += chain_blocks; }
         if (beta_shared && up) { a.beta.n_all = rows_used; a.beta.ctr = beta_ctr; }  // (the fused route ends here: this kernel finishes the sum)
+        if (beta_shared && !up) a.beta.clear_ctr = beta_ctr;                          // (the other route: the shape kernel below finishes it)
         a.d_posefeat = d_posefeat;
         a.d_Rs_up = g->up_Rs;
         a.parents = m->parents; a.depth = m->depth;

@@ -405,7 +405,7 @@ def main():
             # reference can run
             del fitter
             torch.cuda.empty_cache()
-            others = {k: time_other_workload(k, dev) for k in ("cfg2", "cfg3", "cfg4")}
+            others = {k: time_other_workload(k, dev, steps=20 if k == "cfg2" else 5) for k in ("cfg2", "cfg3", "cfg4")}  # (cfg2: 2 ms steps)
             others["one_frame_eager"] = time_other_workload("cfg2", dev, steps=50, warmup=5, frames=1)
             others["one_frame_graph"] = time_other_workload("cfg2", dev, steps=50, warmup=5, frames=1, graph=True)
             out["other_workloads"] = others

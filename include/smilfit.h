@@ -97,6 +97,20 @@ typedef struct {
 
 int smil_lbs_forward(const SmilModel *m, const SmilLbsInputs *in, const SmilLbsOutputs *out, void *stream);
 
+/* Depth gradients of the end points of edges that cross the rasteriser's clipping plane (pytorch3d clip_faces differentiates the
+ * crossing point through w = (z_a - z_clip) / (z_a - z_b) and the explicit depth factors; the reference leaves clipping on,
+ * p3d_renderer.py:36-47).  A sparse side channel next to d_ndc (N,V,2): the silhouette backward entry points append, per image that
+ * has cut faces, entries {vertex, d loss / d z_view[vertex]} and record the image's run in `range`; smil_lbs_backward_ndc and
+ * smil_clip_depth_backward carry them through the camera (z_view = X_world . R[:,2] + T_z) into the world-space vertex gradient.
+ * All buffers are the caller's.  No BASELINE configuration cuts a face: the channel stays empty there and costs one word read. */
+typedef struct {
+    int32_t *vertex;      /* (capacity) */
+    float *dz;            /* (capacity) */
+    uint32_t *range;      /* (N_total, 2): first entry and number of entries of every image of the caller's batch */
+    uint32_t *counter;    /* [0] entries in use (reset by the call whose image0 == 0), [1] entries that did not fit (dropped, counted) */
+    int32_t capacity;
+} SmilClipDepth;
+
 typedef struct {
     const float *d_verts;  /* (B,V,3) upstream gradient or NULL */
     const float *d_joints; /* (B,J,3) upstream gradient or NULL */
@@ -120,6 +134,8 @@ typedef struct {
     const float *up_Rs;       /* (B,J,3,3) or NULL: upstream gradient on the rotation matrices the forward returned
                               (SMAL.__call__ hands Rs to its caller, smal_torch.py:367-370); flows to d_theta / d_Rs_in */
     const float *up_v_shaped; /* (nS,V,3) or NULL: upstream gradient on the returned v_shaped; flows to d_beta and d_del_v */
+    const SmilClipDepth *clip_depth; /* or NULL (smil_lbs_backward_ndc only): depth gradients from the rasteriser's clipping plane,
+                              added to the frame's vertex gradient through the cameras */
     float *beta_rows;         /* scratch, 2 * B * nB_used + 16 floats: required iff shared_beta and d_beta.  The kernels leave one partial
                               sum per block there and the last block to finish adds them in a fixed order; the word behind the rows
                               counts the finished blocks of THIS call (cleared by the call's own kernels: calls with different
@@ -201,6 +217,9 @@ int smil_lbs_backward_ndc(const SmilModel *m, const SmilLbsInputs *in, const Smi
                           const SmilCameras *cam, const float *d_ndc, const float *d_ndc_scale, const float *d_yx_joints,
                           float *d_joints, float *d_fov_img, void *stream);
 int smil_lbs_backward_ndc_supported(const SmilModel *m, int32_t nB_used, int32_t views);
+/* The separate-kernel route's counterpart of SmilLbsGrads.clip_depth: d_verts (B,V,3) += the depth gradients of `cd` carried through
+ * the cameras (image n belongs to frame n / views).  Call after smil_project_backward{,2}. */
+int smil_clip_depth_backward(const SmilCameras *cam, const SmilClipDepth *cd, int32_t N, int32_t V, float *d_verts, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Soft silhouette.  Replaces MeshRasterizer(naive, K faces per pixel, blur) + SoftSilhouetteShader
@@ -217,6 +236,10 @@ typedef struct {
                                  what pytorch3d's unsorted K-queue ends up with when it visits the faces in index order (the
                                  reference's rasteriser, p3d_renderer.py:42-47): such pixels (~2 % of the truncated ones) are replayed
                                  one by one by a second kernel.  Measured difference on the L1 term: ~1e-5 relative at K = 100 */
+    const SmilClipDepth *clip_depth; /* or NULL: where smil_silhouette_backward / smil_silhouette_l1_fused leave the depth gradients of
+                                 cut edges' end points (NULL: dropped - the xy gradients are complete either way) */
+    int32_t image0;           /* index of this call's first image in the caller's batch (`clip_depth->range` is indexed by it): a
+                                 batch cut into several calls passes 0, N_1, N_1 + N_2, ... */
 } SmilRasterSettings;
 #define SMIL_TIE_DEPTH_FACE_ID 0
 #define SMIL_TIE_REFERENCE_QUEUE 1
@@ -229,8 +252,8 @@ size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
 /* Counters of the most recent rasteriser call that used `workspace` with the same N, copied to out4[4] (synchronises the
  * stream): [0] faces that cross z_clip (one or two vertices nearer than znear / 2): cut at the plane like pytorch3d's
  * clip_faces, which p3d_renderer.py:36-47 leaves on - the front part is rendered as one or two extra triangles whose new
- * vertices hand their gradient back to the cut edge's end points (interpolation coefficients held constant; no gradient on
- * the depths).  [1] touched 8x8 tiles.  [2] faces that cross the plane beyond the capacity of the per-image clip tables - 1024 cut faces per
+ * vertices hand their gradient back to the cut edge's end points: to their xy through d_ndc, to their DEPTHS - the crossing
+ * point also moves with z_a and z_b - through SmilRasterSettings.clip_depth (a sparse list; dropped when NULL).  [1] touched 8x8 tiles.  [2] faces that cross the plane beyond the capacity of the per-image clip tables - 1024 cut faces per
  * image, each with up to two front-part triangles and two new vertices: rendered whole, or not at all when a vertex is nearer than 1e-8 - the one case in which a call still deviates.
  * [3] reserved. */
 int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream, uint32_t *out4);

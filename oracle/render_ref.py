@@ -93,9 +93,9 @@ def clip_faces_np(verts: np.ndarray, faces: np.ndarray, z_clip: float):
 
     Returns ``(verts_aug (V + X, 3), faces_aug (F + E, 3), src (X, 2) int, coef (X, 2) float64)``: rows 0..F-1 of ``faces_aug``
     keep the face ids (a clipped face becomes a zero-area placeholder), the front parts follow at F...; every new vertex j is
-    ``coef[j,0] xy[src[j,0]] + coef[j,1] xy[src[j,1]]``.  Gradients: the rasteriser's xy gradient of a new vertex goes back
-    to its two source vertices with those coefficients HELD CONSTANT (pytorch3d differentiates through them as well, which
-    also yields gradients on the source depths; not restated - the HIP path implements the same constant-coefficient rule)."""
+    ``coef[j,0] xy[src[j,0]] + coef[j,1] xy[src[j,1]]``.  Gradients (``silhouette_backward_np``): the rasteriser's xy gradient of
+    a new vertex goes back to its two source vertices - to their xy with those coefficients, and, since round 5, to their DEPTHS
+    through ``w_b`` and the explicit ``z_a``, ``z_b`` factors, as pytorch3d's autograd does (``clip_depth_gradient``)."""
     v = np.asarray(verts, np.float64)
     f = np.asarray(faces, np.int64)
     behind = v[:, 2][f] < z_clip                      # (F, 3)
@@ -127,6 +127,19 @@ def clip_faces_np(verts: np.ndarray, faces: np.ndarray, z_clip: float):
     verts_aug = np.concatenate([v, np.asarray(new_v)]).astype(np.float32)
     faces_aug = np.concatenate([f_aug, np.asarray(new_f, np.int64)]).astype(np.int32)
     return verts_aug, faces_aug, np.asarray(src, np.int64), np.asarray(coef, np.float64)
+
+
+def clip_depth_gradient(va, vb, g_xy, z_clip):
+    """d (new vertex xy) / d (z_a, z_b) contracted with the new vertex's xy gradient ``g_xy``: with ``w = (z_a - z_c) / (z_a - z_b)``
+    and ``xy = (xy_a z_a (1 - w) + xy_b z_b w) / z_c`` (``clip_faces_np``):
+    ``d xy / d z_a = (xy_a (1 - w) + (xy_b z_b - xy_a z_a) (z_c - z_b) / (z_a - z_b)^2) / z_c`` and
+    ``d xy / d z_b = (xy_b w + (xy_b z_b - xy_a z_a) (z_a - z_c) / (z_a - z_b)^2) / z_c``.  Returns ``(dz_a, dz_b)``."""
+    xa, xb = np.asarray(va[:2], np.float64), np.asarray(vb[:2], np.float64)
+    za, zb, zc = float(va[2]), float(vb[2]), float(z_clip)
+    w = (za - zc) / (za - zb)
+    dwa, dwb = (zc - zb) / (za - zb) ** 2, (za - zc) / (za - zb) ** 2
+    d = xb * zb - xa * za
+    return float(np.dot(g_xy, (xa * (1.0 - w) + d * dwa) / zc)), float(np.dot(g_xy, (xb * w + d * dwb) / zc))
 
 
 def _clip_plan(verts_ndc: np.ndarray, faces: np.ndarray):
@@ -200,9 +213,12 @@ def silhouette_backward_np(verts_ndc, faces, S, grad_sil, blur=BLUR_RADIUS, sigm
                 va, fa, src, coef = p
                 g = silhouette_backward_np(va[None], fa, S, grad_sil[n:n + 1], blur, sigma, K, _clipped=True)[0].astype(np.float64)
                 acc = g[:V0].copy()
-                for j in range(src.shape[0]):  # new vertex -> its two source vertices, coefficients held constant
+                for j in range(src.shape[0]):  # new vertex -> its two source vertices: their xy, and their depths through the coefficients
                     acc[src[j, 0], :2] += coef[j, 0] * g[V0 + j, :2]
                     acc[src[j, 1], :2] += coef[j, 1] * g[V0 + j, :2]
+                    dza, dzb = clip_depth_gradient(va[src[j, 0]], va[src[j, 1]], g[V0 + j, :2], _Z_CLIP)
+                    acc[src[j, 0], 2] += dza
+                    acc[src[j, 1], 2] += dzb
                 out[n] = acc.astype(np.float32)
             return out
     N, V, _ = verts_ndc.shape
@@ -214,7 +230,8 @@ def silhouette_backward_np(verts_ndc, faces, S, grad_sil, blur=BLUR_RADIUS, sigm
 
 
 class SoftSilhouette(torch.autograd.Function):
-    """verts_ndc (N,V,3) -> silhouette (N,S,S), differentiable wrt the xy of verts_ndc."""
+    """verts_ndc (N,V,3) -> silhouette (N,S,S), differentiable wrt the xy of verts_ndc (and wrt the depth of the end points of edges
+    that cross z_clip)."""
 
     @staticmethod
     def forward(ctx, verts_ndc, faces, S, blur, sigma, K):

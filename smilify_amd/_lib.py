@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SMILFIT_LIB") or os.path.join(_HERE, "lib", "libsmilf
 
 EXPORTS = [
     "smil_model_create", "smil_model_destroy", "smil_model_dims", "smil_last_error", "smil_version",
-    "smil_lbs_forward", "smil_lbs_forward_project", "smil_lbs_backward", "smil_lbs_backward_ndc", "smil_lbs_backward_ndc_supported", "smil_project", "smil_project2", "smil_project_backward", "smil_project_backward2",
+    "smil_lbs_forward", "smil_lbs_forward_project", "smil_lbs_backward", "smil_lbs_backward_ndc", "smil_lbs_backward_ndc_supported", "smil_clip_depth_backward", "smil_project", "smil_project2", "smil_project_backward", "smil_project_backward2",
     "smil_fov_reduce", "smil_fit_epilogue",
     "smil_raster_workspace_bytes", "smil_raster_stats", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
@@ -60,7 +60,12 @@ class LbsOutputs(Structure):
 class LbsGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("d_verts", "d_joints", "d_beta", "d_theta", "d_logscale", "d_btrans",
                                         "d_trans", "d_A", "d_Jrest", "d_Rs", "d_vposed", "d_posefeat", "d_del_v", "d_Rs_in")] + [
-        ("accumulate_shared_beta", c_int32), ("up_Rs", c_void_p), ("up_v_shaped", c_void_p), ("beta_rows", c_void_p)]
+        ("accumulate_shared_beta", c_int32), ("up_Rs", c_void_p), ("up_v_shaped", c_void_p), ("clip_depth", c_void_p),
+        ("beta_rows", c_void_p)]
+
+
+class ClipDepth(Structure):
+    _fields_ = [("vertex", c_void_p), ("dz", c_void_p), ("range", c_void_p), ("counter", c_void_p), ("capacity", c_int32)]
 
 
 class Cameras(Structure):
@@ -71,7 +76,7 @@ class Cameras(Structure):
 
 class RasterSettings(Structure):
     _fields_ = [("blur_radius", c_float), ("sigma", c_float), ("faces_per_pixel", c_int32), ("z_clip", c_float),
-                ("tie_rule", c_int32)]
+                ("tie_rule", c_int32), ("clip_depth", c_void_p), ("image0", c_int32)]
 
 
 class FitConfig(Structure):
@@ -107,6 +112,7 @@ def load():
     lib.smil_lbs_backward_ndc.argtypes = [c_void_p, POINTER(LbsInputs), POINTER(LbsOutputs), POINTER(LbsGrads), POINTER(Cameras),
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.smil_lbs_backward_ndc_supported.argtypes = [c_void_p, c_int32, c_int32]
+    lib.smil_clip_depth_backward.argtypes = [POINTER(Cameras), POINTER(ClipDepth), c_int32, c_int32, c_void_p, c_void_p]
     lib.smil_project.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
     lib.smil_project_backward.argtypes = [POINTER(Cameras), c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int32, c_void_p, c_void_p]

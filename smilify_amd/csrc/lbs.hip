@@ -1139,6 +1139,7 @@ struct LbsBwdNdcArgs {
     const float *cval, *sd;
     float *d_A, *d_joints, *d_beta_frame, *d_trans, *d_fov_img;
     BetaSum beta;                               // shared betas: one row per workgroup (summed by the chain kernel's last block)
+    SmilClipDepth cd;                           // depth gradients of cut edges' end points from the rasteriser (range == NULL: none)
     int B, V, J, nS, nB_used, regress, trans_after, bone_slots;
 };
 
@@ -1193,6 +1194,7 @@ __global__ void __launch_bounds__(NT, NDC_BWD_MIN_WAVES) k_lbs_bwd_ndc(LbsBwdNdc
     if (VPL && a.nS == 1)  // one set of rest vertices for every frame: staged once (each thread its own vertices; phase 3 is behind a barrier)
         for (int v = tid; v < V; v += NT) { vpL[3 * v] = a.v_skin[3 * v]; vpL[3 * v + 1] = a.v_skin[3 * v + 1]; vpL[3 * v + 2] = a.v_skin[3 * v + 2]; }
     float beta_acc = 0.f;               // thread k < nB_used: the shared shape gradient summed over this workgroup's frames
+    const bool have_clip = a.cd.range && a.d_ndc && a.cd.counter[0] != 0u;  // (one word: the rasteriser cut a face somewhere in the batch)
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         // ---- phase 0: the frame's transforms, cameras and joint gradient ----
         for (int i = tid; i < 12 * J; i += NT) sA[i] = a.A[(size_t)b * J * 12 + i];
@@ -1274,6 +1276,20 @@ __global__ void __launch_bounds__(NT, NDC_BWD_MIN_WAVES) k_lbs_bwd_ndc(LbsBwdNdc
                 }
             }
         __syncthreads();  // sDJ (and the fov sums) complete
+        if (have_clip) {  // (uniform; never on the BASELINE configurations) depth gradients from the rasteriser's clipping plane
+            for (int view = 0; view < views; ++view) {
+                const size_t n = (size_t)b * views + view;
+                const uint32_t first = a.cd.range[2 * n], cnt = a.cd.range[2 * n + 1];
+                const float *cp = sCam + 16 * view;
+                for (uint32_t e = tid; e < cnt; e += NT) {
+                    const int v = a.cd.vertex[first + e];
+                    const float dz = a.cd.dz[first + e];
+                    if (v < 0 || v >= V || dz == 0.f) continue;
+                    atomicAdd(&dvL[3 * v], dz * cp[2]); atomicAdd(&dvL[3 * v + 1], dz * cp[5]); atomicAdd(&dvL[3 * v + 2], dz * cp[8]);
+                }
+            }
+            __syncthreads();
+        }
         // ---- phase 2: + regressor^T d_joints; translation and shape terms ----
         constexpr int U2 = NBT > 6 ? 1 : NDC_UNR2;  // (nine coefficients x two vertices in flight spilled 30 registers)
         float term[12];
@@ -1538,6 +1554,11 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
         a.colptr = m->jreg_colptr; a.row = m->jreg_row; a.cval = m->jreg_cval; a.sd = m->shapedirs; a.vfirst = m->jreg_vfirst;
         a.d_A = g->d_A; a.d_joints = up->d_joints; a.d_beta_frame = dbeta_frame_all;
         a.d_trans = g->d_trans; a.d_fov_img = up->d_fov_img;
+        a.cd = SmilClipDepth{nullptr, nullptr, nullptr, nullptr, 0};
+        if (g->clip_depth) {
+            SMIL_REQUIRE(g->clip_depth->vertex && g->clip_depth->dz && g->clip_depth->range && g->clip_depth->counter, "smil_lbs_backward_ndc: incomplete SmilClipDepth");
+            a.cd = *g->clip_depth;
+        }
         a.B = B; a.V = V; a.J = J; a.nS = nS_skin; a.nB_used = nBu_all; a.regress = regress; a.bone_slots = m->bone_slots;
         a.trans_after = in->trans_after_joints ? 1 : 0;
         const int form = ndc_bwd_form(m, up->cam->views);

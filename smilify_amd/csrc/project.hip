@@ -168,6 +168,33 @@ extern "C" int smil_project_backward2(const SmilCameras *cam, const float *pts_a
     return SMIL_OK;
 }
 
+// Depth gradients of cut edges' end points (SmilClipDepth, written by the rasteriser's k_clip_backward) carried through the camera into
+// the world-space vertex gradient: z_view = x R[2] + y R[5] + z R[8] + T_z.  One workgroup per image; images without cut faces (all of
+// them on the BASELINE configurations) read two words and leave.  Two views of a frame may touch the same vertex: float atomics.
+__global__ void __launch_bounds__(64) k_clip_depth_bwd(SmilCameras c, SmilClipDepth cd, int V, float *__restrict__ d_verts) {
+    if (cd.counter[0] == 0u) return;  // (nothing was cut anywhere in the batch)
+    const int n = blockIdx.x;
+    const uint32_t first = cd.range[2 * (size_t)n], cnt = cd.range[2 * (size_t)n + 1];
+    if (cnt == 0u) return;
+    const CamParams cp = load_camera(c, n);
+    float *dv = d_verts + (size_t)(n / c.views) * V * 3;
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const int v = cd.vertex[first + e];
+        const float dz = cd.dz[first + e];
+        if (v < 0 || v >= V || dz == 0.f) continue;
+        atomicAdd(dv + 3 * v, dz * cp.R[2]); atomicAdd(dv + 3 * v + 1, dz * cp.R[5]); atomicAdd(dv + 3 * v + 2, dz * cp.R[8]);
+    }
+}
+
+extern "C" int smil_clip_depth_backward(const SmilCameras *cam, const SmilClipDepth *cd, int32_t N, int32_t V, float *d_verts, void *stream) {
+    SMIL_REQUIRE(cam && cd && d_verts, "smil_clip_depth_backward: null argument");
+    SMIL_REQUIRE(cd->vertex && cd->dz && cd->range && cd->counter, "smil_clip_depth_backward: incomplete SmilClipDepth");
+    SMIL_REQUIRE(N > 0 && V > 0 && cam->views > 0 && N == cam->N && N % cam->views == 0, "smil_clip_depth_backward: bad sizes");
+    hipLaunchKernelGGL(k_clip_depth_bwd, dim3(N), dim3(64), 0, (hipStream_t)stream, *cam, *cd, V, d_verts);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
 // d fov_deg[c] = sum_{n = c mod nFov}  -(pi/360) (1 + t^2)/t * d_fov_img[n]      (x_ndc, y_ndc ~ 1/t)
 __global__ void k_fov_reduce(SmilCameras c, const float *__restrict__ d_fov_img, float *__restrict__ d_fov) {
     __shared__ float red[16];

@@ -220,6 +220,8 @@ struct RasterArgs {
     Rec3 *crec;
     int list_stride, n_cf;   // entries of slist / scfirst per workgroup
     unsigned int slots;      // resident workgroup slots of the device (the dealing policy's yardstick; gridDim.x <= slots)
+    SmilClipDepth cd;        // where k_clip_backward leaves the depth gradients of cut edges' end points (range == NULL: nowhere)
+    int image0;              // index of the call's first image in the caller's batch (cd.range)
     int tie_rule;            // SmilRasterSettings.tie_rule (0: K smallest by (depth, face id); 1: the reference's queue, k_raster_tie_replay)
     unsigned long long *tie_mask;  // tie_rule 1: per work item (same index as `items`) the pixels of the tile whose K-th depth is a
                              // tie group that K cuts through: left out by the tile kernel, rendered by k_raster_tie_replay
@@ -302,6 +304,7 @@ struct SetupArgs {
     uint2 *lists;       // (N, list_cap) binned tile lists: {face id, bits of its nearest vertex depth} (8 bytes: the farthest depth only ever fed the
                         // tile's depth range, and farthest <= nearest + the image's largest face extent bounds that as well)
     uint32_t list_cap;  // entries per image (0: no binning)
+    uint32_t *cd_counter;  // SmilClipDepth.counter of a gradient call with image0 == 0: reset here (block 0), or NULL
     int copies;         // (round 5) per-tile counters / list cursors are kept in this many copies (1, 2 or 4: what fits 48 KB of LDS), a
                         // face using copy (face id % copies): consecutive faces hit the same tiles, and LDS atomics of one wave
                         // instruction on ONE address execute one after the other - the two atomic passes were two thirds of this kernel
@@ -332,6 +335,7 @@ __global__ void __launch_bounds__(SETUP_THREADS, 8) k_raster_setup(SetupArgs q) 
         for (int i = threadIdx.x; i < V; i += blockDim.x) z[i] = make_float2(0.f, 0.f);
     }
     if (q.loss_dst && threadIdx.x == 0) { q.loss_dst[n] = q.loss_src[n]; q.loss_acc[n] = 0ull; }
+    if (q.cd_counter && n == 0 && threadIdx.x == 0) { q.cd_counter[0] = 0u; q.cd_counter[1] = 0u; }
     const int n_tiles = tiles_x * tiles_x;
     const bool counted = n_tiles <= COUNT_TILES_MAX;
     uint32_t *const tbits = reinterpret_cast<uint32_t *>(tcnt64);        // (!counted) touched-tile bitmap
@@ -768,15 +772,48 @@ __global__ void __launch_bounds__(256) k_unpack_dndc(float *__restrict__ d_ndc, 
 // coefficients held constant (see ClipTables).  One workgroup per image; images without cut faces leave at once.  Images with
 // cut faces accumulate in plain floats, so these are float atomics on d_ndc (two new vertices may share an end point).
 __global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__restrict__ d_ndc, int V, float *__restrict__ loss_img,
-                                                      const unsigned long long *__restrict__ loss_acc) {
+                                                      const unsigned long long *__restrict__ loss_acc, const float *__restrict__ verts_ndc,
+                                                      float z_clip, SmilClipDepth cd, int image0) {
     const int n = blockIdx.x;
     // (fused entry point: the image's loss = what the setup kernel seeded it with + the tiles' terms, summed as integers)
     if (loss_img && threadIdx.x == 0) loss_img[n] += (float)((double)(long long)loss_acc[n] * (1.0 / 4294967296.0));
     const uint32_t nx = c.xcount[n];
+    // Depth channel (round 5): the crossing point xy = (xy_a z_a (1 - w) + xy_b z_b w) / z_clip, w = (z_a - z_clip) / (z_a - z_b), also
+    // depends on the end points' DEPTHS - pytorch3d's autograd differentiates clip_faces through them.  d_ndc has no depth
+    // component, so these (rare) terms travel as a sparse list: two entries {vertex, d / d z} per new vertex, the image's run
+    // recorded in cd.range; the LBS backward / smil_clip_depth_backward carry them through the camera.
+    __shared__ uint32_t s_first;
+    if (cd.range) {
+        if (threadIdx.x == 0) {
+            uint32_t first = 0u, cnt = 0u;
+            if (nx) {
+                first = atomicAdd(&cd.counter[0], 2u * nx);
+                if (first + 2u * nx <= (uint32_t)cd.capacity) cnt = 2u * nx;
+                else atomicAdd(&cd.counter[1], 2u * nx);  // (does not fit: dropped, counted; the run stays reserved but unused)
+            }
+            cd.range[2 * (size_t)(image0 + n)] = first;
+            cd.range[2 * (size_t)(image0 + n) + 1] = cnt;
+            s_first = cnt ? first : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+    }
+    const uint32_t zfirst = cd.range ? s_first : 0xFFFFFFFFu;
+    const float *vn = verts_ndc + (size_t)n * V * 3;
     for (uint32_t j = threadIdx.x; j < nx; j += blockDim.x) {
         const float gx = c.xg[((size_t)n * CLIP_VX + j) * 2], gy = c.xg[((size_t)n * CLIP_VX + j) * 2 + 1];
-        if (gx == 0.f && gy == 0.f) continue;
         const int2 ab = c.xsrc[(size_t)n * CLIP_VX + j];
+        if (zfirst != 0xFFFFFFFFu) {
+            const float xa = vn[3 * ab.x], ya = vn[3 * ab.x + 1], za = vn[3 * ab.x + 2];
+            const float xb = vn[3 * ab.y], yb = vn[3 * ab.y + 1], zb = vn[3 * ab.y + 2];
+            const float inv = 1.0f / (za - zb), w = (za - z_clip) * inv;
+            const float dwa = (z_clip - zb) * inv * inv, dwb = (za - z_clip) * inv * inv;
+            const float dx = xb * zb - xa * za, dy = yb * zb - ya * za, rz = 1.0f / z_clip;
+            cd.vertex[zfirst + 2u * j] = ab.x;
+            cd.dz[zfirst + 2u * j] = (gx * (xa * (1.0f - w) + dx * dwa) + gy * (ya * (1.0f - w) + dy * dwa)) * rz;
+            cd.vertex[zfirst + 2u * j + 1u] = ab.y;
+            cd.dz[zfirst + 2u * j + 1u] = (gx * (xb * w + dx * dwb) + gy * (yb * w + dy * dwb)) * rz;
+        }
+        if (gx == 0.f && gy == 0.f) continue;
         const float2 co = c.xcoef[(size_t)n * CLIP_VX + j];
         float *da = d_ndc + ((size_t)n * V + ab.x) * 2, *db = d_ndc + ((size_t)n * V + ab.y) * 2;
         atomicAdd(da, co.x * gx); atomicAdd(da + 1, co.x * gy);
@@ -2248,7 +2285,7 @@ extern "C" int smil_raster_stats(const SmilModel *m, int32_t N, const void *work
 static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int S, const SmilRasterSettings *rs,
                          void *workspace, hipStream_t stream, RasterArgs &a, float *d_ndc_zero = nullptr,
                          const float *loss_src = nullptr, float *loss_dst = nullptr, float *dndc_scale = nullptr,
-                         const float *pix_scale = nullptr, int packed = 0) {
+                         const float *pix_scale = nullptr, int packed = 0, bool grads = false) {
     SMIL_REQUIRE(m && verts_ndc && rs && workspace, "raster: null argument");
     SMIL_REQUIRE(N > 0 && S > 0 && S <= TILE * 256, "raster: bad sizes N=%d S=%d", N, S);
     SMIL_REQUIRE(rs->faces_per_pixel > 0 && rs->faces_per_pixel <= SMIL_MAX_FACES_PER_PIXEL,
@@ -2301,6 +2338,7 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
         q.d_ndc_zero = d_ndc_zero; q.loss_src = loss_src; q.loss_dst = loss_dst; q.loss_acc = loss_acc; q.img_bound = img_bound; q.max_valence = m->max_valence;
         q.dndc_scale = dndc_scale; q.pix_scale = pix_scale; q.inv_sigma = 1.0f / rs->sigma; q.packed = packed;
         q.lists = lists; q.list_cap = list_cap; q.clip = clip;
+        q.cd_counter = (grads && rs->clip_depth && rs->image0 == 0) ? rs->clip_depth->counter : nullptr;
         // per tile and copy: 8 bytes of counts + 4 bytes of list cursor (as many copies as fit 48 KB: two workgroups per CU), or one bit
         q.copies = n_tiles * 2 * 12 <= 48 * 1024 ? 2 : 1;  // (measured: two copies -10 % STICK / -17 % mouse at 256^2, four copies -5 % / -6 %)
 #ifdef SETUP_COPIES
@@ -2331,6 +2369,13 @@ static int raster_common(const SmilModel *m, const float *verts_ndc, int N, int 
     }
     a.lists = lists; a.list_cap = list_cap; a.clip = clip; a.FT = FT; a.slots = (unsigned int)tile_slots();
     a.tie_rule = rs->tie_rule; a.tie_mask = tie_mask; a.loss_acc = loss_acc;
+    a.cd = SmilClipDepth{nullptr, nullptr, nullptr, nullptr, 0};
+    a.image0 = rs->image0;
+    if (grads && rs->clip_depth) {
+        SMIL_REQUIRE(rs->clip_depth->vertex && rs->clip_depth->dz && rs->clip_depth->range && rs->clip_depth->counter && rs->clip_depth->capacity >= 0 &&
+                     rs->image0 >= 0, "raster: incomplete SmilClipDepth");
+        a.cd = *rs->clip_depth;
+    }
     a.verts_ndc = verts_ndc; a.faces = m->faces; a.tbox = tbox; a.gbox = gbox; a.items = items; a.item_cap = item_cap; a.fzr = fzr; a.ctr = ctr; a.img_bound = img_bound; a.packed = 0;
     a.N = N; a.V = m->V; a.F = m->F; a.S = S; a.tiles_x = tiles_x; a.K = rs->faces_per_pixel;
     a.blur = rs->blur_radius; a.sqrt_blur = sqrt_blur; a.inv_sigma = 1.0f / rs->sigma; a.inv_sigma_log2e = (float)(1.4426950408889634 / (double)rs->sigma);
@@ -2415,7 +2460,7 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
                                         void *workspace, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     RasterArgs a;
-    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a);
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, true);
     if (rc) return rc;
     SMIL_REQUIRE(grad_sil && d_ndc, "smil_silhouette_backward: null argument");
     SMIL_HIP(hipMemsetAsync(d_ndc, 0, (size_t)N * m->V * 2 * sizeof(float), stream));
@@ -2425,7 +2470,7 @@ extern "C" int smil_silhouette_backward(const SmilModel *m, const float *verts_n
     PROF_END(stream);
     launch_tie_replay<MODE_BWD>(a, stream);
     SMIL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V, (float *)nullptr, (const unsigned long long *)nullptr);  // (new vertices of cut faces -> their edges' end points)
+    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V, (float *)nullptr, (const unsigned long long *)nullptr, verts_ndc, rs->z_clip, a.cd, a.image0);  // (new vertices of cut faces -> their edges' end points)
     SMIL_LAUNCH_CHECK();
     return SMIL_OK;
 }
@@ -2440,7 +2485,7 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     // large launches accumulate the vertex gradients as packed fixed point (half the memory-side atomics); small ones keep float
     // atomics.  The packed rows are decoded in place afterwards, unless the caller takes them as they are (d_ndc_scale).
     const int packed = (N >= PACKED_MIN_IMAGES && (reinterpret_cast<uintptr_t>(d_ndc) & 7u) == 0u) ? 1 : 0;  // (64-bit atomics need 8-byte alignment)
-    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a, d_ndc, target_sum, loss_img, d_ndc_scale, pix_scale, packed);
+    int rc = raster_common(m, verts_ndc, N, S, rs, workspace, stream, a, d_ndc, target_sum, loss_img, d_ndc_scale, pix_scale, packed, true);
     if (rc) return rc;
     if (sil_out) SMIL_HIP(hipMemsetAsync(sil_out, 0, (size_t)N * S * S * sizeof(float), stream));
     if (target_is_u8) a.target_u8 = (const uint8_t *)target; else a.target = (const float *)target;
@@ -2451,7 +2496,7 @@ extern "C" int smil_silhouette_l1_fused(const SmilModel *m, const float *verts_n
     PROF_END(stream);
     launch_tie_replay<MODE_FUSED>(a, stream);
     SMIL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V, loss_img, (const unsigned long long *)a.loss_acc);  // (new vertices of cut faces -> their edges' end points; the images' loss sums)
+    hipLaunchKernelGGL(k_clip_backward, dim3(N), dim3(64), 0, stream, a.clip, d_ndc, m->V, loss_img, (const unsigned long long *)a.loss_acc, verts_ndc, rs->z_clip, a.cd, a.image0);  // (new vertices of cut faces -> their edges' end points; the images' loss sums)
     SMIL_LAUNCH_CHECK();
     if (a.packed && !d_ndc_scale) {
         hipLaunchKernelGGL(k_unpack_dndc, dim3(N, ceil_div(m->V, 256)), dim3(256), 0, stream, d_ndc, a.img_bound, pix_scale, a.inv_sigma, m->V, a.clip.xcount);

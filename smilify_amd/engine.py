@@ -163,6 +163,52 @@ class CameraSet:
 TIE_RULES = {"depth_face_id": 0, "reference_queue": 1}
 
 
+class ClipDepth:
+    """Caller-owned buffers of the rasteriser's depth-gradient side channel (``SmilClipDepth``): the end points of edges that
+    cross the clipping plane receive a gradient on their DEPTH (pytorch3d differentiates ``clip_faces`` through its
+    interpolation weight), which ``d_ndc (N,V,2)`` cannot hold.  ``silhouette_backward`` / ``silhouette_l1_fused`` fill it
+    (``clip_depth=``), ``lbs_backward(ndc_upstream=dict(..., clip_depth=))`` or ``clip_depth_backward`` consume it."""
+
+    def __init__(self, device, n_images: int, capacity: int = 1 << 18):
+        dev = torch.device(device)
+        self.n_images, self.capacity = int(n_images), int(capacity)
+        self.vertex = torch.zeros(capacity, dtype=torch.int32, device=dev)
+        self.dz = torch.zeros(capacity, dtype=torch.float32, device=dev)
+        self.range = torch.zeros(n_images, 2, dtype=torch.int32, device=dev)
+        self.counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._struct = _lib.ClipDepth(self.vertex.data_ptr(), self.dz.data_ptr(), self.range.data_ptr(), self.counter.data_ptr(), self.capacity)
+
+    def pointer(self):
+        return ctypes.cast(ctypes.pointer(self._struct), ctypes.c_void_p)
+
+    def dense(self, V: int) -> torch.Tensor:
+        """(n_images, V) depth gradients (tests; synchronises)."""
+        out = torch.zeros(self.n_images, V, dtype=torch.float64)
+        rg, vx, dz = self.range.cpu().numpy(), self.vertex.cpu().numpy(), self.dz.cpu().numpy()
+        for n in range(self.n_images):
+            for e in range(int(rg[n, 0]), int(rg[n, 0]) + int(rg[n, 1])):
+                out[n, int(vx[e])] += float(dz[e])
+        return out
+
+
+def _rs_for_slice(rs, clip_depth: Optional["ClipDepth"], image0: int):
+    """A copy of the raster settings that names the depth-gradient sink and the slice's first image."""
+    if clip_depth is None:
+        return rs
+    cp = _lib.RasterSettings()
+    ctypes.pointer(cp)[0] = rs
+    cp.clip_depth, cp.image0 = clip_depth.pointer(), int(image0)
+    return cp
+
+
+def clip_depth_backward(cams: "CameraSet", clip_depth: ClipDepth, d_verts: torch.Tensor) -> None:
+    """``d_verts`` (frames,V,3) += the depth gradients of ``clip_depth`` carried through the cameras (separate-kernel route)."""
+    N = d_verts.shape[0] * cams.views
+    c = cams.struct(N)
+    _lib.check(_lib.load().smil_clip_depth_backward(ctypes.byref(c), ctypes.byref(clip_depth._struct), N, d_verts.shape[1], _ptr(d_verts),
+                                                    _stream()), "smil_clip_depth_backward")
+
+
 def raster_settings(blur=BLUR_RADIUS, sigma=SIGMA, K=FACES_PER_PIXEL, tie_rule="depth_face_id") -> _lib.RasterSettings:
     """``tie_rule``: which faces a truncated pixel keeps among equal depths at its K-th place - ``"depth_face_id"`` (default: the
     smallest face ids, order independent) or ``"reference_queue"`` (what pytorch3d's unsorted K-queue keeps when it visits the
@@ -303,6 +349,8 @@ def lbs_backward(model: DeviceModel, saved: Dict, d_verts, d_joints, need_beta=T
         up = ndc_upstream
         cams = up["cams"]
         g["d_joints"] = f(B, J, 3)
+        if up.get("clip_depth") is not None:
+            gs.clip_depth = up["clip_depth"].pointer()
         c = cams.struct(B * cams.views)
         _lib.check(_lib.load().smil_lbs_backward_ndc(model.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(gs), ctypes.byref(c),
                                                      _ptr(up.get("d_ndc")), _ptr(up.get("d_ndc_scale")), _ptr(up.get("d_yx")),
@@ -443,7 +491,9 @@ def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=N
     return sil
 
 
-def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, grad_sil: torch.Tensor, rs=None) -> torch.Tensor:
+def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, grad_sil: torch.Tensor, rs=None,
+                        clip_depth: Optional[ClipDepth] = None) -> torch.Tensor:
+    """``clip_depth``: receives the depth gradients of the end points of edges that cross the clipping plane (``ClipDepth``)."""
     rs = rs or raster_settings()
     N = verts_ndc.shape[0]
     d_ndc = torch.empty(N, model.V, 2, dtype=torch.float32, device=verts_ndc.device)
@@ -451,14 +501,14 @@ def silhouette_backward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, gra
     ws = model.workspace(step, S)
     model._claim_workspace(N - ((N - 1) // step) * step)
     for n0, n1 in _slices(N, step):
-        _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs),
+        _lib.check(_lib.load().smil_silhouette_backward(model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(_rs_for_slice(rs, clip_depth, n0)),
                                                         _ptr(grad_sil[n0:n1]), _ptr(d_ndc[n0:n1]), _ptr(ws), _stream()),
                    "smil_silhouette_backward")
     return d_ndc
 
 
 def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pix_scale, rs=None, want_sil=False,
-                        loss_img=None, d_ndc=None, packed_out=False):
+                        loss_img=None, d_ndc=None, packed_out=False, clip_depth: Optional[ClipDepth] = None):
     """Fused soft silhouette + L1 + backward.  Returns (loss_img, d_ndc, sil), or with ``packed_out`` (loss_img, d_ndc, sil,
     d_ndc_scale): ``d_ndc`` as the kernel accumulated it (64-bit packed fixed point for large batches) plus the per-image
     decode factors ``project_backward`` takes - this saves the decode pass over the whole gradient."""
@@ -478,7 +528,7 @@ def silhouette_l1_fused(model: DeviceModel, verts_ndc, S, target, target_sum, pi
         raise _lib.SmilError(f"target silhouettes must be float32 or uint8, got {target.dtype}")
     for n0, n1 in _slices(N, step):
         _lib.check(_lib.load().smil_silhouette_l1_fused(
-            model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(rs), _ptr(target[n0:n1]), int(target.dtype == torch.uint8),
+            model.handle, _ptr(verts_ndc[n0:n1]), n1 - n0, S, ctypes.byref(_rs_for_slice(rs, clip_depth, n0)), _ptr(target[n0:n1]), int(target.dtype == torch.uint8),
             _ptr(target_sum[n0:n1]), _ptr(pix_scale[n0:n1]), _ptr(loss_img[n0:n1]), _ptr(d_ndc[n0:n1]),
             _ptr(None if sil is None else sil[n0:n1]), _ptr(None if scale is None else scale[n0:n1]), _ptr(ws), _stream()),
             "smil_silhouette_l1_fused")

@@ -327,7 +327,7 @@ class SMALFitter(nn.Module):
                                      allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True, theta_mask=mask,
                                      project=dict(cams=cams, ndc=w_reproj > 0, yx=w_j2d > 0) if engine.FUSED_LBS_FORWARD else None)
             both = w_j2d > 0 and w_reproj > 0
-            ndc = yx = d_yx = d_ndc = d_verts = d_joints = None
+            ndc = yx = d_yx = d_ndc = d_verts = d_joints = cd = None
             if engine.FUSED_LBS_FORWARD:  # projected by the skinning kernel (vertices -> NDC, joints -> pixels)
                 ndc, yx = lbs.get("ndc"), lbs.get("yx")
             elif both:  # vertices -> NDC and joints -> pixels in one launch
@@ -348,13 +348,19 @@ class SMALFitter(nn.Module):
                 tsum = self._sil_sum if idx is None else self._sil_sum.index_select(0, img_idx).contiguous()
                 pscale = self._pix_scale(fc, views, S)
                 # (the vertex gradient stays as the tile kernel accumulated it: the projection backward decodes it while it reads)
+                # (the depth gradients of edges cut at the clipping plane travel beside d_ndc; persistent buffers: a captured
+                # iteration replays the same pointers)
+                cd = self.__dict__.get("_clip_depth")
+                if cd is None or cd.n_images != n_img or cd.vertex.device != dev:
+                    cd = self.__dict__["_clip_depth"] = engine.ClipDepth(dev, n_img)
                 loss_img, d_ndc, _, d_ndc_scale = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings,
-                                                                             packed_out=True)
+                                                                             packed_out=True, clip_depth=cd)
             # image-plane gradients -> world space: inside the skinning backward (one kernel per frame, no (B,V,3) vertex
             # gradient in memory) where the library offers it, else by the projection backward first
             ndc_up = None
             if engine.FUSED_LBS_BACKWARD and engine.lbs_backward_ndc_supported(dm, nB if self.betas.requires_grad else 0, views):
-                ndc_up = dict(cams=cams, d_ndc=d_ndc, d_ndc_scale=d_ndc_scale if d_ndc is not None else None, d_yx=d_yx, d_fov_img=d_fov_img)
+                ndc_up = dict(cams=cams, d_ndc=d_ndc, d_ndc_scale=d_ndc_scale if d_ndc is not None else None, d_yx=d_yx, d_fov_img=d_fov_img,
+                              clip_depth=cd if d_ndc is not None else None)
             elif both:
                 d_verts, d_joints = engine.project_backward_verts_and_joints(cams, lbs["verts"], d_ndc, lbs["joints"], d_yx, d_fov_img,
                                                                              d_ndc_scale=d_ndc_scale)
@@ -362,6 +368,8 @@ class SMALFitter(nn.Module):
                 d_joints, _ = engine.project_backward(cams, lbs["joints"], d_yx=d_yx, d_fov_img=d_fov_img)
             else:
                 d_verts, _ = engine.project_backward(cams, lbs["verts"], d_ndc=d_ndc, d_fov_img=d_fov_img, d_ndc_scale=d_ndc_scale)
+            if d_verts is not None and d_ndc is not None and cd is not None:
+                engine.clip_depth_backward(cams, cd, d_verts)
             d_fov_sel = arena[o_fov:o_ls] if (n_fov and cams.fov.numel() == n_fov) else torch.empty(cams.fov.numel(), dtype=torch.float32, device=dev)
             # the shared shape gradient is accumulated straight into d_betas (where the shape prior adds its own); the shared
             # scale tables' gradients land in their slots of the shared block

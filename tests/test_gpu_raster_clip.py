@@ -189,3 +189,72 @@ def test_gradient_of_a_cut_face_by_finite_differences(tables):
             assert abs(fd - grad[v, c]) <= 0.06 * abs(grad[v, c]) + 0.02 * np.abs(grad).max(), (v, c, fd, grad[v, c])
             checked += 1
     assert checked >= 3, (checked, np.abs(grad).max())
+
+def test_depth_gradient_of_cut_edges(tables):
+    """The end points of an edge that crosses z_clip receive a DEPTH gradient (pytorch3d differentiates clip_faces through the
+    interpolation weight; reference settings p3d_renderer.py:36-47).  It travels beside d_ndc as a sparse list (``ClipDepth``): HIP
+    against the oracle's analytic depth gradient and against central finite differences of the rendered silhouette, and the list
+    carried through the cameras by both LBS backward routes (fused kernel / projection backward + ``clip_depth_backward``)."""
+    from smilify_amd import engine as eng
+    from oracle import render_ref
+    from test_gpu_edge_cases import _scene
+
+    t = tables("synthetic")
+    dm = eng.DeviceModel(t, DEV)
+    S, N = 48, 2
+    ndc = _scene(t, N, S, 2.5, 3).clone()
+    ndc[0, [5, 40, 77], 2] = torch.tensor([2e-4, 1e-5, 4e-4])      # image 0: three vertices pulled through the plane; image 1: none
+    gs = torch.from_numpy(np.cos(0.3 * np.arange(N * S * S)).astype(np.float32).reshape(N, S, S))
+    want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy())
+    assert np.abs(want[0, :, 2]).max() > 0 and np.abs(want[1, :, 2]).max() == 0
+    cd = eng.ClipDepth(DEV, N)
+    d_ndc = eng.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), clip_depth=cd).cpu().numpy()
+    dz = cd.dense(t.V).numpy()
+    assert int(cd.counter[1]) == 0 and int(cd.range[1, 1]) == 0 and int(cd.range[0, 1]) > 0
+    sc = np.abs(want[0, :, 2]).max()
+    assert np.abs(dz[0] - want[0, :, 2]).max() <= 2e-3 * sc, (np.abs(dz[0] - want[0, :, 2]).max(), sc)
+    assert np.abs(dz[1]).max() == 0.0
+    scxy = np.abs(want[..., :2]).max()
+    assert np.abs(d_ndc - want[..., :2]).max() <= 2e-3 * scxy
+    # finite differences in the depth of the end points in front of the plane
+    loss = lambda x: float((eng.silhouette_forward(dm, x.to(DEV), S).double().cpu() * gs.double()).sum())  # noqa: E731
+    checked = 0
+    for v in np.argsort(-np.abs(dz[0]))[:6]:
+        if float(ndc[0, v, 2]) < 5e-4:
+            continue
+        eps = 2e-3 * float(ndc[0, v, 2])
+        hi, lo = ndc.clone(), ndc.clone()
+        hi[0, v, 2] += eps
+        lo[0, v, 2] -= eps
+        fd = (loss(hi) - loss(lo)) / (float(hi[0, v, 2]) - float(lo[0, v, 2]))
+        assert abs(fd - dz[0, v]) <= 0.1 * abs(dz[0, v]) + 0.02 * np.abs(dz[0]).max(), (v, fd, dz[0, v])
+        checked += 1
+    assert checked >= 2
+    # the same list through the fused fit path and through the separate kernels: fused l1 entry point, both LBS backward routes
+    f = None
+    from smilify_amd import synthetic
+    f = synthetic.make_problem(t, N, 1, S, DEV, radius=2.5, seed=3, window=N)
+    f._refresh_targets()
+    lbs = eng.lbs_forward(f.device_model, f.betas.detach(), f._pose, trans=f.trans.detach().contiguous(), shared_beta=True, trans_after_joints=True)
+    cam = f.renderer.cameras
+    cams = eng.CameraSet(cam.R.contiguous(), cam.T.contiguous(), f.fov.detach(), None, 1, S)
+    d_fake = torch.zeros(N, t.V, 2, device=DEV)
+    fake = eng.ClipDepth(DEV, N)                                      # two entries for image 1, none for image 0
+    fake.vertex[:2] = torch.tensor([7, 33], dtype=torch.int32)
+    fake.dz[:2] = torch.tensor([0.75, -1.5])
+    fake.range[1] = torch.tensor([0, 2], dtype=torch.int32)
+    fake.counter[0] = 2
+    d_v, _ = eng.project_backward(cams, lbs["verts"], d_ndc=d_fake)
+    eng.clip_depth_backward(cams, fake, d_v)
+    R = cam.R[0].to(DEV) if cam.R.shape[0] == 1 else cam.R[1].to(DEV)
+    expect = torch.zeros(N, t.V, 3, device=DEV)
+    expect[1, 7] = 0.75 * R[:, 2]
+    expect[1, 33] = -1.5 * R[:, 2]
+    assert torch.allclose(d_v, expect, atol=1e-6), (d_v - expect).abs().max()
+    if eng.lbs_backward_ndc_supported(f.device_model, t.nB, 1):
+        g_sep = eng.lbs_backward(f.device_model, lbs, d_v, None, need_beta=True)
+        g_fus = eng.lbs_backward(f.device_model, lbs, None, None, need_beta=True,
+                                 ndc_upstream=dict(cams=cams, d_ndc=d_fake, d_ndc_scale=None, d_yx=None, d_fov_img=None, clip_depth=fake))
+        for k in ("d_theta", "d_trans", "d_beta"):
+            a_, b_ = g_sep[k].cpu().numpy(), g_fus[k].cpu().numpy()
+            assert np.abs(a_ - b_).max() <= 1e-5 * (np.abs(a_).max() + 1e-12), (k, np.abs(a_ - b_).max(), np.abs(a_).max())

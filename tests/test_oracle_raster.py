@@ -162,6 +162,31 @@ def test_backward_matches_finite_differences():
     assert worst < 0.05, worst
 
 
+def test_depth_gradient_of_cut_edges_matches_finite_differences():
+    """pytorch3d differentiates ``clip_faces`` through its interpolation weight ``w = (z_a - z_clip) / (z_a - z_b)`` and the explicit
+    depth factors of the perspective-correct crossing (renderer/mesh/clip.py; left on by p3d_renderer.py:36-47): the end points of an
+    edge that crosses the plane receive a DEPTH gradient.  The oracle's analytic one (``clip_depth_gradient``) against central
+    differences of its own forward, for an end point in front of the plane and one behind it."""
+    S_ = 40
+    v = np.array([[[-0.55, -0.4, 2.0e-3], [0.6, -0.35, 1.6e-3], [0.05, 0.55, 2.0e-4],      # vertex 2 is nearer than z_clip = 5e-4
+                   [-0.3, 0.2, 1.2e-3], [0.35, 0.25, 3.0e-4], [0.0, -0.6, 0.9e-3]]], np.float32)
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    w = np.cos(0.37 * np.arange(S_ * S_)).reshape(1, S_, S_).astype(np.float32)
+    _, _, src, _ = rr.clip_faces_np(v[0], f, 5e-4)
+    assert len(src) == 4
+    g = rr.silhouette_backward_np(v, f, S_, w)
+    assert np.abs(g[0, :, 2]).max() > 0
+    loss = lambda x: float((rr.silhouette_forward_np(x, f, S_)[0].astype(np.float64) * w).sum())  # noqa: E731
+    assert (np.abs(g[0, :, 2]) > 0).all()  # both faces are cut: all six vertices are end points of a cut edge
+    for vi in range(6):
+        eps = 5e-4 * abs(float(v[0, vi, 2]))
+        vp, vm = v.copy(), v.copy()
+        vp[0, vi, 2] += eps
+        vm[0, vi, 2] -= eps
+        fd = (loss(vp) - loss(vm)) / (float(vp[0, vi, 2]) - float(vm[0, vi, 2]))
+        assert abs(fd - g[0, vi, 2]) <= 0.02 * abs(g[0, vi, 2]), (vi, fd, g[0, vi, 2])
+
+
 def test_default_camera_and_screen_projection():
     R, T = rr.look_at_view_transform(2.7, 0.0, 0.0)
     np.testing.assert_allclose(R[0].numpy(), np.diag([-1.0, 1.0, -1.0]), atol=1e-6)

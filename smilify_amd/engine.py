@@ -172,8 +172,8 @@ class ClipDepth:
     def __init__(self, device, n_images: int, capacity: int = 1 << 18):
         dev = torch.device(device)
         self.n_images, self.capacity = int(n_images), int(capacity)
-        self.vertex = torch.zeros(capacity, dtype=torch.int32, device=dev)
-        self.dz = torch.zeros(capacity, dtype=torch.float32, device=dev)
+        self.vertex = torch.empty(capacity, dtype=torch.int32, device=dev)  # (entries are written before they are read: range / counter say which)
+        self.dz = torch.empty(capacity, dtype=torch.float32, device=dev)
         self.range = torch.zeros(n_images, 2, dtype=torch.int32, device=dev)
         self.counter = torch.zeros(2, dtype=torch.int32, device=dev)
         self._struct = _lib.ClipDepth(self.vertex.data_ptr(), self.dz.data_ptr(), self.range.data_ptr(), self.counter.data_ptr(), self.capacity)
@@ -189,6 +189,14 @@ class ClipDepth:
             for e in range(int(rg[n, 0]), int(rg[n, 0]) + int(rg[n, 1])):
                 out[n, int(vx[e])] += float(dz[e])
         return out
+
+
+def clip_depth_for(model: "DeviceModel", n_images: int) -> ClipDepth:
+    """The model's cached ``ClipDepth`` for calls of ``n_images`` images (one per size: a captured graph keeps its pointers)."""
+    cache = model.__dict__.setdefault("_clip_depth_cache", {})
+    if n_images not in cache:
+        cache[n_images] = ClipDepth(model.device, n_images)
+    return cache[n_images]
 
 
 def _rs_for_slice(rs, clip_depth: Optional["ClipDepth"], image0: int):

@@ -350,9 +350,7 @@ class SMALFitter(nn.Module):
                 # (the vertex gradient stays as the tile kernel accumulated it: the projection backward decodes it while it reads)
                 # (the depth gradients of edges cut at the clipping plane travel beside d_ndc; persistent buffers: a captured
                 # iteration replays the same pointers)
-                cd = self.__dict__.get("_clip_depth")
-                if cd is None or cd.n_images != n_img or cd.vertex.device != dev:
-                    cd = self.__dict__["_clip_depth"] = engine.ClipDepth(dev, n_img)
+                cd = engine.clip_depth_for(dm, n_img)
                 loss_img, d_ndc, _, d_ndc_scale = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings,
                                                                              packed_out=True, clip_depth=cd)
             # image-plane gradients -> world space: inside the skinning backward (one kernel per frame, no (B,V,3) vertex

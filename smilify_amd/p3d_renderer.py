@@ -60,7 +60,7 @@ class _RenderFunction(torch.autograd.Function):
         d_fov_img = torch.zeros(N, dtype=torch.float32, device=p.device)
         d_v = None
         if ndc is not None and g_sil is not None and ctx.needs_input_grad[5]:
-            cd = engine.ClipDepth(v.device, N)  # depth gradients of edges cut at the clipping plane (empty unless the mesh reaches the camera)
+            cd = engine.clip_depth_for(ctx.dm, N)  # depth gradients of edges cut at the clipping plane (empty unless the mesh reaches the camera)
             d_ndc = engine.silhouette_backward(ctx.dm, ndc, ctx.S, g_sil.reshape(N, ctx.S, ctx.S).contiguous().float(), ctx.rs, clip_depth=cd)
             d_v, _ = engine.project_backward(cams, v, d_ndc=d_ndc, d_fov_img=d_fov_img)
             engine.clip_depth_backward(cams, cd, d_v)

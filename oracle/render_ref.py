@@ -130,16 +130,16 @@ def clip_faces_np(verts: np.ndarray, faces: np.ndarray, z_clip: float):
 
 
 def clip_depth_gradient(va, vb, g_xy, z_clip):
-    """d (new vertex xy) / d (z_a, z_b) contracted with the new vertex's xy gradient ``g_xy``: with ``w = (z_a - z_c) / (z_a - z_b)``
-    and ``xy = (xy_a z_a (1 - w) + xy_b z_b w) / z_c`` (``clip_faces_np``):
-    ``d xy / d z_a = (xy_a (1 - w) + (xy_b z_b - xy_a z_a) (z_c - z_b) / (z_a - z_b)^2) / z_c`` and
-    ``d xy / d z_b = (xy_b w + (xy_b z_b - xy_a z_a) (z_a - z_c) / (z_a - z_b)^2) / z_c``.  Returns ``(dz_a, dz_b)``."""
+    """d (new vertex xy) / d (z_a, z_b) contracted with the new vertex's xy gradient ``g_xy``.  ``clip_faces_np`` places the new vertex at
+    ``xy = (xy_a z_a (1 - w) + xy_b z_b w) / z_c`` with ``w = (z_a - z_c) / (z_a - z_b)``; the two weights ``z_a (1 - w) / z_c`` and
+    ``s = z_b w / z_c`` sum to one (the crossing's depth is ``z_c``), so ``xy = xy_a + s (xy_b - xy_a)`` and
+    ``d xy / d z_a = (xy_b - xy_a) z_b (z_c - z_b) / (z_c (z_a - z_b)^2)``, ``d xy / d z_b = (xy_b - xy_a) z_a (z_a - z_c) / (z_c (z_a - z_b)^2)``:
+    a depth only slides the crossing ALONG the edge's line.  (What autograd obtains through the same expressions by the chain rule;
+    checked against finite differences in tests/test_oracle_raster.py.)  Returns ``(dz_a, dz_b)``, float64."""
     xa, xb = np.asarray(va[:2], np.float64), np.asarray(vb[:2], np.float64)
     za, zb, zc = float(va[2]), float(vb[2]), float(z_clip)
-    w = (za - zc) / (za - zb)
-    dwa, dwb = (zc - zb) / (za - zb) ** 2, (za - zc) / (za - zb) ** 2
-    d = xb * zb - xa * za
-    return float(np.dot(g_xy, (xa * (1.0 - w) + d * dwa) / zc)), float(np.dot(g_xy, (xb * w + d * dwb) / zc))
+    ge = float(np.dot(np.asarray(g_xy, np.float64), xb - xa)) / (zc * (za - zb) ** 2)
+    return ge * zb * (zc - zb), ge * za * (za - zc)
 
 
 def _clip_plan(verts_ndc: np.ndarray, faces: np.ndarray):

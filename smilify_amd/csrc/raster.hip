@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__res
     // (fused entry point: the image's loss = what the setup kernel seeded it with + the tiles' terms, summed as integers)
     if (loss_img && threadIdx.x == 0) loss_img[n] += (float)((double)(long long)loss_acc[n] * (1.0 / 4294967296.0));
     const uint32_t nx = c.xcount[n];
-    // Depth channel (round 5): the crossing point xy = (xy_a z_a (1 - w) + xy_b z_b w) / z_clip, w = (z_a - z_clip) / (z_a - z_b), also
+    // Depth channel (round 5): the crossing point xy_new = (xy_a z_a (1 - w) + xy_b z_b w) / z_clip, w = (z_a - z_clip) / (z_a - z_b), also
     // depends on the end points' DEPTHS - pytorch3d's autograd differentiates clip_faces through them.  d_ndc has no depth
     // component, so these (rare) terms travel as a sparse list: two entries {vertex, d / d z} per new vertex, the image's run
     // recorded in cd.range; the LBS backward / smil_clip_depth_backward carry them through the camera.
@@ -805,13 +805,16 @@ __global__ void __launch_bounds__(64) k_clip_backward(ClipTables c, float *__res
         if (zfirst != 0xFFFFFFFFu) {
             const float xa = vn[3 * ab.x], ya = vn[3 * ab.x + 1], za = vn[3 * ab.x + 2];
             const float xb = vn[3 * ab.y], yb = vn[3 * ab.y + 1], zb = vn[3 * ab.y + 2];
-            const float inv = 1.0f / (za - zb), w = (za - z_clip) * inv;
-            const float dwa = (z_clip - zb) * inv * inv, dwb = (za - z_clip) * inv * inv;
-            const float dx = xb * zb - xa * za, dy = yb * zb - ya * za, rz = 1.0f / z_clip;
+            // xy_new = xy_a (1 - s) + xy_b s with s = z_b w / z_clip (the two weights sum to one: the crossing's depth is z_clip), so both
+            // derivatives point along the edge: d xy_new / d z_a = (xy_b - xy_a) z_b (z_clip - z_b) / (z_clip (z_a - z_b)^2) and
+            // d xy_new / d z_b = (xy_b - xy_a) z_a (z_a - z_clip) / (z_clip (z_a - z_b)^2).  Expanding them from the w form instead
+            // cancels two terms of size |xy| |z| / z_clip against each other in fp32 (profiles/r5_fuzz.md).
+            const float inv = 1.0f / (za - zb);
+            const float ge = fmaf(gx, xb - xa, gy * (yb - ya)) * (inv * inv) * (1.0f / z_clip);
             cd.vertex[zfirst + 2u * j] = ab.x;
-            cd.dz[zfirst + 2u * j] = (gx * (xa * (1.0f - w) + dx * dwa) + gy * (ya * (1.0f - w) + dy * dwa)) * rz;
+            cd.dz[zfirst + 2u * j] = ge * (zb * (z_clip - zb));
             cd.vertex[zfirst + 2u * j + 1u] = ab.y;
-            cd.dz[zfirst + 2u * j + 1u] = (gx * (xb * w + dx * dwb) + gy * (yb * w + dy * dwb)) * rz;
+            cd.dz[zfirst + 2u * j + 1u] = ge * (za * (za - z_clip));
         }
         if (gx == 0.f && gy == 0.f) continue;
         const float2 co = c.xcoef[(size_t)n * CLIP_VX + j];

@@ -680,6 +680,13 @@ class SMALFitter(nn.Module):
             return 0
         st = engine.raster_stats(self.device_model, self.num_images * self.views)
         n, lost = int(st["straddling_faces"]), int(st["unclipped_faces"])
+        dropped = sum(int(cd.counter[1]) for cd in self.device_model.__dict__.get("_clip_depth_cache", {}).values())
+        if dropped:  # (more cut edges in one call than ClipDepth.capacity entries: their depth gradients were left out, never silently)
+            import warnings
+
+            warnings.warn(f"{dropped} depth-gradient entries of cut edges did not fit engine.ClipDepth (capacity "
+                          f"{next(iter(self.device_model._clip_depth_cache.values())).capacity}) in the last call and were dropped.",
+                          RuntimeWarning, stacklevel=2)
         if n and not self.__dict__.get("_warned_straddling"):
             import warnings
 

@@ -2,28 +2,17 @@
    python tools/dbg/fp64_check.py <seed> clip <fuzz_one log with the kernel's values>
 Builds a float64 copy of oracle/raster_oracle.c under /tmp (same source, `float` -> `double`), renders the fuzz scene of
 tools/dbg/fuzz_one.py with both, and compares them at the pixels the log lists."""
-import ctypes, os, re, subprocess, sys
+import os, re, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from smilify_amd import model_io
 from oracle import render_ref, lbs_ref, fitter_ref
 from conftest import oracle_model
 
 seed = int(sys.argv[1]); CLIP = sys.argv[2] == "clip"; log = sys.argv[3]
-src = open(os.path.join(REPO, "oracle", "raster_oracle.c")).read()
-src = re.sub(r"\bfloat\b", "double", src)
-for fn in ("fmaxf", "fminf", "fabsf", "expf", "sqrtf", "floorf", "ceilf"):
-    src = re.sub(r"\b" + fn + r"\b", fn[:-1], src)
-src = re.sub(r"(\d)f\b", r"\1", src)  # 1e-8f -> 1e-8
-os.makedirs("/tmp/fp64", exist_ok=True)
-open("/tmp/fp64/raster_oracle64.c", "w").write(src)
-subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", "/tmp/fp64/lib64.so", "/tmp/fp64/raster_oracle64.c", "-lm"])
-lib = ctypes.CDLL("/tmp/fp64/lib64.so")
-dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int32)
-lib.oracle_silhouette_forward.argtypes = [dp, ip] + [ctypes.c_int] * 4 + [ctypes.c_double] * 2 + [ctypes.c_int, dp, ip, ip, dp, dp]
-lib.oracle_set_z_clip.argtypes = [ctypes.c_double]
-lib.oracle_set_select_mode(1)
+import fp64_oracle
+lib = fp64_oracle.load(); dp, ip = fp64_oracle.DP, fp64_oracle.IP
 
 rng = np.random.default_rng(seed)
 key = ["synthetic", "stick", "mouse"][int(rng.integers(0, 3))]

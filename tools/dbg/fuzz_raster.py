@@ -1,10 +1,11 @@
 import os, sys
 import numpy as np, torch
 REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from smilify_amd import engine, model_io
 from oracle import render_ref, lbs_ref, fitter_ref
 from conftest import oracle_model
+import fp64_oracle
 DEV = "cuda:0"
 models = {"synthetic": model_io.synthetic_model(),
           "stick": model_io.load_model(os.path.join(REPO, "data/models/SMILy_STICK.npz")),
@@ -41,14 +42,47 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     gs = torch.from_numpy(rng.standard_normal((N, S, S)).astype(np.float32))
     with render_ref.select_mode(MODE):
         want = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy(), K=K)[..., :2]
-    gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), engine.raster_settings(K=K, tie_rule=RULE)).cpu().numpy()
+    cd = engine.ClipDepth(DEV, N) if CLIP else None  # (the depth gradients of cut edges' end points, beside d_ndc)
+    gotg = engine.silhouette_backward(dm, ndc.to(DEV), S, gs.to(DEV), engine.raster_settings(K=K, tie_rule=RULE), clip_depth=cd).cpu().numpy()
     nrm = np.linalg.norm(want)
     cos = (gotg * want).sum() / (np.linalg.norm(gotg) * nrm + 1e-30) if nrm > 0 else 1.0
     ok = ok and (cos > (0.97 if CLIP else 0.99) or nrm < 1e-6) and np.isfinite(gotg).all()
     st = engine.raster_stats(dm, N)
+    zk = zo = 0.0
+    if CLIP and st['unclipped_faces'] == 0:
+        # The depth gradient of a cut edge's end points is J . g_xy(new vertex), J = d(crossing point)/d(depth), and the crossing point
+        # slides ALONG the edge's line when a depth changes.  With the crossing far outside the image (the usual fuzz scene, |xy| ~ 1e3)
+        # the only edge of the cut face that crosses the image IS that line, every pixel's contribution to g_xy is perpendicular to
+        # it, and the product is a rounding residual |J| |g| ~ 1e6 times larger than itself: the fp32 oracle's own value changes
+        # by its full size when the vertices move by one ulp (profiles/r5_fuzz.md).  So both are measured against the same pass in
+        # float64 (fp64_oracle.py), on the scale the depth gradient acts on - the view-space gradient the vertices receive through
+        # xy, |d_ndc| / z - and the yardstick is the fp32 oracle's own distance from float64, the largest of three samples: the scene
+        # itself and two copies with every xy one ulp up or down.  The kernel may be 4x as far, or 2e-3 of that scale.
+        # (Well-conditioned cuts are compared directly: tests/test_gpu_raster_clip.py.)
+        with render_ref.select_mode(MODE):
+            wfull = render_ref.silhouette_backward_np(ndc.numpy(), t.faces, S, gs.numpy(), K=K).astype(np.float64)
+        gz = cd.dense(t.V).numpy()
+        for n in range(N):
+            nd = ndc[n].numpy()
+            if not bool((nd[:, 2] < render_ref._Z_CLIP).any()):
+                ok = ok and bool((gz[n] == 0).all())
+                continue
+            z64 = fp64_oracle.depth_gradient(render_ref, nd, t.faces, S, K, gs[n].numpy(), select_mode=MODE)
+            scale = float((np.linalg.norm(wfull[n, :, :2], axis=-1) / np.maximum(np.abs(nd[:, 2]), 5e-4)).max()) + 1e-300
+            zk = max(zk, float(np.abs(gz[n] - z64).max() / scale)); zo = max(zo, float(np.abs(wfull[n, :, 2] - z64).max() / scale))
+            ok = ok and bool((gz[n][(z64 == 0) & (wfull[n, :, 2] == 0)] == 0).all())  # (vertices off every cut edge receive nothing)
+            for k in range(2):
+                up = np.random.default_rng(seed * 4 + k).integers(0, 2, size=(t.V, 2)).astype(bool)
+                nd2 = nd.copy()
+                nd2[:, :2] = np.where(up, np.nextafter(nd[:, :2], np.float32(np.inf)), np.nextafter(nd[:, :2], np.float32(-np.inf)))
+                with render_ref.select_mode(MODE):
+                    w2 = render_ref.silhouette_backward_np(nd2[None], t.faces, S, gs[n:n + 1].numpy(), K=K)[0, :, 2].astype(np.float64)
+                z2 = fp64_oracle.depth_gradient(render_ref, nd2, t.faces, S, K, gs[n].numpy(), select_mode=MODE)
+                zo = max(zo, float(np.abs(w2 - z2).max() / scale))
+        ok = ok and zk <= max(4.0 * zo, 2e-3) and np.isfinite(gz).all() and int(cd.counter[1]) == 0
     over = st['unclipped_faces'] > 0  # more than 256 cut faces in an image: the ones beyond the clip tables are rendered whole (documented
     ok = ok or over                   # capacity, counted by smil_raster_stats) - the oracle cuts them all, so the scene cannot agree
     print(f"cut={st['straddling_faces']:4d} lost={st['unclipped_faces']:3d} ", end="")
-    print(f"seed {seed:3d} {key:9s} N={N} S={S:3d} K={K:3d} dist={dist:6.2f} maxcand={ncand.max():5d} mean|d|={d1.mean():.2e} frac>1e-4={np.mean(d1>1e-4):.1e} cos={cos:.5f} {('ok (over clip capacity)' if over else 'ok') if ok else 'FAIL'}", flush=True)
+    print(f"seed {seed:3d} {key:9s} N={N} S={S:3d} K={K:3d} dist={dist:6.2f} maxcand={ncand.max():5d} mean|d|={d1.mean():.2e} frac>1e-4={np.mean(d1>1e-4):.1e} cos={cos:.5f} dz: kernel {zk:.1e} oracle {zo:.1e} {('ok (over clip capacity)' if over else 'ok') if ok else 'FAIL'}", flush=True)
     bad += (not ok)
 print("failures", bad)

@@ -239,6 +239,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-gpu rehearses the multi-rank path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only; never for reported numbers)")
+    ap.add_argument("--tie-rule", default="depth_face_id", choices=["depth_face_id", "reference_queue"],
+                    help="which faces a truncated pixel keeps among equal depths at its K-th place (DESIGN.md section 4.2, item 1); the "
+                         "reported headline uses the default")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the short runs of the other BASELINE configurations behind the headline region (default workload, one GPU)")
     args = ap.parse_args()
@@ -283,6 +286,8 @@ def main():
     # sequence from the same seed and keep their own slice
     fitter = synthetic.make_problem(tables, frames, views, S, dev, radius=wl["radius"], seed=1234, window=window,
                                     frame0=rank * frames, n_frames_total=world * frames)
+    if args.tie_rule != "depth_face_id":
+        fitter.renderer.raster_settings = engine.raster_settings(tie_rule=args.tie_rule)
     n_cpu = 0
     if rank == 0 and world == 1 and args.cpu_frames != 0:
         n_cpu = min(frames, args.cpu_frames if args.cpu_frames > 0 else max(1, 8 // views))
@@ -377,7 +382,7 @@ def main():
             "data": "synthetic",
             "rehearsal": bool(args.share_gpu or args.backend != "nccl"),
             "config": {"workload": wl["name"] + (f" [--frames {frames}]" if args.frames else ""), "frames_per_gpu": frames, "views": views, "image": S, "window": window,
-                       "weights": synthetic.STAGE1_WEIGHTS, "w_temporal": synthetic.STAGE1_TEMPORAL, "faces_per_pixel": 100,
+                       "weights": synthetic.STAGE1_WEIGHTS, "w_temporal": synthetic.STAGE1_TEMPORAL, "faces_per_pixel": 100, "tie_rule": args.tie_rule,
                        "parallelism": f"frames sharded x{world}, all-reduce of shared-parameter gradients"},
             "final_loss": loss,
             "roofline": {"bound": "hbm", "kernel": "k_raster_dense<FUSED> (soft silhouette fwd + L1 + bwd)",

@@ -255,7 +255,8 @@ size_t smil_raster_workspace_bytes(const SmilModel *m, int32_t N, int32_t S);
  * vertices hand their gradient back to the cut edge's end points: to their xy through d_ndc, to their DEPTHS - the crossing
  * point also moves with z_a and z_b - through SmilRasterSettings.clip_depth (a sparse list; dropped when NULL).  [1] touched 8x8 tiles.  [2] faces that cross the plane beyond the capacity of the per-image clip tables - 1024 cut faces per
  * image, each with up to two front-part triangles and two new vertices: rendered whole, or not at all when a vertex is nearer than 1e-8 - the one case in which a call still deviates.
- * [3] reserved. */
+ * [3] pixels whose tie group at the K-th depth was cut by K and that were therefore replayed through the reference's queue
+ * (tie_rule = SMIL_TIE_REFERENCE_QUEUE only; 0 otherwise). */
 int smil_raster_stats(const SmilModel *m, int32_t N, const void *workspace, void *stream, uint32_t *out4);
 
 /* verts_ndc (N,V,3) -> sil (N,S,S) */

@@ -127,6 +127,8 @@ struct RasterCounters {
     struct { unsigned int next, pad[15]; } deal[N_PARTS];  // one cache line per partition's cursor
     unsigned int straddling;  // faces that cross z_clip in this launch: cut at the plane (smil_raster_stats) ...
     unsigned int unclipped;   // ... except these: beyond the per-image clip tables, rendered whole or dropped
+    unsigned int tie_pixels;  // (tie_rule 1) pixels left to k_raster_tie_replay
+    unsigned int tie_next;    // ... and its ticket counter
 };
 
 // The tile kernel's dealing policy, shared by the kernel and the host: with fewer tiles than workgroup slots every tile is dealt out
@@ -1678,9 +1680,35 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     lds_fence();
                 }
                 if (trunc) zt_bits = pre + kmin;
-                // `need` of the n_eq faces at the threshold are kept: the ones with the smallest face ids
-                const bool split = trunc && need < n_eq && !a.tie_rule;
-                defer = trunc && need < n_eq && a.tie_rule;
+                // `need` of the n_eq faces at the threshold are kept: the ones with the smallest face ids - or, under tie_rule 1, the
+                // ones the reference's queue would keep (k_raster_tie_replay).  Which `need` of them they are matters only if the tied
+                // records differ: a pixel outside two faces that meet in an edge (or a fan that meets in a vertex) - the usual tie -
+                // has the same closest point, depth, distance and end points on all of them, so every choice gives the same
+                // silhouette value and the same vertex gradient.  Such a pixel is cut by face id here (round 5: 237 000 replayed
+                // pixels per cfg2b launch were 3.5 ms of replay); only tie groups whose records differ in distance or side go on.
+                bool same = false;
+#ifndef TIE_NO_EQUIV  // (A/B switch of tools/dbg: every cut tie group replayed)
+                if (a.tie_rule && __ballot(trunc && need < n_eq) != 0ull) {  // (wave-uniform)
+                    lds.psel[lane] = make_uint2((trunc && need < n_eq) ? pre : INV, 0u);
+                    lds.hist[lane] = 0xFFFFFFFFu; lds.hist[WAVE + lane] = 0u;         // min / max of the tied records' log bits
+                    lds.hist[2 * WAVE + lane] = 1u; lds.hist[3 * WAVE + lane] = 0u;   // and / or of their inside flags
+                    lds_fence();
+#pragma unroll
+                    for (int r_ = 0; r_ < SELR; ++r_) {
+                        const uint32_t pxl = rm[r_] & 63u;
+                        if (rk[r_] != INV && rk[r_] == lds.psel[pxl].x) {
+                            const uint32_t lb = __float_as_uint(rl[r_]), ins = (rm[r_] >> 22) & 1u;
+                            atomicMin(&lds.hist[pxl], lb); atomicMax(&lds.hist[WAVE + pxl], lb);
+                            atomicAnd(&lds.hist[2 * WAVE + pxl], ins); atomicOr(&lds.hist[3 * WAVE + pxl], ins);
+                        }
+                    }
+                    lds_fence();
+                    same = lds.hist[lane] == lds.hist[WAVE + lane] && lds.hist[2 * WAVE + lane] == lds.hist[3 * WAVE + lane];
+                    lds_fence();
+                }
+#endif
+                const bool split = trunc && need < n_eq && (!a.tie_rule || same);
+                defer = trunc && need < n_eq && a.tie_rule && !same;
                 uint32_t rf[SELR];  // face ids of the records at the threshold of a split pixel (fetched only in tiles that have one)
 #pragma unroll
                 for (int r_ = 0; r_ < SELR; ++r_) rf[r_] = INV;
@@ -1982,7 +2010,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             TSUB(7)
             p_lo += span;
         }
-        if (tie_acc != 0ull && lane == 0) atomicOr(&a.tie_mask[(size_t)part * 2u * a.item_cap + item_at], tie_acc);  // (pieces of one tile add their bits)
+        if (tie_acc != 0ull && lane == 0) {
+            atomicOr(&a.tie_mask[(size_t)part * 2u * a.item_cap + item_at], tie_acc);  // (pieces of one tile add their bits)
+            atomicAdd(&a.ctr->tie_pixels, (unsigned int)__popcll(tie_acc));
+        }
         TUNIT_END
     }
     }  // next partition
@@ -2012,41 +2043,89 @@ __device__ __forceinline__ FaceRows face_rows_from_tri(const Tri9 &tv, float cx,
     q.r6 = make_float4(rl12, 0.f, 0.f, 0.f);
     return q;
 }
+// largest value of the wave (values > 0, or 0 for "none") in DPP: a running maximum along the lanes as wave_scan_add runs its sum
+// (lanes that receive nothing read 0), read from the last lane - no LDS round trips in the replay's serial chain
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, WAVE));
-    return v;
+    int x = (int)v;
+#define MAX_STEP(ctrl, rows) { x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xF, false)); }
+    MAX_STEP(0x111, 0xF) MAX_STEP(0x112, 0xF) MAX_STEP(0x114, 0xF) MAX_STEP(0x118, 0xF)
+    MAX_STEP(0x142, 0xA) MAX_STEP(0x143, 0xC)
+#undef MAX_STEP
+    return (uint32_t)__builtin_amdgcn_readlane(x, WAVE - 1);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
 
+#ifndef TIE_ORD_CAP
+#define TIE_ORD_CAP 2048  // faces of a tile's list that the replay orders in LDS (longer lists, and images whose lists were not binned: group scan)
+#endif
+static_assert(TIE_ORD_CAP % 64 == 0 && TIE_ORD_CAP / 32 <= WAVE, "the high bits of the ordered ids are cleared by one wave");
 template <int MODE>
 __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
     const int lane = threadIdx.x;
     const int K = a.K;  // <= SMIL_MAX_FACES_PER_PIXEL = 128: two queue slots per lane
     const int n_tiles = a.tiles_x * a.tiles_x;
     const int n_groups = a.FT / WAVE;
+    // The reference visits the faces in INDEX order; the tile's binned list holds them in the order the setup kernel's atomics
+    // handed out.  A bitmap over the face ids (FT bits, dynamic LDS) puts them in order: one LDS atomic per entry, then the set bits
+    // of 64 words at a time, laid out by a prefix sum of their counts.  The ordered ids serve every replayed pixel of the tile.
+    extern __shared__ uint32_t tie_lds[];
+    // LDS (the fewer bytes the more waves a SIMD holds, and this kernel is one long dependent chain per wave): the bitmap and the
+    // filling queue share a region (the bitmap is dead once the ids are laid out); an ordered id is 16 bits + one high bit (FT < 2^17)
+    const int region0 = max(a.FT / 32, 6 * WAVE);  // words
+    uint32_t *const bm = tie_lds;
+    // the queue while it fills (slot = arrival rank: written by all lanes at once), moved to registers when it is full
+    uint32_t *const fz = tie_lds, *const fm = fz + 2 * WAVE;
+    float *const fs = reinterpret_cast<float *>(fm + 2 * WAVE);
+    uint16_t *const ord = reinterpret_cast<uint16_t *>(tie_lds + region0);
+    uint32_t *const ord_hi = tie_lds + region0 + TIE_ORD_CAP / 2;  // bit i: id i >= 65536
+    const int bm_words = a.FT / 32;
     unsigned int total = 0;
     for (int q = 0; q < N_PARTS; ++q)
         for (int c = 0; c < N_CLASSES; ++c) total += a.ctr->n_class[q][c];
-    for (unsigned int idx = blockIdx.x; idx < total; idx += gridDim.x) {  // every work item of the launch, partition by partition
-        unsigned int part = 0, item = idx;
-        for (;; ++part) {
-            unsigned int np = 0;
-            for (int c = 0; c < N_CLASSES; ++c) np += a.ctr->n_class[part][c];
-            if (item < np) break;
-            item -= np;
+    // Work unit = (work item, quarter of its 64 pixels), unit index = quarter x items + item: the replayed pixels cluster in few tiles
+    // (0.8 per touched tile on average, dozens in some), and a pixel costs ~7 000 wave instructions, so the units are dealt out
+    // dynamically - a ticket is 64 units, lane = unit reads its item's mask - and the quarters of one heavy tile go to
+    // different waves.
+    unsigned int pre[N_PARTS + 1];  // items before each partition
+    pre[0] = 0u;
+    for (int q = 0; q < N_PARTS; ++q) pre[q + 1] = pre[q] + a.ctr->n_class[q][0] + a.ctr->n_class[q][1] + a.ctr->n_class[q][2] + a.ctr->n_class[q][3];
+    const unsigned int n_units = total * 4u, n_tickets = (n_units + (unsigned int)WAVE - 1u) / (unsigned int)WAVE;
+    for (;;) {
+        unsigned int ticket = 0u;
+        if (lane == 0) ticket = atomicAdd(&a.ctr->tie_next, 1u);
+        ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (ticket >= n_tickets) break;  // (every wave ends here: the counter only grows)
+        // (a ticket's 64 units lie n_tickets apart: the items are sorted by cost class, and 64 neighbours of the heaviest class in one
+        // ticket would be a tail of their own)
+        const unsigned int u = (unsigned int)lane * n_tickets + ticket;
+        unsigned long long my_mask = 0ull;
+        uint32_t my_slot = 0u;
+        if (u < n_units) {
+            const unsigned int quarter = u / total, idx = u - quarter * total;
+            int part = 0;
+#pragma unroll
+            for (int q = 1; q < N_PARTS; ++q) part += idx >= pre[q] ? 1 : 0;
+            const unsigned int item = idx - pre[part];
+            const unsigned int nc0 = a.ctr->n_class[part][0], nc1 = a.ctr->n_class[part][1], nc2 = a.ctr->n_class[part][2];
+            const uint32_t item_at = item < nc0 ? item
+                                   : item < nc0 + nc1 ? a.item_cap - 1u - (item - nc0)
+                                   : item < nc0 + nc1 + nc2 ? a.item_cap + (item - nc0 - nc1)
+                                   : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
+            my_slot = (uint32_t)part * 2u * a.item_cap + item_at;
+            my_mask = a.tie_mask[my_slot] & (0xFFFFull << (16u * quarter));
         }
-        const unsigned int nc0 = a.ctr->n_class[part][0], nc1 = a.ctr->n_class[part][1], nc2 = a.ctr->n_class[part][2];
-        const uint32_t item_at = item < nc0 ? item
-                               : item < nc0 + nc1 ? a.item_cap - 1u - (item - nc0)
-                               : item < nc0 + nc1 + nc2 ? a.item_cap + (item - nc0 - nc1)
-                               : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
-        const size_t slot_i = (size_t)part * 2u * a.item_cap + item_at;
-        unsigned long long mask = a.tie_mask[slot_i];
-        if (mask == 0ull) continue;  // (wave-uniform)
-        const uint32_t code = a.items[slot_i].x;
+        unsigned long long um = __ballot(my_mask != 0ull);
+        while (um) {
+        const int ul = (int)__builtin_ctzll(um);
+        um &= um - 1ull;
+        const size_t slot_i = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_slot, ul);
+        unsigned long long mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_mask, ul) |
+                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_mask >> 32), ul) << 32);
+        const uint4 it = a.items[slot_i];
+        const uint32_t code = it.x;
         const int n = (int)(code / (uint32_t)n_tiles), tile = (int)(code % (uint32_t)n_tiles);
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const float cx = pix_to_ndc(a.S - 1 - (tx * TILE + 4), a.S), cy = pix_to_ndc(a.S - 1 - (ty * TILE + 4), a.S);
@@ -2055,6 +2134,34 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
         const int *const xf_n = a.clip.xf + (size_t)n * CLIP_FX * 3;
         const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.FT;
         const uint32_t *__restrict__ gbox_n = a.gbox + (size_t)n * n_groups;
+        const bool ordered = it.z != 0xFFFFFFFFu && it.z <= (uint32_t)TIE_ORD_CAP;  // (wave-uniform)
+        int n_ord = 0;
+        if (ordered) {
+            __syncthreads();  // (the previous tile's readers of `ord` are done)
+            for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0u;
+            if (lane < TIE_ORD_CAP / 32) ord_hi[lane] = 0u;
+            __syncthreads();
+            const uint2 *const ls = a.lists + (size_t)n * a.list_cap + it.y;
+            for (int i = lane; i < (int)it.z; i += WAVE) {
+                const uint32_t f = ls[i].x;
+                atomicOr(&bm[f >> 5], 1u << (f & 31u));
+            }
+            __syncthreads();
+            for (int w0 = 0; w0 < bm_words; w0 += WAVE) {
+                uint32_t wv = w0 + lane < bm_words ? bm[w0 + lane] : 0u;
+                const int c = __popc(wv), inc = wave_scan_add(c);
+                int o = n_ord + inc - c;
+                while (wv) {
+                    const uint32_t id = (uint32_t)((w0 + lane) * 32 + (__ffs((int)wv) - 1));
+                    ord[o] = (uint16_t)id;
+                    if (id >> 16) atomicOr(&ord_hi[o >> 5], 1u << (o & 31));
+                    ++o;
+                    wv &= wv - 1u;
+                }
+                n_ord += __builtin_amdgcn_readlane(inc, WAVE - 1);
+            }
+            __syncthreads();
+        }
         while (mask) {
             const int p = (int)__builtin_ctzll(mask);
             mask &= mask - 1ull;
@@ -2070,62 +2177,98 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             float qs0 = 0.f, qs1 = 0.f;
             int qsize = 0, qmax_idx = 0;
             uint32_t qmax_z = 0u;  // (depths are positive: their bit patterns order like the values, and 0 is below all of them)
-            for (int g0 = 0; g0 < n_groups; g0 += WAVE) {
-                const int g = g0 + lane;
-                unsigned long long gm = __ballot(g < n_groups && box_has(gbox_n[min(g, n_groups - 1)], tx, ty));
-                while (gm) {  // the groups of 64 consecutive faces that reach the tile, in ascending order
-                    const int gi = g0 + (int)__builtin_ctzll(gm);
-                    gm &= gm - 1ull;
-                    const int f = gi * WAVE + lane;  // (< FT: gi < n_groups)
+            // lane = face: is it a candidate of this pixel, and with what depth / flags / distance
+            auto eval_face = [&](int f, bool &cand, uint32_t &zb, uint32_t &fl, float &sd) {
+                const int i0 = face_vertex(a.faces, xf_n, a.F, f, 0), i1 = face_vertex(a.faces, xf_n, a.F, f, 1), i2 = face_vertex(a.faces, xf_n, a.F, f, 2);
+                const FaceRows fr = face_rows_from_tri(load_tri(a, vn, xv_n, i0, i1, i2), cx, cy);
+                PairEval2 e;
+                eval_pair2(fr, dx_even, dx_odd, dyp, a.blur, e);
+                cand = odd ? e.cand1 : e.cand0;
+                const f32x2 z2 = pair_depth2(fr, e);
+                zb = __float_as_uint(vmax_raw(odd ? z2.y : z2.x, fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w)));
+                sd = odd ? e.sd.y : e.sd.x;
+                fl = ((odd ? e.inside1 : e.inside0) ? 1u << 22 : 0u) | (odd ? e.ebits1 : e.ebits0);
+            };
+            // The candidates of up to 64 faces (lanes in ascending face order) through the reference's queue.  While it FILLS, a
+            // candidate's slot is its arrival rank: all lanes store at once (LDS), and the farthest entry is looked for once, when the
+            // queue is full - the first slot holding the largest depth, which is what the reference's running `>` leaves.  From then on
+            // a candidate enters only if it is strictly nearer than the queue's farthest entry, and that bound only ever falls: the
+            // ones at or beyond it are dropped by one compare for all lanes, the others go in one by one.
+            auto farthest = [&]() {
+                const uint32_t v0 = lane < min(K, WAVE) ? qz0 : 0u, v1 = lane + WAVE < K ? qz1 : 0u;
+                const uint32_t mx = wave_max_u32(max(v0, v1));
+                const unsigned long long b0 = __ballot(v0 == mx);
+                qmax_z = mx;
+                qmax_idx = b0 ? (int)__builtin_ctzll(b0) : WAVE + (int)__builtin_ctzll(__ballot(v1 == mx));
+            };
+            auto load_queue = [&]() {  // LDS -> registers (slot s = lane s % 64, register s / 64)
+                __syncthreads();
+                qz0 = lane < qsize ? fz[lane] : 0u; qm0 = lane < qsize ? fm[lane] : 0u; qs0 = lane < qsize ? fs[lane] : 0.f;
+                qz1 = lane + WAVE < qsize ? fz[lane + WAVE] : 0u; qm1 = lane + WAVE < qsize ? fm[lane + WAVE] : 0u; qs1 = lane + WAVE < qsize ? fs[lane + WAVE] : 0.f;
+                __syncthreads();  // (the next pixel's fill may overwrite the arrays)
+            };
+            auto feed = [&](bool cand, uint32_t zb, uint32_t fl, float sd, int f) {
+                const uint32_t m_lane = fl | (uint32_t)f;
+                if (qsize < K) {  // (wave-uniform) still filling
+                    const unsigned long long cf = __ballot(cand);
+                    const int rank = qsize + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cf, 0u));
+                    if (cand && rank < K) { fz[rank] = zb; fm[rank] = m_lane; fs[rank] = sd; }
+                    const int nc = (int)__popcll(cf);
+                    if (qsize + nc < K) { qsize += nc; return; }
+                    qsize = K;  // full inside this batch: the candidates of rank >= K go on below
+                    load_queue();
+                    farthest();
+                    cand = cand && rank >= K;
+                }
+                unsigned long long cm = __ballot(cand && zb < qmax_z);
+                while (cm) {
+                    const int l = (int)__builtin_ctzll(cm);
+                    cm &= cm - 1ull;
+                    const uint32_t z = (uint32_t)__builtin_amdgcn_readlane((int)zb, l);
+                    if (!(z < qmax_z)) continue;  // (wave-uniform; the bound fell since the compare above)
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)m_lane, l);
+                    const float s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sd), l));
+                    const int put = qmax_idx;
+                    const bool w0 = lane == put, w1 = lane + WAVE == put;  // (straight-line: the loop is one dependent chain, a taken branch costs more than six selects)
+                    qz0 = w0 ? z : qz0; qm0 = w0 ? m : qm0; qs0 = w0 ? s : qs0;
+                    qz1 = w1 ? z : qz1; qm1 = w1 ? m : qm1; qs1 = w1 ? s : qs1;
+                    // the farthest entry was replaced: the new farthest is the first slot holding the largest depth, the replaced
+                    // slot itself when nothing is strictly farther than the newcomer
+                    const uint32_t v0 = lane < min(K, WAVE) ? qz0 : 0u, v1 = lane + WAVE < K ? qz1 : 0u;
+                    const uint32_t mx = wave_max_u32(max(v0, v1));
+                    const unsigned long long b0 = __ballot(v0 == mx), b1 = __ballot(v1 == mx);
+                    const int first = b0 ? (int)__builtin_ctzll(b0) : WAVE + (int)__builtin_ctzll(b1 | (1ull << 63));
+                    qmax_idx = mx > z ? first : put;
+                    qmax_z = mx;  // (>= z: the newcomer is in the queue)
+                }
+            };
+            if (ordered) {
+                for (int b0 = 0; b0 < n_ord; b0 += WAVE) {
+                    const bool have = b0 + lane < n_ord;
+                    const int f = have ? (int)ord[b0 + lane] | (int)(((ord_hi[(b0 + lane) >> 5] >> ((b0 + lane) & 31)) & 1u) << 16) : 0;
                     bool cand = false;
                     uint32_t zb = 0u, fl = 0u;
                     float sd = 0.f;
-                    if (box_has(tbox_n[f], tx, ty)) {
-                        const int i0 = face_vertex(a.faces, xf_n, a.F, f, 0), i1 = face_vertex(a.faces, xf_n, a.F, f, 1), i2 = face_vertex(a.faces, xf_n, a.F, f, 2);
-                        const FaceRows fr = face_rows_from_tri(load_tri(a, vn, xv_n, i0, i1, i2), cx, cy);
-                        PairEval2 e;
-                        eval_pair2(fr, dx_even, dx_odd, dyp, a.blur, e);
-                        cand = odd ? e.cand1 : e.cand0;
-                        const f32x2 z2 = pair_depth2(fr, e);
-                        zb = __float_as_uint(vmax_raw(odd ? z2.y : z2.x, fminf(fminf(fr.r2.y, fr.r2.z), fr.r2.w)));
-                        sd = odd ? e.sd.y : e.sd.x;
-                        fl = ((odd ? e.inside1 : e.inside0) ? 1u << 22 : 0u) | (odd ? e.ebits1 : e.ebits0);
-                    }
-                    unsigned long long cm = __ballot(cand);
-                    while (cm) {  // its candidates, in face order, one by one through the reference's queue
-                        const int l = (int)__builtin_ctzll(cm);
-                        cm &= cm - 1ull;
-                        const uint32_t z = (uint32_t)__builtin_amdgcn_readlane((int)zb, l);
-                        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)fl, l) | (uint32_t)(gi * WAVE + l);
-                        const float s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sd), l));
-                        int put = -1;
-                        if (qsize < K) {
-                            put = qsize;
-                            if (z > qmax_z) { qmax_z = z; qmax_idx = qsize; }
-                            ++qsize;
-                        } else if (z < qmax_z) {
-                            put = qmax_idx;
-                        }
-                        if (put >= 0) {  // (wave-uniform)
-                            if (lane == (put & (WAVE - 1))) {
-                                if (put < WAVE) { qz0 = z; qm0 = m; qs0 = s; } else { qz1 = z; qm1 = m; qs1 = s; }
-                            }
-                            if (qsize == K && put == qmax_idx && z < qmax_z) {
-                                // the farthest entry was replaced: the new farthest is the first slot holding the largest depth,
-                                // the replaced slot itself when nothing is strictly farther than the newcomer
-                                const uint32_t v0 = lane < min(K, WAVE) ? qz0 : 0u, v1 = lane + WAVE < K ? qz1 : 0u;
-                                const uint32_t mx = wave_max_u32(max(v0, v1));
-                                qmax_z = z;
-                                if (mx > z) {
-                                    qmax_z = mx;
-                                    const unsigned long long b0 = __ballot(v0 == mx);
-                                    qmax_idx = b0 ? (int)__builtin_ctzll(b0) : WAVE + (int)__builtin_ctzll(__ballot(v1 == mx));
-                                }
-                            }
-                        }
+                    if (have) eval_face(f, cand, zb, fl, sd);
+                    feed(cand, zb, fl, sd, f);
+                }
+            } else {
+                for (int g0 = 0; g0 < n_groups; g0 += WAVE) {
+                    const int g = g0 + lane;
+                    unsigned long long gm = __ballot(g < n_groups && box_has(gbox_n[min(g, n_groups - 1)], tx, ty));
+                    while (gm) {  // the groups of 64 consecutive faces that reach the tile, in ascending order
+                        const int gi = g0 + (int)__builtin_ctzll(gm);
+                        gm &= gm - 1ull;
+                        const int f = gi * WAVE + lane;  // (< FT: gi < n_groups)
+                        bool cand = false;
+                        uint32_t zb = 0u, fl = 0u;
+                        float sd = 0.f;
+                        if (box_has(tbox_n[f], tx, ty)) eval_face(f, cand, zb, fl, sd);
+                        feed(cand, zb, fl, sd, f);
                     }
                 }
             }
+            if (qsize < K) load_queue();  // (fewer candidates than K: cannot happen for a pixel the tile kernel deferred, handled all the same)
             // ---- blend, loss term, upstream gradient: as the tile kernel's epilogue, for this one pixel ----
             const bool ok0 = lane < qsize, ok1 = lane + WAVE < qsize;
             const float lf0 = ok0 ? __log2f(1.0f - face_prob(qs0, a.inv_sigma_log2e)) : 0.f;
@@ -2191,6 +2334,7 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             entry_grad(ok0, qm0, qs0);
             entry_grad(ok1, qm1, qs1);
         }
+        }  // next unit of the ticket
     }
 }
 
@@ -2281,7 +2425,7 @@ extern "C" int smil_raster_stats(const SmilModel *m, int32_t N, const void *work
     unsigned int tiles = 0;
     for (int q = 0; q < N_PARTS; ++q)
         for (int c = 0; c < N_CLASSES; ++c) tiles += h.n_class[q][c];
-    out4[0] = h.straddling; out4[1] = tiles; out4[2] = h.unclipped; out4[3] = 0;
+    out4[0] = h.straddling; out4[1] = tiles; out4[2] = h.unclipped; out4[3] = h.tie_pixels;
     return SMIL_OK;
 }
 
@@ -2438,7 +2582,11 @@ static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
 // (tie_rule 1) the pixels the tile kernel left out: the reference's queue replayed, one wave per pixel
 template <int MODE>
 static void launch_tie_replay(const RasterArgs &a, hipStream_t stream) {
-    if (a.tie_rule) hipLaunchKernelGGL((k_raster_tie_replay<MODE>), dim3((unsigned int)tile_slots()), dim3(64), 0, stream, a);
+    // dynamic LDS: the face-id bitmap (FT bits) or the filling queue (128 slots x 3 words), + the tile's ordered face ids (17 bits each)
+    const size_t r0 = (size_t)a.FT / 8 > 6 * WAVE * sizeof(uint32_t) ? (size_t)a.FT / 8 : 6 * WAVE * sizeof(uint32_t);
+    const size_t lds = r0 + (size_t)TIE_ORD_CAP * sizeof(uint16_t) + TIE_ORD_CAP / 8;
+    // (76 VGPRs: six waves per SIMD, which the ~6 - 8 KB of LDS allow as well; the waves take tickets until none is left)
+    if (a.tie_rule) hipLaunchKernelGGL((k_raster_tie_replay<MODE>), dim3((unsigned int)device_cus() * 24u), dim3(64), lds, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

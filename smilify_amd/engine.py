@@ -473,17 +473,17 @@ def _slices(N: int, step: int = MAX_IMAGES_PER_LAUNCH):
 
 def raster_stats(model: DeviceModel, N: int) -> dict:
     """Counters of the most recent rasteriser call of ``model`` (of its last slice when the batch was cut into several launches):
-    faces straddling z_clip, touched tiles, faces beyond the clip tables.  ``N`` is ignored (kept for callers of round 3): the slice
+    faces straddling z_clip, touched tiles, faces beyond the clip tables, pixels replayed through the reference's queue (``tie_rule``).  ``N`` is ignored (kept for callers of round 3): the slice
     size is recorded at launch time.  Zeros when the model has not rasterised since the workspace was last used by another model.
     Synchronises."""
-    zero = {"straddling_faces": 0, "tiles": 0, "unclipped_faces": 0}
+    zero = {"straddling_faces": 0, "tiles": 0, "unclipped_faces": 0, "tie_pixels": 0}
     user = _WS_USER.get(model._ws_key())
     last = model.__dict__.get("_last_launch")
     if model._ws is None or last is None or user is None or user[0] is not model:
         return zero  # this model has not rasterised, or another model / topology has used the shared workspace since
     out = (ctypes.c_uint32 * 4)()
     _lib.check(_lib.load().smil_raster_stats(model.handle, last, _ptr(model._ws), _stream(), out), "smil_raster_stats")
-    return {"straddling_faces": int(out[0]), "tiles": int(out[1]), "unclipped_faces": int(out[2])}
+    return {"straddling_faces": int(out[0]), "tiles": int(out[1]), "unclipped_faces": int(out[2]), "tie_pixels": int(out[3])}
 
 
 def silhouette_forward(model: DeviceModel, verts_ndc: torch.Tensor, S: int, rs=None) -> torch.Tensor:

@@ -20,6 +20,7 @@ ap.add_argument("--radius", type=float, default=2.7)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--mode", default="fused", choices=["fused", "fwd"])
 ap.add_argument("--quick", action="store_true", help="timing only (skip the per-tile list statistics)")
+ap.add_argument("--tie-rule", default="depth_face_id", choices=["depth_face_id", "reference_queue"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 tables = model_io.load_model(os.path.join(REPO, "data", "models", args.model + ".npz"))
@@ -33,16 +34,20 @@ ndc, _ = engine.project(cams, lbs["verts"], want_yx=False)
 N = ndc.shape[0]
 cfg = engine.fit_config(args.frames, dm.J, dm.nB, 10, synthetic.STAGE1_WEIGHTS)
 ps = engine.pix_scale(cfg, args.views, args.S, dev)
+rs = engine.raster_settings(tie_rule=args.tie_rule)
 for it in range(args.reps + 1):
     if it == 1:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     if args.mode == "fused":
-        engine.silhouette_l1_fused(dm, ndc, args.S, f._sil_dev, f._sil_sum, ps)
+        engine.silhouette_l1_fused(dm, ndc, args.S, f._sil_dev, f._sil_sum, ps, rs)
     else:
-        engine.silhouette_forward(dm, ndc, args.S)
+        engine.silhouette_forward(dm, ndc, args.S, rs)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.reps
 if args.quick:
+    if args.tie_rule != "depth_face_id":
+        st = engine.raster_stats(dm, N)
+        print(f"tie_rule {args.tie_rule}: {st['tie_pixels']} pixels replayed ({st['tie_pixels'] / N:.1f} per image, {st['tie_pixels'] / max(st['tiles'], 1):.2f} per touched tile)")
     print(f"images {N}  time/launch {dt*1e3:.3f} ms  {dt/N*1e6:.2f} us/image  [SMIL_RESIDENT={os.environ.get('SMIL_RESIDENT')} SMIL_WRAP={os.environ.get('SMIL_WRAP')}]")
     sys.exit(0)
 ws = dm._ws

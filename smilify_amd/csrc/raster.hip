@@ -1684,8 +1684,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 // ones the reference's queue would keep (k_raster_tie_replay).  Which `need` of them they are matters only if the tied
                 // records differ: a pixel outside two faces that meet in an edge (or a fan that meets in a vertex) - the usual tie -
                 // has the same closest point, depth, distance and end points on all of them, so every choice gives the same
-                // silhouette value and the same vertex gradient.  Such a pixel is cut by face id here (round 5: 237 000 replayed
-                // pixels per cfg2b launch were 3.5 ms of replay); only tie groups whose records differ in distance or side go on.
+                // silhouette value and the same vertex gradient.  Such a pixel is cut by face id here (a fifth of the cut tie groups: 237 000 ->
+                // 184 000 replayed pixels per cfg2b launch); only tie groups whose records differ in distance or side go on - mostly fans
+                // around a vertex, whose faces clip the pixel's barycentrics to that vertex (one depth) but are at different distances.
                 bool same = false;
 #ifndef TIE_NO_EQUIV  // (A/B switch of tools/dbg: every cut tie group replayed)
                 if (a.tie_rule && __ballot(trunc && need < n_eq) != 0ull) {  // (wave-uniform)
@@ -2058,6 +2059,24 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+#ifdef DBG_TIE_TIMERS  // (tools/dbg variant only) where a replay wave's cycles go: list order, face evaluation, queue, blend + gradient, ticket
+__device__ unsigned long long g_tie_t[8];
+extern "C" int smil_dbg_tie_timers(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tie_t), sizeof(g_tie_t)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tie_t), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define TT_DECL unsigned long long tt_[8] = {}, tt0_ = __builtin_amdgcn_s_memtime();
+#define TT(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tt_[i] += n_ - tt0_; tt0_ = n_; }
+#define TT_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_tie_t[i_], tt_[i_]);
+#else
+#define TT_DECL
+#define TT(i)
+#define TT_FLUSH
+#endif
+#ifndef TIE_WHOLE_TILE
+#define TIE_WHOLE_TILE 6  // replayed pixels up to which a tile is one work unit (above: four, by quarters of its pixels)
+#endif
 #ifndef TIE_ORD_CAP
 #define TIE_ORD_CAP 2048  // faces of a tile's list that the replay orders in LDS (longer lists, and images whose lists were not binned: group scan)
 #endif
@@ -2093,11 +2112,14 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
     pre[0] = 0u;
     for (int q = 0; q < N_PARTS; ++q) pre[q + 1] = pre[q] + a.ctr->n_class[q][0] + a.ctr->n_class[q][1] + a.ctr->n_class[q][2] + a.ctr->n_class[q][3];
     const unsigned int n_units = total * 4u, n_tickets = (n_units + (unsigned int)WAVE - 1u) / (unsigned int)WAVE;
+    TT_DECL
     for (;;) {
+        TT(5)
         unsigned int ticket = 0u;
         if (lane == 0) ticket = atomicAdd(&a.ctr->tie_next, 1u);
         ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
         if (ticket >= n_tickets) break;  // (every wave ends here: the counter only grows)
+        TT(4)
         // (a ticket's 64 units lie n_tickets apart: the items are sorted by cost class, and 64 neighbours of the heaviest class in one
         // ticket would be a tail of their own)
         const unsigned int u = (unsigned int)lane * n_tickets + ticket;
@@ -2115,9 +2137,12 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                                    : item < nc0 + nc1 + nc2 ? a.item_cap + (item - nc0 - nc1)
                                    : 2u * a.item_cap - 1u - (item - nc0 - nc1 - nc2);
             my_slot = (uint32_t)part * 2u * a.item_cap + item_at;
-            my_mask = a.tie_mask[my_slot] & (0xFFFFull << (16u * quarter));
+            // (a tile with few replayed pixels is one unit - quarter 0 takes them all - so that its face list is put in order once)
+            const unsigned long long full = a.tie_mask[my_slot];
+            my_mask = __popcll(full) <= TIE_WHOLE_TILE ? (quarter == 0u ? full : 0ull) : full & (0xFFFFull << (16u * quarter));
         }
         unsigned long long um = __ballot(my_mask != 0ull);
+        TT(4)
         while (um) {
         const int ul = (int)__builtin_ctzll(um);
         um &= um - 1ull;
@@ -2162,6 +2187,7 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             }
             __syncthreads();
         }
+        TT(0)
         while (mask) {
             const int p = (int)__builtin_ctzll(mask);
             mask &= mask - 1ull;
@@ -2250,7 +2276,9 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                     uint32_t zb = 0u, fl = 0u;
                     float sd = 0.f;
                     if (have) eval_face(f, cand, zb, fl, sd);
+                    TT(1)
                     feed(cand, zb, fl, sd, f);
+                    TT(2)
                 }
             } else {
                 for (int g0 = 0; g0 < n_groups; g0 += WAVE) {
@@ -2333,9 +2361,11 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             };
             entry_grad(ok0, qm0, qs0);
             entry_grad(ok1, qm1, qs1);
+            TT(3)
         }
         }  // next unit of the ticket
     }
+    TT_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -18,6 +18,10 @@ for w in ("cfg2b", "cfg2", "cfg3", "cfg4", "cfg5s"):
     p = os.path.join(src, f"bench_{w}.json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_bench_{w}.json"))
+for w in ("cfg2b", "cfg3"):  # the same workloads under tie_rule = reference_queue (bench.py --tie-rule)
+    p = os.path.join(src, f"bench_tie_{w}.json")
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_bench_tie_{w}.json"))
 for name, out in (("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("latency.txt", f"{tag}_latency.txt")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out))

@@ -1688,8 +1688,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 // 184 000 replayed pixels per cfg2b launch); only tie groups whose records differ in distance or side go on - mostly fans
                 // around a vertex, whose faces clip the pixel's barycentrics to that vertex (one depth) but are at different distances.
                 bool same = false;
-#ifndef TIE_NO_EQUIV  // (A/B switch of tools/dbg: every cut tie group replayed)
-                if (a.tie_rule && __ballot(trunc && need < n_eq) != 0ull) {  // (wave-uniform)
+                if (HOOK_TIE_EQUIV && a.tie_rule && __ballot(trunc && need < n_eq) != 0ull) {  // (wave-uniform)
                     lds.psel[lane] = make_uint2((trunc && need < n_eq) ? pre : INV, 0u);
                     lds.hist[lane] = 0xFFFFFFFFu; lds.hist[WAVE + lane] = 0u;         // min / max of the tied records' log bits
                     lds.hist[2 * WAVE + lane] = 1u; lds.hist[3 * WAVE + lane] = 0u;   // and / or of their inside flags
@@ -1707,7 +1706,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                     same = lds.hist[lane] == lds.hist[WAVE + lane] && lds.hist[2 * WAVE + lane] == lds.hist[3 * WAVE + lane];
                     lds_fence();
                 }
-#endif
                 const bool split = trunc && need < n_eq && (!a.tie_rule || same);
                 defer = trunc && need < n_eq && a.tie_rule && !same;
                 uint32_t rf[SELR];  // face ids of the records at the threshold of a split pixel (fetched only in tiles that have one)
@@ -2059,28 +2057,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-#ifdef DBG_TIE_TIMERS  // (tools/dbg variant only) where a replay wave's cycles go: list order, face evaluation, queue, blend + gradient, ticket
-__device__ unsigned long long g_tie_t[8];
-extern "C" int smil_dbg_tie_timers(unsigned long long *out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tie_t), sizeof(g_tie_t)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tie_t), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#define TT_DECL unsigned long long tt_[8] = {}, tt0_ = __builtin_amdgcn_s_memtime();
-#define TT(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tt_[i] += n_ - tt0_; tt0_ = n_; }
-#define TT_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_tie_t[i_], tt_[i_]);
-#else
-#define TT_DECL
-#define TT(i)
-#define TT_FLUSH
-#endif
 #ifndef TIE_WHOLE_TILE
 #define TIE_WHOLE_TILE 6  // replayed pixels up to which a tile is one work unit (above: four, by quarters of its pixels)
 #endif
 #ifndef TIE_ORD_CAP
 #define TIE_ORD_CAP 2048  // faces of a tile's list that the replay orders in LDS (longer lists, and images whose lists were not binned: group scan)
 #endif
-static_assert(TIE_ORD_CAP % 64 == 0 && TIE_ORD_CAP / 32 <= WAVE, "the high bits of the ordered ids are cleared by one wave");
+static_assert(TIE_ORD_CAP % 64 == 0 && TIE_ORD_CAP / 32 <= WAVE && TIE_ORD_CAP >= 64 * 32, "the high bits of the ordered ids are cleared by one wave; a segment of 64 bitmap words fits");
 template <int MODE>
 __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
     const int lane = threadIdx.x;
@@ -2091,15 +2074,14 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
     // handed out.  A bitmap over the face ids (FT bits, dynamic LDS) puts them in order: one LDS atomic per entry, then the set bits
     // of 64 words at a time, laid out by a prefix sum of their counts.  The ordered ids serve every replayed pixel of the tile.
     extern __shared__ uint32_t tie_lds[];
-    // LDS (the fewer bytes the more waves a SIMD holds, and this kernel is one long dependent chain per wave): the bitmap and the
-    // filling queue share a region (the bitmap is dead once the ids are laid out); an ordered id is 16 bits + one high bit (FT < 2^17)
-    const int region0 = max(a.FT / 32, 6 * WAVE);  // words
+    // LDS (the fewer bytes the more waves a SIMD holds, and this kernel is one long dependent chain per wave): the bitmap (FT bits), the
+    // filling queue (128 slots x 3 words), TIE_ORD_CAP ordered ids of 16 bits + one high bit each (FT < 2^17)
     uint32_t *const bm = tie_lds;
     // the queue while it fills (slot = arrival rank: written by all lanes at once), moved to registers when it is full
-    uint32_t *const fz = tie_lds, *const fm = fz + 2 * WAVE;
+    uint32_t *const fz = tie_lds + a.FT / 32, *const fm = fz + 2 * WAVE;
     float *const fs = reinterpret_cast<float *>(fm + 2 * WAVE);
-    uint16_t *const ord = reinterpret_cast<uint16_t *>(tie_lds + region0);
-    uint32_t *const ord_hi = tie_lds + region0 + TIE_ORD_CAP / 2;  // bit i: id i >= 65536
+    uint16_t *const ord = reinterpret_cast<uint16_t *>(fm + 4 * WAVE);
+    uint32_t *const ord_hi = fm + 4 * WAVE + TIE_ORD_CAP / 2;  // bit i: id i >= 65536
     const int bm_words = a.FT / 32;
     unsigned int total = 0;
     for (int q = 0; q < N_PARTS; ++q)
@@ -2112,14 +2094,14 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
     pre[0] = 0u;
     for (int q = 0; q < N_PARTS; ++q) pre[q + 1] = pre[q] + a.ctr->n_class[q][0] + a.ctr->n_class[q][1] + a.ctr->n_class[q][2] + a.ctr->n_class[q][3];
     const unsigned int n_units = total * 4u, n_tickets = (n_units + (unsigned int)WAVE - 1u) / (unsigned int)WAVE;
-    TT_DECL
+    TIE_TIMERS_INIT
     for (;;) {
-        TT(5)
+        TIE_T(5)
         unsigned int ticket = 0u;
         if (lane == 0) ticket = atomicAdd(&a.ctr->tie_next, 1u);
         ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
         if (ticket >= n_tickets) break;  // (every wave ends here: the counter only grows)
-        TT(4)
+        TIE_T(4)
         // (a ticket's 64 units lie n_tickets apart: the items are sorted by cost class, and 64 neighbours of the heaviest class in one
         // ticket would be a tail of their own)
         const unsigned int u = (unsigned int)lane * n_tickets + ticket;
@@ -2142,7 +2124,7 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             my_mask = __popcll(full) <= TIE_WHOLE_TILE ? (quarter == 0u ? full : 0ull) : full & (0xFFFFull << (16u * quarter));
         }
         unsigned long long um = __ballot(my_mask != 0ull);
-        TT(4)
+        TIE_T(4)
         while (um) {
         const int ul = (int)__builtin_ctzll(um);
         um &= um - 1ull;
@@ -2159,35 +2141,55 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
         const int *const xf_n = a.clip.xf + (size_t)n * CLIP_FX * 3;
         const uint32_t *__restrict__ tbox_n = a.tbox + (size_t)n * a.FT;
         const uint32_t *__restrict__ gbox_n = a.gbox + (size_t)n * n_groups;
-        const bool ordered = it.z != 0xFFFFFFFFu && it.z <= (uint32_t)TIE_ORD_CAP;  // (wave-uniform)
-        int n_ord = 0;
-        if (ordered) {
-            __syncthreads();  // (the previous tile's readers of `ord` are done)
-            for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0u;
-            if (lane < TIE_ORD_CAP / 32) ord_hi[lane] = 0u;
-            __syncthreads();
+        const float2 *__restrict__ fzr_n = a.fzr + (size_t)n * a.FT;
+        // the tile's faces as a bitmap over the face ids: from its binned list, or - images whose lists did not fit - from the
+        // faces' tile boxes
+        __syncthreads();  // (the previous unit's readers of `bm` / `ord` are done)
+        for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0u;
+        __syncthreads();
+        if (it.z != 0xFFFFFFFFu) {  // (wave-uniform)
             const uint2 *const ls = a.lists + (size_t)n * a.list_cap + it.y;
             for (int i = lane; i < (int)it.z; i += WAVE) {
                 const uint32_t f = ls[i].x;
                 atomicOr(&bm[f >> 5], 1u << (f & 31u));
             }
+        } else {
+            for (int g = 0; g < n_groups; ++g)
+                if (box_has(gbox_n[g], tx, ty)) {  // (wave-uniform: the group's box union; lane = face)
+                    const unsigned long long hit = __ballot(box_has(tbox_n[g * WAVE + lane], tx, ty));
+                    if (lane == 0) { bm[2 * g] = (uint32_t)hit; bm[2 * g + 1] = (uint32_t)(hit >> 32); }
+                }
+        }
+        __syncthreads();
+        // set bits of the words [w0, w1) -> ordered ids ord[0 ...): a prefix sum of the words' counts lays them out
+        auto extract = [&](int w0, int w1) -> int {
+            int cnt = 0;
+            if (lane < TIE_ORD_CAP / 32) ord_hi[lane] = 0u;
             __syncthreads();
-            for (int w0 = 0; w0 < bm_words; w0 += WAVE) {
-                uint32_t wv = w0 + lane < bm_words ? bm[w0 + lane] : 0u;
+            for (int wb = w0; wb < w1; wb += WAVE) {
+                uint32_t wv = wb + lane < w1 ? bm[wb + lane] : 0u;
                 const int c = __popc(wv), inc = wave_scan_add(c);
-                int o = n_ord + inc - c;
+                int o = cnt + inc - c;
                 while (wv) {
-                    const uint32_t id = (uint32_t)((w0 + lane) * 32 + (__ffs((int)wv) - 1));
+                    const uint32_t id = (uint32_t)((wb + lane) * 32 + (__ffs((int)wv) - 1));
                     ord[o] = (uint16_t)id;
                     if (id >> 16) atomicOr(&ord_hi[o >> 5], 1u << (o & 31));
                     ++o;
                     wv &= wv - 1u;
                 }
-                n_ord += __builtin_amdgcn_readlane(inc, WAVE - 1);
+                cnt += __builtin_amdgcn_readlane(inc, WAVE - 1);
             }
             __syncthreads();
-        }
-        TT(0)
+            return cnt;
+        };
+        // a list of up to TIE_ORD_CAP faces is put in order once for all the unit's pixels; a longer one 64 words (<= 2 048 faces) at a
+        // time, again for every pixel (the heaviest tiles of the mouse hold more)
+        int n_faces = 0;
+        for (int w = lane; w < bm_words; w += WAVE) n_faces += __popc(bm[w]);
+        n_faces = __builtin_amdgcn_readlane(wave_scan_add(n_faces), WAVE - 1);
+        const bool whole = n_faces <= TIE_ORD_CAP;  // (wave-uniform)
+        const int n_ord = whole ? extract(0, bm_words) : 0;
+        TIE_T(0)
         while (mask) {
             const int p = (int)__builtin_ctzll(mask);
             mask &= mask - 1ull;
@@ -2268,32 +2270,32 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                     qmax_z = mx;  // (>= z: the newcomer is in the queue)
                 }
             };
-            if (ordered) {
-                for (int b0 = 0; b0 < n_ord; b0 += WAVE) {
-                    const bool have = b0 + lane < n_ord;
+            auto walk = [&](int n_ids) {  // the faces ord[0 ... n_ids), 64 at a time
+                for (int b0 = 0; b0 < n_ids; b0 += WAVE) {
+                    const bool have = b0 + lane < n_ids;
                     const int f = have ? (int)ord[b0 + lane] | (int)(((ord_hi[(b0 + lane) >> 5] >> ((b0 + lane) & 31)) & 1u) << 16) : 0;
+                    // Once the queue is full only a depth strictly below its farthest entry gets in, and a face's depth at any pixel
+                    // is at least its nearest vertex's: faces at or beyond the bound are not evaluated (no vertex fetch, no rows), a
+                    // batch of them is skipped whole - in the heaviest tiles (thousands of faces behind the first hundred) most are.
+                    const bool live = have && (qsize < K || __float_as_uint(fzr_n[f].x) < qmax_z);
+                    if (__ballot(live) == 0ull) continue;  // (wave-uniform)
                     bool cand = false;
                     uint32_t zb = 0u, fl = 0u;
                     float sd = 0.f;
-                    if (have) eval_face(f, cand, zb, fl, sd);
-                    TT(1)
+                    if (live) eval_face(f, cand, zb, fl, sd);
+                    TIE_T(1)
                     feed(cand, zb, fl, sd, f);
-                    TT(2)
+                    TIE_T(2)
                 }
+            };
+            if (whole) {
+                walk(n_ord);
             } else {
-                for (int g0 = 0; g0 < n_groups; g0 += WAVE) {
-                    const int g = g0 + lane;
-                    unsigned long long gm = __ballot(g < n_groups && box_has(gbox_n[min(g, n_groups - 1)], tx, ty));
-                    while (gm) {  // the groups of 64 consecutive faces that reach the tile, in ascending order
-                        const int gi = g0 + (int)__builtin_ctzll(gm);
-                        gm &= gm - 1ull;
-                        const int f = gi * WAVE + lane;  // (< FT: gi < n_groups)
-                        bool cand = false;
-                        uint32_t zb = 0u, fl = 0u;
-                        float sd = 0.f;
-                        if (box_has(tbox_n[f], tx, ty)) eval_face(f, cand, zb, fl, sd);
-                        feed(cand, zb, fl, sd, f);
-                    }
+                for (int w0 = 0; w0 < bm_words; w0 += WAVE) {
+                    const int cnt = extract(w0, min(w0 + WAVE, bm_words));
+                    TIE_T(0)
+                    walk(cnt);
+                    __syncthreads();  // (`ord` is rewritten by the next segment)
                 }
             }
             if (qsize < K) load_queue();  // (fewer candidates than K: cannot happen for a pixel the tile kernel deferred, handled all the same)
@@ -2320,6 +2322,7 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                     if (lsum != 0.f) atomicAdd(&a.loss_acc[n], (unsigned long long)(long long)rint((double)lsum * 4294967296.0));
                 }
             }
+            TIE_T(6)
             if (MODE == MODE_FWD || !((g != 0.f) && (alpha > ALPHA_GRAD_EPS) && (plog_px != 0.0))) continue;  // (wave-uniform)
             // ---- gradient of every kept entry, straight to the vertices (no accumulators: at most K entries) ----
             const float coef = -g * alpha * a.inv_sigma;
@@ -2359,13 +2362,12 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                     atomicAdd(rb, bx); atomicAdd(rb + 1, by);
                 }
             };
-            entry_grad(ok0, qm0, qs0);
-            entry_grad(ok1, qm1, qs1);
-            TT(3)
+            HOOK_TIE_GRADIENT(entry_grad(ok0, qm0, qs0); entry_grad(ok1, qm1, qs1);)
+            TIE_T(3)
         }
         }  // next unit of the ticket
     }
-    TT_FLUSH
+    TIE_TIMERS_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2612,9 +2614,8 @@ static void launch_tiles(const RasterArgs &a, int N, hipStream_t stream) {
 // (tie_rule 1) the pixels the tile kernel left out: the reference's queue replayed, one wave per pixel
 template <int MODE>
 static void launch_tie_replay(const RasterArgs &a, hipStream_t stream) {
-    // dynamic LDS: the face-id bitmap (FT bits) or the filling queue (128 slots x 3 words), + the tile's ordered face ids (17 bits each)
-    const size_t r0 = (size_t)a.FT / 8 > 6 * WAVE * sizeof(uint32_t) ? (size_t)a.FT / 8 : 6 * WAVE * sizeof(uint32_t);
-    const size_t lds = r0 + (size_t)TIE_ORD_CAP * sizeof(uint16_t) + TIE_ORD_CAP / 8;
+    // dynamic LDS: the face-id bitmap (FT bits), the filling queue (128 slots x 3 words), the tile's ordered face ids (17 bits each)
+    const size_t lds = (size_t)a.FT / 8 + 6 * WAVE * sizeof(uint32_t) + (size_t)TIE_ORD_CAP * sizeof(uint16_t) + TIE_ORD_CAP / 8;
     // (76 VGPRs: six waves per SIMD, which the ~6 - 8 KB of LDS allow as well; the waves take tickets until none is left)
     if (a.tie_rule) hipLaunchKernelGGL((k_raster_tie_replay<MODE>), dim3((unsigned int)device_cus() * 24u), dim3(64), lds, stream, a);
 }

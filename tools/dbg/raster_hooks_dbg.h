@@ -131,3 +131,30 @@ static inline void raster_dbg_report(unsigned long long *&dbg_out) {
 #else
 #define HOOK_SETUP_COUNT(stmt) stmt
 #endif
+
+// ---- k_raster_tie_replay (tie_rule = reference_queue) ----
+#ifdef DBG_TIE_TIMERS  // where a replay wave's cycles go (tools/dbg/tie_timers.py): list order, face evaluation, queue, gradient, ticket, ...
+__device__ unsigned long long g_tie_t[8];
+extern "C" int smil_dbg_tie_timers(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tie_t), sizeof(g_tie_t)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tie_t), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define TIE_TIMERS_INIT unsigned long long tt_[8] = {}, tt0_ = __builtin_amdgcn_s_memtime();
+#define TIE_T(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tt_[i] += n_ - tt0_; tt0_ = n_; }
+#define TIE_TIMERS_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_tie_t[i_], tt_[i_]);
+#else
+#define TIE_TIMERS_INIT
+#define TIE_T(k)
+#define TIE_TIMERS_FLUSH
+#endif
+#ifdef ABL_TIE_NO_ATOMICS  // what the replay's gradient atomics cost (garbage gradients)
+#define HOOK_TIE_GRADIENT(stmt)
+#else
+#define HOOK_TIE_GRADIENT(stmt) stmt
+#endif
+#ifdef TIE_NO_EQUIV  // every cut tie group replayed, interchangeable ones included
+#define HOOK_TIE_EQUIV false
+#else
+#define HOOK_TIE_EQUIV true
+#endif

@@ -13,7 +13,7 @@ import torch
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 8)()
 assert _lib.load().smil_dbg_tie_timers(out, 1) == 0
-names = ["ordered list", "face evaluation", "queue", "blend + gradient", "ticket + masks", "loop head", "-", "-"]
+names = ["ordered list", "face evaluation", "queue", "gradient", "ticket + masks", "loop head", "blend + loss", "group scan (list not ordered)"]
 tot = sum(out)
 for n, v in zip(names, out):
     if v:

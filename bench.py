@@ -173,7 +173,7 @@ def parity_check(fitter, tables, wl, sample, window):
                     "(depth, face id) tie rule, DESIGN.md section 4)"}
 
 
-def time_other_workload(key, dev, steps=5, warmup=3, frames=0, graph=False):
+def time_other_workload(key, dev, steps=5, warmup=3, frames=0, graph=False, tie_rule=None):
     """One of the other BASELINE configurations, timed AFTER the headline region and outside it (rank 0, one GPU): the same fit
     iteration on that configuration's own synthetic problem.  Returns ms per step, the tile kernel's average launch time from
     HIP events, and the roofline fraction by the same definition as the headline (algorithmic bytes per launch / kernel time)."""
@@ -183,6 +183,8 @@ def time_other_workload(key, dev, steps=5, warmup=3, frames=0, graph=False):
     tables = model_io.load_model(os.path.join(REPO, "data", "models", wl["model"] + ".npz"))
     n_frames, views, S = (frames or wl["frames"]), wl["views"], wl["S"]
     fitter = synthetic.make_problem(tables, n_frames, views, S, dev, radius=wl["radius"], seed=1234, window=10)
+    if tie_rule:
+        fitter.renderer.raster_settings = engine.raster_settings(tie_rule=tie_rule)
     fitter.begin_stage(synthetic.STAGE1_LR, fov_lr=1.0)
     step = fitter.fit_step_graph if graph else fitter.fit_step
     for _ in range(warmup):
@@ -201,7 +203,7 @@ def time_other_workload(key, dev, steps=5, warmup=3, frames=0, graph=False):
     launches_per_step = max(1, round(kern_n / max(steps, 1)))
     kern_avg = kern_ms / max(kern_n, 1)
     achieved = (n_img / launches_per_step * per_view) / (kern_avg * 1e-3) / 1e9 if kern_n else 0.0
-    out = {"workload": wl["name"] + (f" [--frames {n_frames}]" if frames else ""), "frames": n_frames, "images": n_img, "steps": steps,
+    out = {"workload": wl["name"] + (f" [--frames {n_frames}]" if frames else "") + (f" [tie_rule {tie_rule}]" if tie_rule else ""), "frames": n_frames, "images": n_img, "steps": steps,
            "ms_per_step": 1000.0 * dt / steps, "frame_iters_per_s": n_frames / (dt / steps), "kernel_ms": kern_avg if kern_n else None,
            "launches_per_step": launches_per_step, "frac": achieved / HBM_PEAK_GBS if kern_n else None}
     del fitter
@@ -413,6 +415,9 @@ def main():
             others = {k: time_other_workload(k, dev, steps=20 if k == "cfg2" else 5) for k in ("cfg2", "cfg3", "cfg4")}  # (cfg2: 2 ms steps)
             others["one_frame_eager"] = time_other_workload("cfg2", dev, steps=50, warmup=5, frames=1)
             others["one_frame_graph"] = time_other_workload("cfg2", dev, steps=50, warmup=5, frames=1, graph=True)
+            # the headline workload with the reference's own choice among equal depths (SmilRasterSettings.tie_rule = 1): what the
+            # faithful mode costs (kernel_ms / frac are the tile kernel's alone, the replay kernel runs behind it)
+            others["cfg2b_tie_rule_reference_queue"] = time_other_workload(args.workload, dev, frames=args.frames, tie_rule="reference_queue")
             out["other_workloads"] = others
         print(json.dumps(out), flush=True)
         if parity is not None and not parity["ok"]:

@@ -79,6 +79,17 @@ def test_baseline_shape_against_oracle(key, views, S, radius, frames, tables):
     sil = engine.silhouette_forward(dm, ndc, S).cpu()
     d = (sil - sil_ref).abs().numpy()
     assert d.mean() < 2e-6 and np.mean(d > 1e-4) < 2e-3, (d.mean(), np.mean(d > 1e-4), d.max())
+    # ... and with the reference's own choice among equal depths (tie_rule = reference_queue; the oracle's default IS that queue): the
+    # pixels that differed by the tie rule come into line, on the silhouettes and on the fit iteration's silhouette term
+    rs_q = engine.raster_settings(tie_rule="reference_queue")
+    dq = (engine.silhouette_forward(dm, ndc, S, rs_q).cpu() - sil_ref).abs().numpy()
+    replayed = engine.raster_stats(dm, frames * views)["tie_pixels"]
+    assert replayed > 0 and dq.mean() <= d.mean() and np.mean(dq > 1e-4) <= np.mean(d > 1e-4) and dq.mean() < 1e-6, (replayed, dq.mean(), d.mean(), np.mean(dq > 1e-4))
+    fitter.renderer.raster_settings = rs_q
+    objs_q, _ = fitter._loss_and_grads(None, weights, 0.0, window=frames)
+    fitter.renderer.raster_settings = engine.raster_settings()
+    assert abs(objs_q[5].item() - terms["sil_reproj"]) <= abs(objs[5].item() - terms["sil_reproj"]) + 2e-6 * abs(terms["sil_reproj"]), \
+        (objs_q[5].item(), objs[5].item(), terms["sil_reproj"])
 
     # gradients of every parameter (float atomics over ~1e6 (face, pixel) pairs: order noise only)
     got = dict(betas=grads["betas"], global_rotation=grads["pose"][:, 0], joint_rotations=grads["pose"][:, 1:], trans=grads["trans"],

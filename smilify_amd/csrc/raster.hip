@@ -2028,12 +2028,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
 // RasterizeMeshesNaiveCudaKernel, selected by the reference with faces_per_pixel = 100 and bin_size = 0,
 // smal_fitter/p3d_renderer.py:42-47).  The K nearest by DEPTH survive whatever the order; which members of a group of EQUAL depths
 // at the K-th place survive depends on the slots the whole history put them in.  The tile kernel's rule - the smallest face ids -
-// is order independent but not that one.  With tie_rule 1 the tile kernel leaves every pixel whose tie group is cut by K to this
-// kernel (a bit per pixel and work item, `tie_mask`), which REPLAYS the reference's loop for that pixel: one wave per pixel, the
-// queue in registers (slot s = lane s % 64, register s / 64; K <= 128), every face whose tile box contains the pixel's tile
-// evaluated in index order (64 at a time, through the 64-face group boxes - the same pair arithmetic as the tile kernel, from
-// registers), the candidates fed to the queue one by one.  Then the pixel's blend, loss term and gradient from the queue's final
-// content, exactly as the tile kernel computes them from its records.  ~2 % of the truncated pixels take this path.
+// is order independent but not that one.  With tie_rule 1 the tile kernel leaves every pixel whose tie group is cut by K - and whose
+// tied records are not interchangeable (see `same` there) - to this kernel (a bit per pixel and work item, `tie_mask`), which REPLAYS
+// the reference's loop for that pixel: one wave per pixel, the queue in registers (slot s = lane s % 64, register s / 64; K <= 128),
+// every face of the tile's list in index order (put in order through an LDS bitmap, 64 at a time, the same pair arithmetic as the tile
+// kernel), the candidates fed to the queue - the fill in one step per batch, the replacements one by one.  Then the pixel's blend, loss
+// term and gradient from the queue's final content, exactly as the tile kernel computes them from its records.  45 pixels per cfg2b
+// image take this path (+20 % per iteration; what was measured and rebuilt on the way: profiles/r5_experiments.md section 7).
 __device__ __forceinline__ FaceRows face_rows_from_tri(const Tri9 &tv, float cx, float cy) {
     FaceRows q;
     float rl12;
@@ -2061,7 +2062,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 #define TIE_WHOLE_TILE 6  // replayed pixels up to which a tile is one work unit (above: four, by quarters of its pixels)
 #endif
 #ifndef TIE_ORD_CAP
-#define TIE_ORD_CAP 2048  // faces of a tile's list that the replay orders in LDS (longer lists, and images whose lists were not binned: group scan)
+#define TIE_ORD_CAP 2048  // faces of a tile's list that the replay puts in order at once (longer lists: 64 bitmap words = up to 2 048 faces at a time)
 #endif
 static_assert(TIE_ORD_CAP % 64 == 0 && TIE_ORD_CAP / 32 <= WAVE && TIE_ORD_CAP >= 64 * 32, "the high bits of the ordered ids are cleared by one wave; a segment of 64 bitmap words fits");
 template <int MODE>

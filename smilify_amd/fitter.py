@@ -545,8 +545,8 @@ class SMALFitter(nn.Module):
     # ---- the same epoch as one hipGraph: ~40 kernel launches replayed with a single call --------------------
     def _graph_key(self, weights, w_temp, window):
         """Everything a captured iteration bakes in besides the parameter buffers: loss weights, which parameters train,
-        the target tensors, and the raw device addresses of the camera tables, the rotation masks and the rasteriser
-        workspace.  A replay happens only while all of them are what they were at capture time."""
+        the target tensors, the rasteriser settings, and the raw device addresses of the camera tables, the rotation masks and the
+        rasteriser workspace.  A replay happens only while all of them are what they were at capture time."""
         flags = tuple(bool(getattr(self, n).requires_grad) for n in
                       ("betas", "log_beta_scales", "betas_trans", "global_rotation", "joint_rotations", "trans", "fov"))
         cam = self.renderer.cameras
@@ -554,7 +554,9 @@ class SMALFitter(nn.Module):
         ws = self.device_model._ws
         addresses = (ptr(cam.R), ptr(cam.T), ptr(cam.aspect_ratio), ptr(self.fov.data), ptr(self._mask_table()),
                      ptr(self.log_beta_scales.data), ptr(self.betas_trans.data), ptr(self.betas.data), None if ws is None else ws.data_ptr())
-        return (tuple(float(w) for w in weights), float(w_temp), window, flags, self._target_signature, addresses)
+        rs = self.renderer.raster_settings  # (passed by value into the captured launches: blur, sigma, K, clipping plane, tie rule)
+        raster = (float(rs.blur_radius), float(rs.sigma), int(rs.faces_per_pixel), float(rs.z_clip), int(rs.tie_rule))
+        return (tuple(float(w) for w in weights), float(w_temp), window, flags, self._target_signature, addresses, raster)
 
     def fit_step_graph(self, weights, w_temp: float, window: Optional[int] = None):
         """``fit_step`` for a single rank, captured once per (stage, weights) in a hipGraph (``torch.cuda.CUDAGraph``)

@@ -196,17 +196,20 @@ def test_smal_and_renderer_dropins(key, tables):
     assert none is None and torch.allclose(proj2, proj.detach())
 
 
-@pytest.mark.parametrize("key,radius", [("stick", 2.7), ("mouse", 4.0)])
-def test_graph_captured_step_equals_eager_step(key, radius, tables):
+@pytest.mark.parametrize("key,radius,tie_rule", [("stick", 2.7, None), ("mouse", 4.0, None), ("stick", 2.7, "reference_queue")])
+def test_graph_captured_step_equals_eager_step(key, radius, tie_rule, tables):
     """fit_step_graph (one hipGraph replay per iteration) against fit_step (one launch per kernel): same losses and the
     same parameters after several iterations, also when eager steps are mixed in.  (The mouse: the one-workgroup-per-CU form of the
-    fused LBS kernels, 139 KB of dynamic LDS, inside a captured graph.)"""
-    from smilify_amd import synthetic
+    fused LBS kernels, 139 KB of dynamic LDS, inside a captured graph.  Third case: the reference's tie rule - the replay kernel, its
+    ticket counter and the tie masks inside the captured graph.)"""
+    from smilify_amd import engine, synthetic
 
     t = tables(key)
     runs = {}
     for mode in ("eager", "graph", "mixed"):
         f = synthetic.make_problem(t, 6, 2, 64, DEV, radius=radius, seed=11, window=3)
+        if tie_rule:
+            f.renderer.raster_settings = engine.raster_settings(tie_rule=tie_rule)
         f.begin_stage(synthetic.STAGE1_LR)
         objs = []
         for it in range(6):
@@ -214,6 +217,8 @@ def test_graph_captured_step_equals_eager_step(key, radius, tables):
             step = f.fit_step_graph if use_graph else f.fit_step
             objs.append(step(synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL).clone())
         torch.cuda.synchronize()
+        if tie_rule:
+            assert engine.raster_stats(f.device_model, 12)["tie_pixels"] > 0  # (the replay kernel did run in the last iteration)
         runs[mode] = (torch.stack(objs).cpu(), {n: getattr(f, n).detach().cpu().clone() for n in PARAMS})
     ref_objs, ref_par = runs["eager"]
     for mode in ("graph", "mixed"):

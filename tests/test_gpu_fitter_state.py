@@ -41,8 +41,8 @@ def test_load_checkpoint_reads_what_the_reference_wrote(tables):
     np.testing.assert_allclose(got["trans"], want["trans"], atol=1e-7)
 
 def test_graph_replay_is_invalidated_by_camera_mask_and_workspace_changes(tables):
-    """A captured iteration bakes in device addresses; after set_cameras / a re-assigned mask / a regrown workspace the
-    next fit_step_graph must re-capture and agree with the eager step."""
+    """A captured iteration bakes in device addresses; after set_cameras / a re-assigned mask / a regrown workspace / new rasteriser
+    settings the next fit_step_graph must re-capture and agree with the eager step."""
     from smilify_amd import synthetic
     from smilify_amd.cameras import look_at_view_transform
 
@@ -95,6 +95,11 @@ def test_graph_replay_is_invalidated_by_camera_mask_and_workspace_changes(tables
     both()
     del held
     assert fg._graph["graph"] is not third
+    fourth = fg._graph["graph"]
+    for f in (fe, fg):                          # the rasteriser settings travel by value into the captured launches
+        f.renderer.raster_settings = _eng.raster_settings(tie_rule="reference_queue")
+    both()
+    assert fg._graph["graph"] is not fourth
 
 def test_renderer_topology_cache_is_keyed_by_content(tables):
     from smilify_amd.p3d_renderer import Renderer

@@ -2087,14 +2087,20 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
     unsigned int total = 0;
     for (int q = 0; q < N_PARTS; ++q)
         for (int c = 0; c < N_CLASSES; ++c) total += a.ctr->n_class[q][c];
-    // Work unit = (work item, quarter of its 64 pixels), unit index = quarter x items + item: the replayed pixels cluster in few tiles
+    // Work unit = (work item, part of its 64 pixels - a quarter in large launches), unit index = part x items + item: the replayed pixels cluster in few tiles
     // (0.8 per touched tile on average, dozens in some), and a pixel costs ~7 000 wave instructions, so the units are dealt out
     // dynamically - a ticket is 64 units, lane = unit reads its item's mask - and the quarters of one heavy tile go to
     // different waves.
     unsigned int pre[N_PARTS + 1];  // items before each partition
     pre[0] = 0u;
     for (int q = 0; q < N_PARTS; ++q) pre[q + 1] = pre[q] + a.ctr->n_class[q][0] + a.ctr->n_class[q][1] + a.ctr->n_class[q][2] + a.ctr->n_class[q][3];
-    const unsigned int n_units = total * 4u, n_tickets = (n_units + (unsigned int)WAVE - 1u) / (unsigned int)WAVE;
+    // (a pixel is ~100 us of one wave: a launch with few replayed pixels per wave - a few hundred frames - is as long as its largest
+    // unit, so its tiles are cut finer: 16 units of 4 pixels below 16 pixels per wave, single pixels below 4)
+    // (no more waves than replayed pixels take tickets: 6 144 waves queueing for ONE counter word were 0.2 ms of a one-frame launch)
+    if (blockIdx.x >= a.ctr->tie_pixels) return;  // (workgroup-uniform, before any barrier)
+    const unsigned int px_per_wave = a.ctr->tie_pixels / gridDim.x;
+    const unsigned int parts_log = px_per_wave >= 16u ? 2u : (px_per_wave >= 4u ? 4u : 6u), px_log = 6u - parts_log;
+    const unsigned int n_units = total << parts_log, n_tickets = (n_units + (unsigned int)WAVE - 1u) / (unsigned int)WAVE;
     TIE_TIMERS_INIT
     for (;;) {
         TIE_T(5)
@@ -2122,7 +2128,8 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             my_slot = (uint32_t)part * 2u * a.item_cap + item_at;
             // (a tile with few replayed pixels is one unit - quarter 0 takes them all - so that its face list is put in order once)
             const unsigned long long full = a.tie_mask[my_slot];
-            my_mask = __popcll(full) <= TIE_WHOLE_TILE ? (quarter == 0u ? full : 0ull) : full & (0xFFFFull << (16u * quarter));
+            const unsigned long long part_mask = ((px_log == 6u ? 0ull : 1ull << (1u << px_log)) - 1ull) << (quarter << px_log);
+            my_mask = (parts_log == 2u && __popcll(full) <= TIE_WHOLE_TILE) ? (quarter == 0u ? full : 0ull) : full & part_mask;
         }
         unsigned long long um = __ballot(my_mask != 0ull);
         TIE_T(4)
@@ -2207,9 +2214,8 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
             int qsize = 0, qmax_idx = 0;
             uint32_t qmax_z = 0u;  // (depths are positive: their bit patterns order like the values, and 0 is below all of them)
             // lane = face: is it a candidate of this pixel, and with what depth / flags / distance
-            auto eval_face = [&](int f, bool &cand, uint32_t &zb, uint32_t &fl, float &sd) {
-                const int i0 = face_vertex(a.faces, xf_n, a.F, f, 0), i1 = face_vertex(a.faces, xf_n, a.F, f, 1), i2 = face_vertex(a.faces, xf_n, a.F, f, 2);
-                const FaceRows fr = face_rows_from_tri(load_tri(a, vn, xv_n, i0, i1, i2), cx, cy);
+            auto eval_tri = [&](const Tri9 &tv, bool &cand, uint32_t &zb, uint32_t &fl, float &sd) {
+                const FaceRows fr = face_rows_from_tri(tv, cx, cy);
                 PairEval2 e;
                 eval_pair2(fr, dx_even, dx_odd, dyp, a.blur, e);
                 cand = odd ? e.cand1 : e.cand0;
@@ -2271,19 +2277,38 @@ __global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
                     qmax_z = mx;  // (>= z: the newcomer is in the queue)
                 }
             };
-            auto walk = [&](int n_ids) {  // the faces ord[0 ... n_ids), 64 at a time
+            // the faces ord[0 ... n_ids), 64 at a time.  A batch is a chain ordered id -> vertex ids -> vertices -> rows; the ids (and the
+            // nearest depth) of the NEXT batch are requested before this one's vertices, so that a batch exposes one round trip, not
+            // two: a pixel is one wave's serial work, and in small launches the replay is as long as its slowest pixel.
+            auto walk = [&](int n_ids) {
+                auto request = [&](int b0, bool &have, int &f, int &i0, int &i1, int &i2, uint32_t &znear) {
+                    have = b0 + lane < n_ids;
+                    f = have ? (int)ord[b0 + lane] | (int)(((ord_hi[(b0 + lane) >> 5] >> ((b0 + lane) & 31)) & 1u) << 16) : 0;
+                    i0 = i1 = i2 = 0; znear = 0xFFFFFFFFu;
+                    if (have) {
+                        i0 = face_vertex(a.faces, xf_n, a.F, f, 0); i1 = face_vertex(a.faces, xf_n, a.F, f, 1); i2 = face_vertex(a.faces, xf_n, a.F, f, 2);
+                        znear = __float_as_uint(fzr_n[f].x);
+                    }
+                };
+                bool have_n; int f_n, j0, j1, j2; uint32_t zn_n;
+                request(0, have_n, f_n, j0, j1, j2, zn_n);
                 for (int b0 = 0; b0 < n_ids; b0 += WAVE) {
-                    const bool have = b0 + lane < n_ids;
-                    const int f = have ? (int)ord[b0 + lane] | (int)(((ord_hi[(b0 + lane) >> 5] >> ((b0 + lane) & 31)) & 1u) << 16) : 0;
+                    const bool have = have_n;
+                    const int f = f_n, i0 = j0, i1 = j1, i2 = j2;
+                    const uint32_t znear = zn_n;
                     // Once the queue is full only a depth strictly below its farthest entry gets in, and a face's depth at any pixel
                     // is at least its nearest vertex's: faces at or beyond the bound are not evaluated (no vertex fetch, no rows), a
                     // batch of them is skipped whole - in the heaviest tiles (thousands of faces behind the first hundred) most are.
-                    const bool live = have && (qsize < K || __float_as_uint(fzr_n[f].x) < qmax_z);
-                    if (__ballot(live) == 0ull) continue;  // (wave-uniform)
+                    const bool live = have && (qsize < K || znear < qmax_z);
                     bool cand = false;
                     uint32_t zb = 0u, fl = 0u;
                     float sd = 0.f;
-                    if (live) eval_face(f, cand, zb, fl, sd);
+                    Tri9 tv;
+                    const bool any_live = __ballot(live) != 0ull;  // (wave-uniform)
+                    if (live) tv = load_tri(a, vn, xv_n, i0, i1, i2);           // this batch's vertices are requested ...
+                    if (b0 + WAVE < n_ids) request(b0 + WAVE, have_n, f_n, j0, j1, j2, zn_n);  // ... then the next batch's ids
+                    if (!any_live) continue;
+                    if (live) eval_tri(tv, cand, zb, fl, sd);
                     TIE_T(1)
                     feed(cand, zb, fl, sd, f);
                     TIE_T(2)

@@ -344,6 +344,17 @@ int smil_fit_epilogue(const SmilFitConfig *cfg, const float *pose, const float *
 int smil_joint_loss(const SmilFitConfig *cfg, int32_t views, int32_t Jc, const int32_t *canon, const float *proj,
                     const float *target, const int32_t *visibility, float *objs, float *d_proj, void *stream);
 
+/* The six loss terms of SMALFitter.forward (fitter.py:292-333) for every WINDOW of this shard separately, computed from the buffers
+ * one whole-batch iteration left behind (proj from smil_lbs_forward_project / smil_project, loss_img from smil_silhouette_l1_fused,
+ * objs_total = the iteration's objs after smil_fit_epilogue): what the reference's per-window forward() calls of one epoch return
+ * (optimize_to_joints.py:153-157), without evaluating the windows one by one.  objs_win (n_windows,6), overwritten:
+ * [joint, limit, pose, splay, betas, sil_reproj].  proj NULL: no joint term; loss_img NULL: no silhouette term.  The shard must start
+ * at a window boundary and n_windows = ceil(N / window). */
+int smil_window_terms(const SmilFitConfig *cfg, int32_t views, int32_t Jc, const int32_t *canon, const float *proj,
+                      const float *target, const int32_t *visibility, const float *pose, const float *mask,
+                      const float *objs_total, const float *loss_img, const float *pix_scale, float *objs_win,
+                      int32_t n_windows, void *stream);
+
 /* Helpers of the fused silhouette term: pix_scale[n] = w_reproj / (b_w views S^2); target_sum[n] =
  * sum_px |target[n]| (once per fit); objs[5] += sum_n pix_scale[n] loss_img[n]. */
 int smil_pix_scale(const SmilFitConfig *cfg, int32_t views, int32_t S, float *pix_scale, void *stream);

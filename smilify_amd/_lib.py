@@ -19,7 +19,7 @@ EXPORTS = [
     "smil_fov_reduce", "smil_fit_epilogue",
     "smil_raster_workspace_bytes", "smil_raster_stats", "smil_silhouette_forward", "smil_silhouette_backward",
     "smil_silhouette_l1_fused", "smil_prior_losses", "smil_mask_rows", "smil_joint_loss", "smil_pix_scale",
-    "smil_image_abs_sum", "smil_sil_objective", "smil_adam_step", "smil_adam_step_multi", "smil_adam_step_dev", "smil_profile_enable",
+    "smil_image_abs_sum", "smil_sil_objective", "smil_window_terms", "smil_adam_step", "smil_adam_step_multi", "smil_adam_step_dev", "smil_profile_enable",
     "smil_profile_read",
 ]
 
@@ -138,6 +138,7 @@ def load():
     lib.smil_pix_scale.argtypes = [POINTER(FitConfig), c_int32, c_int32, c_void_p, c_void_p]
     lib.smil_image_abs_sum.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.smil_sil_objective.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
+    lib.smil_window_terms.argtypes = [POINTER(FitConfig), c_int32, c_int32] + [c_void_p] * 10 + [c_int32, c_void_p]
     lib.smil_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                    c_int32, c_void_p]
     lib.smil_adam_step_multi.argtypes = [POINTER(AdamTensor), c_int32, c_float, c_float, c_float, c_void_p]

@@ -304,6 +304,88 @@ extern "C" int smil_joint_loss(const SmilFitConfig *cfg, int32_t views, int32_t 
     return SMIL_OK;
 }
 
+// The six terms of SMALFitter.forward (fitter.py:292-333) WINDOW BY WINDOW, from what one evaluation of the whole batch left behind:
+// the reference's driver calls forward once per WINDOW_SIZE frames (optimize_to_joints.py:153-157) and wants each window's own
+// loss and terms back.  The fused iteration evaluates all windows at once (objs = their sum); this kernel restates the per-window
+// sums - one workgroup per window, fixed summation order, no atomics - so that the drop-in forward() can serve every window of an
+// epoch from ONE evaluation (SMALFitter._epoch in fitter.py).  objs_win (windows of this shard, 6): joint, limit, pose, splay,
+// betas, sil_reproj - the same arithmetic per element as k_joint_loss / prior_losses_body / betas_prior_body / the silhouette objective.
+struct WindowTermArgs {
+    SmilFitConfig c;
+    int views, Jc;
+    const int *canon;
+    const float *proj, *target;
+    const int *vis;
+    const float *pose, *mask, *objs_total, *loss_img, *pix_scale;
+    float *objs_win;
+};
+__global__ void __launch_bounds__(256) k_window_terms(WindowTermArgs a) {
+    __shared__ float red[16];
+    const SmilFitConfig &c = a.c;
+    const int w = c.window > 0 ? c.window : c.N_total;
+    const int first_win = c.frame0 / w;                 // (shards start at window boundaries: optimize.plan_shards)
+    const int gw = first_win + (int)blockIdx.x;
+    const int g0 = max(gw * w, c.frame0), g1 = min(min((gw + 1) * w, c.N_total), c.frame0 + c.N);  // global frames of this window held here
+    const int i0 = g0 - c.frame0, n = g1 - g0;          // local frames [i0, i0 + n)
+    float *out = a.objs_win + 6 * (size_t)blockIdx.x;
+    float o_joint = 0.f, o_limit = 0.f, o_pose = 0.f, o_splay = 0.f, o_sil = 0.f;
+    if (n > 0) {
+        const float bw = (float)window_size_of(c, i0);
+        if (a.proj && c.w_j2d > 0.f) {  // fitter.py:292-296
+            const float s = c.w_j2d / (bw * (float)a.views * (float)a.Jc * 2.f);
+            const int total = n * a.views * a.Jc;
+            for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+                const int img = i0 * a.views + idx / a.Jc, k = idx % a.Jc;
+                const int j = a.canon ? a.canon[k] : k;
+                if (a.vis[(size_t)img * a.Jc + k] != 0) {
+                    const size_t po = ((size_t)img * c.J + j) * 2, to = ((size_t)img * a.Jc + k) * 2;
+                    const float dy = a.proj[po] - a.target[to], dx = a.proj[po + 1] - a.target[to + 1];
+                    o_joint += s * (dy * dy + dx * dx);
+                }
+            }
+        }
+        const int P3 = 3 * c.J;
+        for (int idx = threadIdx.x; idx < n * (P3 - 3); idx += blockDim.x) {  // joint rotations only (fitter.py:303-319)
+            const int i = i0 + idx / (P3 - 3), e = 3 + idx % (P3 - 3);
+            const float cur = a.pose[(size_t)i * P3 + e] * a.mask[e];
+            if (c.w_limit > 0.f) o_limit += c.w_limit / (bw * (float)(P3 - 3)) * (fmaxf(cur - c.limit, 0.f) + fmaxf(-c.limit - cur, 0.f));
+            if (c.w_pose > 0.f) o_pose += c.w_pose / (bw * (float)P3) * cur * cur;
+            if (c.w_splay > 0.f && (e % 3) != 1) o_splay += c.w_splay * cur * cur;
+        }
+        if (a.loss_img)  // fitter.py:332-333
+            for (int k = threadIdx.x; k < n * a.views; k += blockDim.x) o_sil += a.loss_img[i0 * a.views + k] * a.pix_scale[i0 * a.views + k];
+    }
+    float v;
+    v = block_sum(o_joint, red); if (threadIdx.x == 0) out[0] = v;
+    v = block_sum(o_limit, red); if (threadIdx.x == 0) out[1] = v;
+    v = block_sum(o_pose, red);  if (threadIdx.x == 0) out[2] = v;
+    v = block_sum(o_splay, red); if (threadIdx.x == 0) out[3] = v;
+    v = block_sum(o_sil, red);   if (threadIdx.x == 0) out[5] = v;
+    if (threadIdx.x == 0) {  // the shape prior is the same for every window: the iteration's sum over the shard's windows, shared out
+        const int first = (c.frame0 + w - 1) / w, last = (c.frame0 + c.N + w - 1) / w;
+        out[4] = (n > 0 && last > first) ? a.objs_total[4] / (float)(last - first) : 0.f;
+    }
+}
+
+extern "C" int smil_window_terms(const SmilFitConfig *cfg, int32_t views, int32_t Jc, const int32_t *canon, const float *proj,
+                                 const float *target, const int32_t *visibility, const float *pose, const float *mask,
+                                 const float *objs_total, const float *loss_img, const float *pix_scale, float *objs_win,
+                                 int32_t n_windows, void *stream_) {
+    SMIL_REQUIRE(cfg && pose && mask && objs_total && objs_win && n_windows > 0, "smil_window_terms: null argument");
+    SMIL_REQUIRE(cfg->N > 0 && cfg->J > 1 && cfg->N_total >= cfg->frame0 + cfg->N, "smil_window_terms: bad sizes");
+    SMIL_REQUIRE(!proj || (target && visibility && views > 0 && Jc > 0 && Jc <= cfg->J), "smil_window_terms: the joint term needs targets and visibility");
+    SMIL_REQUIRE(!loss_img || (pix_scale && views > 0), "smil_window_terms: the silhouette term needs pix_scale");
+    const int w = cfg->window > 0 ? cfg->window : cfg->N_total;
+    SMIL_REQUIRE(cfg->frame0 % w == 0, "smil_window_terms: the shard starts inside a window (frame0=%d window=%d)", cfg->frame0, w);
+    SMIL_REQUIRE(n_windows == ceil_div(cfg->N, w), "smil_window_terms: n_windows=%d but the shard holds %d", n_windows, ceil_div(cfg->N, w));
+    WindowTermArgs a;
+    a.c = *cfg; a.views = views; a.Jc = Jc; a.canon = canon; a.proj = proj; a.target = target; a.vis = visibility;
+    a.pose = pose; a.mask = mask; a.objs_total = objs_total; a.loss_img = loss_img; a.pix_scale = pix_scale; a.objs_win = objs_win;
+    hipLaunchKernelGGL(k_window_terms, dim3(n_windows), dim3(256), 0, (hipStream_t)stream_, a);
+    SMIL_LAUNCH_CHECK();
+    return SMIL_OK;
+}
+
 // per-image silhouette loss -> objs[5]: sum_n scale[n] * loss_img[n]
 __global__ void __launch_bounds__(256) k_sil_objective(const float *__restrict__ loss_img, const float *__restrict__ pix_scale,
                                                        int N, float *__restrict__ objs) {

@@ -1533,7 +1533,7 @@ static int lbs_backward_impl(const SmilModel *m, const SmilLbsInputs *in, const 
     // adds them in a fixed order (BetaSum: bit-reproducible); per-frame betas: one row per frame
     const bool beta_shared = g->d_beta && nBu_all > 0 && in->shared_beta;
     if (g->d_beta && nBu_all > 0 && !in->shared_beta) dbeta_frame_all = g->d_beta;
-    SMIL_REQUIRE(!beta_shared || g->beta_rows, "smil_lbs_backward: shared betas need the beta_rows scratch (2 B nB_used floats)");
+    SMIL_REQUIRE(!beta_shared || g->beta_rows, "smil_lbs_backward: shared betas need the beta_rows scratch (2 B nB_used + 16 floats)");
     BetaSum bsum;  // template: rows / all / n_all / ctr are set per kernel
     bsum.rows = nullptr; bsum.all = g->beta_rows; bsum.n_all = 0; bsum.ctr = nullptr; bsum.clear_ctr = nullptr; bsum.out = g->d_beta;
     bsum.accumulate = g->accumulate_shared_beta ? 1 : 0; bsum.n = nBu_all;

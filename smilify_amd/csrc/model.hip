@@ -19,9 +19,9 @@ extern "C" const char *smil_last_error(void) { return g_err; }
 // "instrumented" marks a library built by `make variant` for tools/dbg (timers, counters, cut-off experiments - possibly with garbage
 // results by design): tests/test_abi_cpu.py checks that the library the product loads is not one of those.
 #ifdef SMIL_INSTRUMENTED
-extern "C" const char *smil_version(void) { return "smilfit 0.2 (gfx950) instrumented"; }
+extern "C" const char *smil_version(void) { return "smilfit 0.3 (gfx950) instrumented"; }
 #else
-extern "C" const char *smil_version(void) { return "smilfit 0.2 (gfx950)"; }
+extern "C" const char *smil_version(void) { return "smilfit 0.3 (gfx950)"; }
 #endif
 
 template <typename T>

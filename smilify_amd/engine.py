@@ -192,7 +192,11 @@ class ClipDepth:
 
 
 def clip_depth_for(model: "DeviceModel", n_images: int) -> ClipDepth:
-    """The model's cached ``ClipDepth`` for calls of ``n_images`` images (one per size: a captured graph keeps its pointers)."""
+    """The model's cached ``ClipDepth`` for calls of ``n_images`` images (one per size: a captured graph keeps its pointers).
+    The cache is shared by every fitter, renderer and stream that uses this ``DeviceModel``: correctness relies on the produce
+    (rasteriser call) -> consume (LBS / projection backward) pair of one evaluation being issued back to back on ONE stream, as
+    ``SMALFitter._loss_and_grads`` does; callers that interleave evaluations of the same size on several streams must bring their own
+    ``ClipDepth``."""
     cache = model.__dict__.setdefault("_clip_depth_cache", {})
     if n_images not in cache:
         cache[n_images] = ClipDepth(model.device, n_images)
@@ -597,6 +601,18 @@ def joint_loss(cfg, views, Jc, canon, proj, target, visibility, objs, d_proj):
 def sil_objective(loss_img, pscale, objs):
     _lib.check(_lib.load().smil_sil_objective(_ptr(loss_img), _ptr(pscale), loss_img.numel(), _ptr(objs), _stream()),
                "smil_sil_objective")
+
+
+def window_terms(cfg, views, Jc, canon, proj, target, visibility, pose, mask, objs_total, loss_img, pscale) -> torch.Tensor:
+    """(windows of this shard, 6) = [joint, limit, pose, splay, betas, sil_reproj] of every window, from the buffers of ONE
+    whole-batch iteration (``smil_window_terms``): what the reference's per-window ``forward`` calls of an epoch return."""
+    w = cfg.window if cfg.window > 0 else cfg.N_total
+    n_win = (cfg.N + w - 1) // w
+    out = torch.empty(n_win, 6, dtype=torch.float32, device=pose.device)
+    _lib.check(_lib.load().smil_window_terms(ctypes.byref(cfg), views, Jc, _ptr(canon), _ptr(proj), _ptr(target), _ptr(visibility), _ptr(pose),
+                                             _ptr(mask), _ptr(objs_total), _ptr(loss_img), _ptr(pscale), _ptr(out), n_win, _stream()),
+               "smil_window_terms")
+    return out
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.5, beta2=0.999, eps=1e-8):

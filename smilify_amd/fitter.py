@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import os
+from collections import Counter
 import pickle as pkl
 from typing import Dict, List, Optional, Sequence
 
@@ -78,7 +79,62 @@ class _FitWindow(torch.autograd.Function):
                 s(g["fov"]))
 
 
+_WEIGHT_OF = {"joint": 0, "sil_reproj": 1, "betas": 2, "pose": 3, "limit": 4, "splay": 5}  # position of a term's weight (fitter.py:238)
+
+
+class _EpochEval(torch.autograd.Function):
+    """Every window of an epoch in ONE evaluation: ``(losses (windows,), terms (windows, 6))``.  The per-window ``forward`` calls
+    of the reference's driver index into these; autograd adds their upstream gradients up into one vector, so backward runs once
+    per epoch.  With the same upstream gradient on every window (the driver adds the window losses with weight 1) the whole-batch
+    gradients are the answer; windows whose upstream gradient differs (left out, weighted differently) are corrected by a direct
+    evaluation of just those windows - exact for every use of ``forward``."""
+
+    @staticmethod
+    def forward(ctx, fitter, weights, window, betas, log_beta_scales, betas_trans, pose, trans, fov):
+        _, grads = fitter._loss_and_grads(None, weights, 0.0, window=window, window_terms=True)
+        objs_win = grads.pop("_objs_win")
+        ctx.fitter, ctx.weights, ctx.window, ctx.grads = fitter, weights, window, grads
+        ctx.key = fitter._state_key(tuple(weights))
+        ctx.mark_non_differentiable(objs_win)
+        return objs_win.sum(1), objs_win
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_terms):
+        # sum_j g_j G_j.  Rows of per-frame parameters belong to one window each: they are scaled by their window's upstream value
+        # (exact, also for a window left out: its rows are exactly zero).  Shared parameters (betas, a shared fov or scale table):
+        # c G_total + sum_{g_j != c} (g_j - c) G_j with c the most frequent upstream value - nothing to correct in the driver's loop,
+        # one direct evaluation per deviating window otherwise (the window an epoch's first call evaluated on its own, ...).
+        f, W = ctx.fitter, ctx.window
+        N, views = f.num_images, f.views
+        vals = g_losses.tolist()  # (the one host sync of an epoch's backward)
+        c = Counter(vals).most_common(1)[0][0]
+        deviating = [(j, gj) for j, gj in enumerate(vals) if gj != c]
+        per_row = lambda t, rep: t * g_losses.repeat_interleave(rep)[:t.shape[0]].reshape((-1,) + (1,) * (t.dim() - 1))  # noqa: E731
+        out, shared = {}, []
+        for k, v in ctx.grads.items():
+            if v is None:
+                out[k] = None
+            elif not deviating:
+                out[k] = v if c == 1.0 else v * c
+            elif not f._is_shared(k):
+                out[k] = per_row(v, W * views if k == "fov" else W)
+            else:
+                out[k] = v * c
+                shared.append(k)
+        if deviating and shared:
+            if f._state_key(tuple(ctx.weights)) != ctx.key:
+                raise RuntimeError("SMALFitter: backward() through window losses after the parameters, targets or cameras they were "
+                                   "evaluated with have changed")
+            for j, gj in deviating:
+                _, gw = f._loss_and_grads(list(range(j * W, min(N, (j + 1) * W))), ctx.weights, 0.0)
+                for k in shared:
+                    out[k] = out[k] + gw[k] * (gj - c)
+        return (None, None, None, out["betas"], out["log_beta_scales"], out["betas_trans"], out["pose"], out["trans"], out["fov"])
+
+
 class SMALFitter(nn.Module):
+    epoch_cache = True  # forward() may serve the windows of an epoch from one whole-batch evaluation (False: every call on its own)
+
     def __init__(self, device, data_batch, batch_size, shape_family=-1, use_unity_prior=False, rgb_only=False, *,
                  tables: Optional[model_io.SmilModelTables] = None, model_path: Optional[str] = None,
                  config: Optional[_config.FitterConfig] = None, views: int = 1, frame0: int = 0, n_frames_total: Optional[int] = None):
@@ -150,6 +206,7 @@ class SMALFitter(nn.Module):
 
         # device-resident targets (the reference re-uploads them every forward, fitter.py:263-266)
         self._graph = None
+        self._epoch = None
         self._targets_dirty = True
         self._adam: Dict[str, Dict] = {}
         self._adam_step = 0
@@ -248,13 +305,15 @@ class SMALFitter(nn.Module):
     # the fused loss + gradient evaluation
     # ------------------------------------------------------------------------------------------
     def _loss_and_grads(self, frames: Optional[Sequence[int]], weights, w_temp: float, window: Optional[int] = None,
-                        halo_prev=None, halo_next=None, halo=None):
+                        halo_prev=None, halo_next=None, halo=None, window_terms: bool = False):
         """Evaluate every loss term and the gradient of their sum for ``frames`` (None = all frames of this rank).
 
         Returns ``(objs (10,), grads)`` with full-size gradient tensors (zero rows outside ``frames``).
         ``window``: frames per loss window; None = the selected frames form one window (``forward`` semantics).
         ``halo``: an ``optimize.PendingHalo`` instead of ``halo_prev`` / ``halo_next`` - waited for right before the epilogue kernel,
         the only reader of the rows, so the messages travel while skinning and rasteriser run.
+        ``window_terms``: also return ``grads["_objs_win"]`` (windows, 6), the six terms of every window on its own (one more
+        kernel over the buffers this evaluation leaves behind: ``smil_window_terms``).
         """
         if self._targets_dirty or self._signature() != self._target_signature:
             self._refresh_targets()
@@ -320,6 +379,7 @@ class SMALFitter(nn.Module):
         need_render = (w_j2d > 0) or (w_reproj > 0)
         g_lbs = None
         d_fov = loss_img = pscale = d_fov_sel = None
+        yx = tj = vis = None
         if need_render:
             # the rotation masks are applied inside the pose kernels (theta_mask): no masked copy of the pose
             lbs = engine.lbs_forward(dm, betas, pose, trans=trans, logscale=ls, btrans=bt, shared_beta=True,
@@ -327,7 +387,7 @@ class SMALFitter(nn.Module):
                                      allow_limb_scaling=cfg.ALLOW_LIMB_SCALING, trans_after_joints=True, theta_mask=mask,
                                      project=dict(cams=cams, ndc=w_reproj > 0, yx=w_j2d > 0) if engine.FUSED_LBS_FORWARD else None)
             both = w_j2d > 0 and w_reproj > 0
-            ndc = yx = d_yx = d_ndc = d_verts = d_joints = cd = None
+            ndc = d_yx = d_ndc = d_verts = d_joints = cd = None
             if engine.FUSED_LBS_FORWARD:  # projected by the skinning kernel (vertices -> NDC, joints -> pixels)
                 ndc, yx = lbs.get("ndc"), lbs.get("yx")
             elif both:  # vertices -> NDC and joints -> pixels in one launch
@@ -337,12 +397,11 @@ class SMALFitter(nn.Module):
             else:
                 ndc, _ = engine.project(cams, lbs["verts"], want_yx=False)
             if w_j2d > 0:
-                tj = self._tj_dev if idx is None else self._tj_dev.index_select(0, img_idx)
-                vis = self._vis_dev if idx is None else self._vis_dev.index_select(0, img_idx)
+                tj = (self._tj_dev if idx is None else self._tj_dev.index_select(0, img_idx)).contiguous()
+                vis = (self._vis_dev if idx is None else self._vis_dev.index_select(0, img_idx)).contiguous()
                 d_yx = torch.empty_like(yx)
                 Jc = self._canon_dev.numel()
-                engine.joint_loss(fc, views, Jc, None if self._canon_identity else self._canon_dev, yx, tj.contiguous(),
-                                  vis.contiguous(), objs, d_yx)
+                engine.joint_loss(fc, views, Jc, None if self._canon_identity else self._canon_dev, yx, tj, vis, objs, d_yx)
             if w_reproj > 0:
                 tgt = self._sil_dev if idx is None else self._sil_dev.index_select(0, img_idx).contiguous()
                 tsum = self._sil_sum if idx is None else self._sil_sum.index_select(0, img_idx).contiguous()
@@ -350,7 +409,7 @@ class SMALFitter(nn.Module):
                 # (the vertex gradient stays as the tile kernel accumulated it: the projection backward decodes it while it reads)
                 # (the depth gradients of edges cut at the clipping plane travel beside d_ndc; persistent buffers: a captured
                 # iteration replays the same pointers)
-                cd = engine.clip_depth_for(dm, n_img)
+                cd = self.__dict__["_last_clip_depth"] = engine.clip_depth_for(dm, n_img)
                 loss_img, d_ndc, _, d_ndc_scale = engine.silhouette_l1_fused(dm, ndc, S, tgt, tsum, pscale, self.renderer.raster_settings,
                                                                              packed_out=True, clip_depth=cd)
             # image-plane gradients -> world space: inside the skinning backward (one kernel per frame, no (B,V,3) vertex
@@ -391,6 +450,10 @@ class SMALFitter(nn.Module):
                             halo_prev=halo_prev, halo_next=halo_next, accumulate=accumulate, loss_img=loss_img, pix_scale=pscale,
                             cams=cams if d_fov_sel is not None else None, d_fov_img=d_fov_img if d_fov_sel is not None else None,
                             d_fov=d_fov_sel)
+        objs_win = None
+        if window_terms:  # every window's own six terms (the drop-in forward() serves the windows of an epoch from one evaluation)
+            objs_win = engine.window_terms(fc, views, self._canon_dev.numel(), None if self._canon_identity else self._canon_dev,
+                                           yx if w_j2d > 0 else None, tj, vis, pose, mask, objs, loss_img, pscale)
         if d_fov_sel is not None and (fov.numel() in (1, views) or idx is None):
             d_fov = d_fov_sel
         else:
@@ -420,6 +483,8 @@ class SMALFitter(nn.Module):
             if self.betas_trans.requires_grad else None,
             fov=d_fov.reshape(self.fov.shape) if self.fov.requires_grad else None,
         )
+        if objs_win is not None:
+            grads["_objs_win"] = objs_win
         return objs, grads
 
     # ------------------------------------------------------------------------------------------
@@ -430,15 +495,78 @@ class SMALFitter(nn.Module):
         print(grad_output)
 
     def forward(self, batch_range, weights, stage_id):
-        """Reference fitter.py:236-335: ``(sum of the weighted terms, dict of the terms)`` for one window."""
-        total, objs = _FitWindow.apply(self, list(batch_range), [float(w) for w in weights], 0.0, self.betas, self.log_beta_scales,
-                                       self.betas_trans, self._pose_leaf(), self.trans, self.fov)
+        """Reference fitter.py:236-335: ``(sum of the weighted terms, dict of the terms)`` for one window.
+
+        The reference's driver calls this once per ``WINDOW_SIZE`` frames and adds the losses up before ONE backward
+        (optimize_to_joints.py:153-175) - 410 calls per epoch at 4096 frames.  The windows of an epoch are independent given the
+        parameters, so from the SECOND window requested under unchanged parameters on, all windows are evaluated in one launch
+        chain (``_EpochEval``) and this call - and every later one of the epoch - is served from it (``_epoch_window``)."""
+        wts = tuple(float(w) for w in weights)
+        j = self._epoch_window(batch_range, wts)
+        if j is not None:
+            total, objs = self._epoch["losses"][j], self._epoch["objs_win"][j]
+        else:
+            total, objs = _FitWindow.apply(self, list(batch_range), list(wts), 0.0, self.betas, self.log_beta_scales,
+                                           self.betas_trans, self._pose_leaf(), self.trans, self.fov)
+        terms = objs.unbind(0)
         out = {}
         for k, name in enumerate(OBJ_NAMES):
-            w = float(weights[{"joint": 0, "sil_reproj": 1, "betas": 2, "pose": 3, "limit": 4, "splay": 5}[name]])
-            if w > 0 and not (name == "sil_reproj" and self.rgb_only):
-                out[name] = objs[k]
+            if wts[_WEIGHT_OF[name]] > 0 and not (name == "sil_reproj" and self.rgb_only):
+                out[name] = terms[k]
         return total, out
+
+    # ---- one evaluation per epoch behind the per-window forward() ------------------------------------------------
+    def _state_key(self, wts):
+        """Everything a cached epoch depends on: the parameters (identity + in-place version counter: ``optimizer.step()`` and
+        ``param[...] = x`` bump it), which of them train, loss weights, targets, masks, cameras and rasteriser settings.  Edits that
+        bypass the counter (``param.data[...] = x``) need ``invalidate_epoch()``."""
+        ps = (self.betas, self.log_beta_scales, self.betas_trans, self.global_rotation, self.joint_rotations, self.trans, self.fov)
+        cam, rs = self.renderer.cameras, self.renderer.raster_settings
+        tv = lambda t: None if t is None else (t.data_ptr(), t._version)  # noqa: E731
+        return (wts, tuple((id(q), q._version, q.requires_grad) for q in ps), self._signature(), tv(self.global_mask), tv(self.rotation_mask),
+                tv(cam.R), tv(cam.T), tv(cam.aspect_ratio), self.propagate_scaling, self.rgb_only,
+                (float(rs.blur_radius), float(rs.sigma), int(rs.faces_per_pixel), float(rs.z_clip), int(rs.tie_rule)))
+
+    def invalidate_epoch(self):
+        """Forget the cached epoch (after editing a parameter through ``.data`` or any other route autograd's version counters miss)."""
+        self.__dict__["_epoch"] = None
+
+    def _epoch_window(self, batch_range, wts):
+        """Index of ``batch_range`` among the windows of the cached epoch evaluation, or None when this call has to be evaluated on
+        its own.  Policy: the first window requested under a new parameter state is evaluated directly (a caller that only ever asks
+        for one window per state - stochastic mini-batches - never pays for a whole batch); the second one switches the epoch to the
+        whole-batch evaluation, and once an epoch has been served that way the next one starts with it at its first window."""
+        W = int(self.batch_size) if self.batch_size else 0
+        N = self.num_images
+        n = len(batch_range)
+        if not self.epoch_cache or W <= 0 or n == 0 or N <= W:
+            return None
+        j0 = int(batch_range[0])
+        if j0 % W or n != min(W, N - j0) or int(batch_range[-1]) != j0 + n - 1 or self.frame0 % W:
+            return None
+        if isinstance(batch_range, range):
+            if batch_range.step != 1:
+                return None
+        elif any(int(b) != j0 + k for k, b in enumerate(batch_range)):
+            return None
+        key = self._state_key(wts)
+        ep = self.__dict__.get("_epoch")
+        if ep is not None and ep["key"] == key:
+            if ep["losses"] is None:  # second window of this state: evaluate them all now
+                self._evaluate_epoch(ep, wts, W)
+            ep["served"] += 1
+            return j0 // W
+        eager = ep is not None and ep["losses"] is not None  # the last state saw a second window: it was served from one evaluation
+        ep = self.__dict__["_epoch"] = dict(key=key, losses=None, objs_win=None, served=0)
+        if not eager:
+            return None
+        self._evaluate_epoch(ep, wts, W)
+        ep["served"] += 1
+        return j0 // W
+
+    def _evaluate_epoch(self, ep, wts, W):
+        ep["losses"], ep["objs_win"] = _EpochEval.apply(self, list(wts), W, self.betas, self.log_beta_scales, self.betas_trans,
+                                                        self._pose_leaf(), self.trans, self.fov)
 
     def _pose_leaf(self):
         """Autograd handle tying the fused pose gradient to the two rotation Parameters."""
@@ -515,6 +643,7 @@ class SMALFitter(nn.Module):
             items.append((p, g.contiguous(), st["m"], st["v"], lr, self._adam_step - st["t0"]))
         if items:  # one launch for all of them
             engine.adam_step_multi(items, h["betas"][0], h["betas"][1], h["eps"])
+            self.__dict__["_epoch"] = None  # (written through .data: the parameters' version counters do not move)
 
     def fit_step(self, weights, w_temp: float, window: Optional[int] = None, halo_prev=None, halo_next=None,
                  shared_grad_hook=None, halo=None):
@@ -578,6 +707,7 @@ class SMALFitter(nn.Module):
         # user of the device's shared workspace, and make the next user wait for them)
         self.device_model._claim_workspace(g["last_launch"])
         g["graph"].replay()
+        self.__dict__["_epoch"] = None
         return g["objs"]
 
     def _capture_step(self, weights, w_temp, window, ranks=None):
@@ -670,6 +800,7 @@ class SMALFitter(nn.Module):
         if handle is not None:
             handle.wait()
         g["graph_adam"].replay()
+        self.__dict__["_epoch"] = None
         return g["objs"]
 
     def straddling_faces(self) -> int:
@@ -682,13 +813,13 @@ class SMALFitter(nn.Module):
             return 0
         st = engine.raster_stats(self.device_model, self.num_images * self.views)
         n, lost = int(st["straddling_faces"]), int(st["unclipped_faces"])
-        dropped = sum(int(cd.counter[1]) for cd in self.device_model.__dict__.get("_clip_depth_cache", {}).values())
+        cd = self.__dict__.get("_last_clip_depth")  # (the buffer of the LAST evaluation only: other sizes' counters are stale)
+        dropped = int(cd.counter.tolist()[1]) if cd is not None else 0  # (both counters in one copy)
         if dropped:  # (more cut edges in one call than ClipDepth.capacity entries: their depth gradients were left out, never silently)
             import warnings
 
-            warnings.warn(f"{dropped} depth-gradient entries of cut edges did not fit engine.ClipDepth (capacity "
-                          f"{next(iter(self.device_model._clip_depth_cache.values())).capacity}) in the last call and were dropped.",
-                          RuntimeWarning, stacklevel=2)
+            warnings.warn(f"{dropped} depth-gradient entries of cut edges did not fit engine.ClipDepth (capacity {cd.capacity}) in the "
+                          "last evaluation and were dropped.", RuntimeWarning, stacklevel=2)
         if n and not self.__dict__.get("_warned_straddling"):
             import warnings
 

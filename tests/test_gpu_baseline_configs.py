@@ -193,3 +193,58 @@ def test_config5_at_its_full_per_gpu_size(tables):
     assert peak < 200e9, f"peak device memory {peak / 1e9:.1f} GB"
     del f, lbs, ndc, li, dn, li0, dn0
     torch.cuda.empty_cache()
+
+
+def test_config2b_at_full_size_against_the_oracle(tables):
+    """cfg2b - 4096 STICK frames x 1 view @256^2 in windows of 10, the shape the north-star target and the bench headline are quoted
+    on - as ONE whole-batch evaluation (the launch size the bench times: packed gradient atomics, every tile in flight), checked
+    against the CPU oracle on its first and its last window (the last one is short: 6 frames): the six loss terms of each window
+    (``smil_window_terms``) at the north-star tolerance 1e-4, and the gradient rows of those frames' parameters against the oracle's
+    autograd - under the default tie rule at the bound of the other BASELINE shapes, under ``tie_rule = reference_queue`` (the
+    oracle's own rule) at the tight one (1e-3 of the largest component, 2e-5 rms)."""
+    from smilify_amd import engine, synthetic
+
+    t = tables("stick")
+    frames, S, W = 4096, 256, 10
+    weights = synthetic.STAGE1_WEIGHTS
+    f = synthetic.make_problem(t, frames, 1, S, DEV, radius=2.7, seed=1234, window=W)
+    m = oracle_model(t)
+    cpu = lambda x: x.detach().cpu().clone()  # noqa: E731
+    R, T = cpu(f.renderer.cameras.R), cpu(f.renderer.cameras.T)
+    oracle = {}
+    for wi, fr in ((0, range(0, W)), ((frames - 1) // W, range((frames - 1) // W * W, frames))):
+        rows = list(fr)
+        params = dict(betas=cpu(f.betas), log_beta_scales=cpu(f.log_beta_scales[rows]), betas_trans=cpu(f.betas_trans[rows]),
+                      global_rotation=cpu(f.global_rotation[rows]), trans=cpu(f.trans[rows]), joint_rotations=cpu(f.joint_rotations[rows]),
+                      fov=cpu(f.fov))
+        for k in ("global_rotation", "trans", "joint_rotations", "log_beta_scales"):
+            params[k].requires_grad_()
+        tg = dict(sil=cpu(f.sil_imgs[rows]).float(), joints=cpu(f.target_joints[rows]), visibility=cpu(f.target_visibility[rows]))
+        total, terms, _ = fitter_ref.fit_losses(m, params, range(len(rows)), weights, tg, dict(R=R, T=T), S, f.mean_betas.cpu(), f.betas_prec.cpu())
+        total.backward()
+        oracle[wi] = (rows, {k: float(v) for k, v in terms.items()}, float(total), params)
+    order = dict(joint=0, limit=1, pose=2, splay=3, betas=4, sil_reproj=5)
+    for rule in ("depth_face_id", "reference_queue"):
+        f.renderer.raster_settings = engine.raster_settings(tie_rule=rule)
+        objs, grads = f._loss_and_grads(None, weights, 0.0, window=W, window_terms=True)
+        objs_win = grads["_objs_win"].cpu().numpy()
+        assert objs_win.shape == ((frames + W - 1) // W, 6)
+        np.testing.assert_allclose(objs_win.sum(0), objs[:6].cpu().numpy(), rtol=2e-5)  # the windows add up to the iteration's terms
+        for wi, (rows, terms, total, params) in oracle.items():
+            for k, i in order.items():
+                assert abs(objs_win[wi, i] - terms[k]) <= 1e-4 * abs(terms[k]) + 1e-7, (rule, wi, k, objs_win[wi, i], terms[k])
+            assert abs(objs_win[wi].sum() - total) <= 1e-4 * abs(total), (rule, wi, objs_win[wi].sum(), total)
+            got = dict(global_rotation=grads["pose"][rows, 0], joint_rotations=grads["pose"][rows, 1:], trans=grads["trans"][rows],
+                       log_beta_scales=grads["log_beta_scales"][rows])
+            for n, g in got.items():
+                ref = params[n].grad.numpy()
+                a = g.cpu().numpy().reshape(ref.shape)
+                if rule == "reference_queue":
+                    err = np.abs(a - ref) / np.abs(ref).max()
+                    assert err.max() < 1e-3 and np.sqrt((err ** 2).mean()) < 2e-5, (rule, wi, n, err.max(), np.sqrt((err ** 2).mean()))
+                else:
+                    cos = float((a * ref).sum() / (np.linalg.norm(a) * np.linalg.norm(ref) + 1e-30))
+                    rel = float(np.linalg.norm(a - ref) / (np.linalg.norm(ref) + 1e-30))
+                    assert cos > 0.9999 and rel < 1e-2, (rule, wi, n, cos, rel)
+        if rule == "reference_queue":
+            assert engine.raster_stats(f.device_model, frames)["tie_pixels"] > 0

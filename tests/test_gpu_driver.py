@@ -156,7 +156,9 @@ def test_four_ranks_on_one_gpu_follow_one_rank():
     four = _run_bench("--gpus", "4", "--backend", "gloo", "--share-gpu", *common)
     one = _run_bench("--gpus", "1", "--frames", "64", *common)
     assert four["n_gpus"] == 4 and four["rehearsal"] is True and four["config"]["frames_per_gpu"] == 16
-    assert abs(four["value"] - 4 * 16 / (four["ms_per_step"] * 1e-3)) <= 1e-6 * four["value"]  # whole-job frames per second
+    assert abs(four["frame_iters_per_sec"] - 4 * 16 / (four["ms_per_step"] * 1e-3)) <= 1e-6 * four["frame_iters_per_sec"]  # whole-job frames per second
+    assert abs(four["value"] - 4 * 1000.0 / four["ms_per_step"]) <= 1e-6 * four["value"]  # BASELINE's metric: fit iterations per second, summed over the GPUs
+    assert four["rccl_ranks"] == 0 and len(four["rank_ms_per_step"]["all"]) == 4  # (gloo rehearsal: no RCCL ranks)
     assert abs(four["final_loss"] - one["final_loss"]) <= 2e-4 * abs(one["final_loss"]), (four["final_loss"], one["final_loss"])
 
 
@@ -254,3 +256,54 @@ def test_two_stage_schedule_follows_the_reference_trajectory(use_graph, tables):
         a, b = getattr(f, name).detach().cpu().numpy(), params[name].detach().numpy().reshape(getattr(f, name).shape)
         d = np.abs(a - b)
         assert np.median(d) < 2e-4 and np.mean(d < 3e-3) > 0.97, (name, np.median(d), d.max())
+
+
+def _reference_epoch(model, N, W, weights, w_temp, window_weight=None):
+    """One epoch body of optimize_to_joints.py:153-172 without the optimiser step: per-window losses, total, parameter gradients."""
+    for p in model.parameters():
+        p.grad = None
+    acc, per_window, terms = 0, [], []
+    for k, j in enumerate(range(0, N, W)):
+        loss, objs = model(list(range(j, min(N, j + W))), weights, 1)
+        per_window.append(float(loss))
+        terms.append({n: float(v) for n, v in objs.items()})
+        acc = acc + loss.mean() * (1.0 if window_weight is None else window_weight[k])
+    jl, gl, tl = model.get_temporal(w_temp)
+    (acc + jl + gl + tl).backward()
+    grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+    return per_window, terms, float(acc), grads
+
+
+@pytest.mark.parametrize("frames,window", [(7, 2), (8, 4)])
+def test_forward_serves_an_epoch_from_one_evaluation(tables, frames, window):
+    """The per-window forward() calls of the reference's loop are answered from ONE whole-batch evaluation (SMALFitter._epoch_window):
+    same window losses, same terms, same parameter gradients as the window-by-window evaluation - also when the windows are weighted
+    differently or one is left out (the correction path of _EpochEval.backward), and a parameter update starts a new epoch."""
+    from smilify_amd import synthetic
+
+    t = tables("synthetic")
+    weights, w_temp = [10.0, 500.0, 1.0, 1.0, 100.0, 0.1], 100.0
+    n_win = (frames + window - 1) // window
+    for ww in (None, [1.0 + 0.5 * k for k in range(n_win)], [0.0] + [1.0] * (n_win - 1)):
+        a = synthetic.make_problem(t, frames, 1, 40, DEV, radius=2.2, seed=5, window=window)
+        b = synthetic.make_problem(t, frames, 1, 40, DEV, radius=2.2, seed=5, window=window)
+        b.epoch_cache = False
+        opt_a = torch.optim.Adam(a.parameters(), lr=5e-3, betas=(0.5, 0.999))
+        opt_b = torch.optim.Adam(b.parameters(), lr=5e-3, betas=(0.5, 0.999))
+        for epoch in range(3):
+            la, ta, acc_a, ga = _reference_epoch(a, frames, window, weights, w_temp, ww)
+            lb, tb, acc_b, gb = _reference_epoch(b, frames, window, weights, w_temp, ww)
+            if epoch > 0:
+                assert a._epoch is not None and a._epoch["served"] == n_win, "the second epoch was not served from one evaluation"
+            np.testing.assert_allclose(la, lb, rtol=2e-5)
+            for da, db in zip(ta, tb):
+                assert da.keys() == db.keys()
+                np.testing.assert_allclose([da[k] for k in da], [db[k] for k in da], rtol=2e-5, atol=1e-7)
+            for n in gb:
+                assert (ga[n] is None) == (gb[n] is None), n
+                if gb[n] is not None:
+                    scale = float(gb[n].abs().max()) + 1e-12
+                    assert float((ga[n] - gb[n]).abs().max()) <= 2e-4 * scale, (n, epoch, ww)
+            opt_a.step()
+            opt_b.step()
+        np.testing.assert_allclose(a.trans.detach().cpu().numpy(), b.trans.detach().cpu().numpy(), atol=2e-6)

@@ -56,4 +56,4 @@ for w in ("cfg2b", "cfg2", "cfg3", "cfg4", "cfg5s"):
     p = os.path.join(dst, f"{tag}_bench_{w}.json")
     if os.path.exists(p):
         d = json.load(open(p))
-        print(w, f"{d['ms_per_step']:.2f} ms/step  {d['value']:.0f} {d['unit']}  kernel {d['roofline']['kernel_ms']:.2f} ms  frac {d['roofline']['frac']:.4f}")
+        print(w, f"{d['ms_per_step']:.2f} ms/step  {d['value']:.2f} fit-iters/s ({d.get('frame_iters_per_sec', 0):.0f} frame-iters/s)  kernel {d['roofline']['kernel_ms']:.2f} ms  frac {d['roofline']['frac']:.4f}")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rasteriser call (setup + tile kernel) at 1 ... 32 images: tools/dbg/r5_small.sh <name>...   ("main" = libsmilfit.so)
+# rasteriser call (setup + tile kernel) at 1 ... 32 images: tools/dbg/small_launches.sh <name>...   ("main" = libsmilfit.so)
 cd "$GRAFT_REPO_ROOT"; L=$PWD/smilify_amd/lib
 for v in "$@"; do
   lib=$L/libsmilfit_$v.so; [ "$v" = main ] && lib=$L/libsmilfit.so

@@ -985,45 +985,6 @@ __device__ __forceinline__ Tri9 load_tri(const RasterArgs &a, const float *__res
     const float *p0 = vertex_ptr(vn, xv_n, a.V, i0), *p1 = vertex_ptr(vn, xv_n, a.V, i1), *p2 = vertex_ptr(vn, xv_n, a.V, i2);
     return Tri9{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2]};
 }
-// ---- hand-scheduled prefetch of pass 1 (round 6) -------------------------------------------------------------------------------
-// gfx950 counts loads, stores and atomics in ONE in-order counter (vmcnt).  Pass 1 requests the next chunk's vertices / vertex ids /
-// list entry one chunk ahead, across the pair sweep - a loop that appends records with an unknown number of stores.  The compiler
-// cannot count those, so it waited for (nearly) ALL of them before it touched the prefetched registers: every chunk began with the
-// drain of the previous sweep's stores (cut-off builds, profiles/r6_experiments.md: pass 1 with its stores 7.56 ms, without 6.21).
-// These loads are therefore issued by inline assembly - invisible to the compiler's wait insertion - and waited for by hand with
-// `s_waitcnt vmcnt(n)`, n = a LOWER bound on the memory instructions issued after them (the sweep's stores, counted as they are
-// issued): completion is in order, so "at most n outstanding" means the loads, which are older than those n, have landed, while the
-// youngest n stores may still be in flight.  Rules this relies on (checked on the built code by tools/check_inflight.py):
-// the destination registers are tied through every asm statement ("+v": one register chain, no copies), nothing reads them between
-// request and wait, and every way out of the loop passes a vmcnt(0) before the registers can be given to anything else.
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-typedef int i32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void inflight_load(f32x3 &dst, const float *p) { asm volatile("global_load_dwordx3 %0, %1, off ; INFLIGHT_REQ" : "+v"(dst) : "v"(p) : "memory"); }
-__device__ __forceinline__ void inflight_load(i32x3 &dst, const int *p) { asm volatile("global_load_dwordx3 %0, %1, off ; INFLIGHT_REQ" : "+v"(dst) : "v"(p) : "memory"); }
-__device__ __forceinline__ void inflight_load(int &dst, const uint32_t *p) { asm volatile("global_load_dword %0, %1, off ; INFLIGHT_REQ" : "+v"(dst) : "v"(p) : "memory"); }
-// `later`: memory instructions certainly issued after the requests (wave-uniform).  Any n <= later is safe; the ladder keeps it to a few
-// scalar compares.  The waits themselves carry no operands (one register chain through the loop: the requests and the ONE statement
-// below that hands the landed values over).
-__device__ __forceinline__ void inflight_wait(uint32_t later, f32x3 &t0, f32x3 &t1, f32x3 &t2, i32x3 &ids, int &f) {
-    if (later >= 48u) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-    else if (later >= 24u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (later >= 12u) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (later >= 6u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (later >= 3u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("; INFLIGHT_LANDED" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(ids), "+v"(f) : : "memory");
-}
-__device__ __forceinline__ void inflight_drain(f32x3 &t0, f32x3 &t1, f32x3 &t2, i32x3 &ids, int &f) {
-    asm volatile("s_waitcnt vmcnt(0) ; INFLIGHT_DRAIN" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(ids), "+v"(f) : : "memory");
-}
-// a landed value taken out of the chain's registers (a copy the compiler can neither fold away nor move in front of the wait): the
-// chain's registers are then free for the next request, and nothing that outlives the request keeps them alive
-__device__ __forceinline__ float inflight_take(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-__device__ __forceinline__ int inflight_take(int x) { int r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-__device__ __forceinline__ const int *face_ptr(const int *__restrict__ faces, const int *__restrict__ xf_n, int F, int f) {
-    return f < F ? faces + 3 * f : xf_n + 3 * (f - faces_padded(F));
-}
-
 // The seven rows of a face record from its vertices, in two halves (stage_faces: one lane each).  Every rounding is spelled out -
 // no contraction left to the compiler (which fuses a*b - c*d one way in one inlining context and another way in the next): the
 // tile kernel and k_raster_tie_replay must get the SAME bits from the same face, or an exact depth tie in one is no tie in the other.
@@ -1445,22 +1406,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
             auto list_at = [&](int c) { return (int)lst[min(c + slot_, list_total - 1)]; };
             // (round 4: one more link ahead - the VERTICES of chunk k + 1 are requested before chunk k is evaluated and wait in nine
             // registers, so a chunk starts with the drain of the previous sweep's stores only, not with a vertex fetch behind it)
-            // (round 6: these requests are issued and waited for by hand, see inflight_load; the registers they land in are written by
-            // nothing else, so the compiler has no load of its own to wait for on them)
-            int f_nx = 0;
-            i32x3 id_nx = {0, 0, 0};     // vertex ids of chunk k + 1 ...
-            int ja, jb, jc;              // ... and of chunk k
-            f32x3 t0_nx = {0.f, 0.f, 0.f}, t1_nx = {0.f, 0.f, 0.f}, t2_nx = {0.f, 0.f, 0.f};  // vertices of chunk k (requested one chunk ahead)
+            int f_nx = list_at(2 * DCHUNK);
+            int ia, ib, ic;      // vertex ids of chunk k + 1 ...
+            int ja, jb, jc;      // ... and of chunk k
+            Tri9 tv_nx;          // vertices of chunk k (requested one chunk ahead)
             { const int f_ = list_at(0); ja = face_vertex(a.faces, xf_n, a.F, f_, 0); jb = face_vertex(a.faces, xf_n, a.F, f_, 1); jc = face_vertex(a.faces, xf_n, a.F, f_, 2); }
-            {
-                const int f_ = list_at(DCHUNK);
-                inflight_load(t0_nx, vertex_ptr(vn, xv_n, a.V, ja));
-                inflight_load(t1_nx, vertex_ptr(vn, xv_n, a.V, jb));
-                inflight_load(t2_nx, vertex_ptr(vn, xv_n, a.V, jc));
-                inflight_load(id_nx, face_ptr(a.faces, xf_n, a.F, f_));
-                inflight_load(f_nx, lst + min(2 * DCHUNK + slot_, list_total - 1));
-            }
-            uint32_t later = 0u;  // memory instructions issued since the requests in flight
+            { const int f_ = list_at(DCHUNK); ia = face_vertex(a.faces, xf_n, a.F, f_, 0); ib = face_vertex(a.faces, xf_n, a.F, f_, 1); ic = face_vertex(a.faces, xf_n, a.F, f_, 2); }
+            tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);
             for (int c0 = 0; c0 < list_total; c0 += DCHUNK) {
                 if (may_truncate) {
                     // digit of this chunk's first face = number of buckets that start at or before it, minus one
@@ -1483,18 +1435,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                 }
                 const int m = min(DCHUNK, list_total - c0);
                 int cf, packed2, packed = 0;
-                inflight_wait(later, t0_nx, t1_nx, t2_nx, id_nx, f_nx);  // what the chunk before requested has landed
                 const int i0 = ja, i1 = jb, i2 = jc;
-                const Tri9 tv = Tri9{inflight_take(t0_nx.x), inflight_take(t0_nx.y), inflight_take(t0_nx.z), inflight_take(t1_nx.x), inflight_take(t1_nx.y),
-                                     inflight_take(t1_nx.z), inflight_take(t2_nx.x), inflight_take(t2_nx.y), inflight_take(t2_nx.z)};  // this chunk's vertices
-                ja = inflight_take(id_nx.x); jb = inflight_take(id_nx.y); jc = inflight_take(id_nx.z);
-                const int f_ids = inflight_take(f_nx);
-                inflight_load(t0_nx, vertex_ptr(vn, xv_n, a.V, ja));  // chunk c0 + DCHUNK
-                inflight_load(t1_nx, vertex_ptr(vn, xv_n, a.V, jb));
-                inflight_load(t2_nx, vertex_ptr(vn, xv_n, a.V, jc));
-                inflight_load(id_nx, face_ptr(a.faces, xf_n, a.F, f_ids));  // chunk c0 + 2 DCHUNK
-                inflight_load(f_nx, lst + min(c0 + 3 * DCHUNK + slot_, list_total - 1));
-                later = 0u;
+                const Tri9 tv = tv_nx;                       // this chunk's vertices (in flight since the chunk before)
+                ja = ia; jb = ib; jc = ic;
+                tv_nx = load_tri(a, vn, xv_n, ja, jb, jc);  // chunk c0 + DCHUNK
+                ia = face_vertex(a.faces, xf_n, a.F, f_nx, 0); ib = face_vertex(a.faces, xf_n, a.F, f_nx, 1); ic = face_vertex(a.faces, xf_n, a.F, f_nx, 2);  // chunk c0 + 2 DCHUNK
+                f_nx = list_at(c0 + 3 * DCHUNK);
                 stage_faces(a, tv, i0, i1, i2, m, lds.rec, lane, cx, cy, fS, tx, ty, ox0, ox1, oy0, oy1, open_px, cf, packed2, sxy, sid, c0, a.list_stride);
                 set_chunk_start(c0 / DCHUNK, (uint32_t)vbase);
                 chunks_done = c0 / DCHUNK + 1;
@@ -1587,12 +1533,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                         }
                     }
                     vbase += __popcll(cm0) + __popcll(cm1);
-                    later += (cm0 != 0ull ? 1u : 0u) + (cm1 != 0ull ? 1u : 0u);  // record stores issued by this step
                 }
                 TSWEEP_MARK
                 lds_fence();  // rec is rewritten by the next chunk
             }
-            inflight_drain(t0_nx, t1_nx, t2_nx, id_nx, f_nx);  // (every way out of the walk: nothing lands in a register that has moved on)
             if (!fits) {  // wave-uniform: try again with half the pixels
                 span >>= 1;
                 __syncthreads();

@@ -1508,11 +1508,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_raster_dense(RasterArgs 
                         zb0 = min(max(__float_as_uint(vmax_raw(z2.x, zf)), kmin), kmax);
                         zb1 = min(max(__float_as_uint(vmax_raw(z2.y, zf)), kmin), kmax);
                     }
-                    // both records of a lane go next to each other (left pixel first): the stream stays in face-major, row-major
-                    // order, the order one pair per lane produced
-                    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm1,
-                                            __builtin_amdgcn_mbcnt_hi((uint32_t)(cm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm0, 0u))));
-                    const uint32_t slot0 = (uint32_t)vbase + before, slot1 = slot0 + (cand0 ? 1u : 0u);
+                    // a step's left-pixel records first, then its right-pixel records: each of the two store instructions writes ONE
+                    // contiguous run of 12-byte records (interleaved - a lane's two records next to each other - both instructions
+                    // touched every cache line of the step's run, each with half of the bytes: the record stores are 1.35 ms of the
+                    // cfg2b launch, profiles/r6_experiments.md).  No sweep depends on the order of the records inside a chunk.
+                    const uint32_t slot0 = (uint32_t)vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm0, 0u));
+                    const uint32_t slot1 = (uint32_t)vbase + (uint32_t)__popcll(cm0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm1, 0u));
                     const uint32_t meta = (uint32_t)p | ((uint32_t)(c0 + fs) << 6);
                     if (cand0) {
                         st_stream(srec, slot0, Rec3{zb0, meta | (e.inside0 ? 1u << 22 : 0u) | e.ebits0, __float_as_uint(e.sd.x)});
@@ -2065,8 +2066,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 #define TIE_ORD_CAP 2048  // faces of a tile's list that the replay puts in order at once (longer lists: 64 bitmap words = up to 2 048 faces at a time)
 #endif
 static_assert(TIE_ORD_CAP % 64 == 0 && TIE_ORD_CAP / 32 <= WAVE && TIE_ORD_CAP >= 64 * 32, "the high bits of the ordered ids are cleared by one wave; a segment of 64 bitmap words fits");
+#ifndef TIE_WAVES_PER_SIMD
+#define TIE_WAVES_PER_SIMD 5  // replay waves a SIMD holds: 96 registers each, nothing spilled (6 -> 80 registers, 17 of them spilled)
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(64) k_raster_tie_replay(RasterArgs a) {
+__global__ void __launch_bounds__(64, TIE_WAVES_PER_SIMD) k_raster_tie_replay(RasterArgs a) {
     const int lane = threadIdx.x;
     const int K = a.K;  // <= SMIL_MAX_FACES_PER_PIXEL = 128: two queue slots per lane
     const int n_tiles = a.tiles_x * a.tiles_x;
@@ -2646,8 +2650,8 @@ template <int MODE>
 static void launch_tie_replay(const RasterArgs &a, hipStream_t stream) {
     // dynamic LDS: the face-id bitmap (FT bits), the filling queue (128 slots x 3 words), the tile's ordered face ids (17 bits each)
     const size_t lds = (size_t)a.FT / 8 + 6 * WAVE * sizeof(uint32_t) + (size_t)TIE_ORD_CAP * sizeof(uint16_t) + TIE_ORD_CAP / 8;
-    // (76 VGPRs: six waves per SIMD, which the ~6 - 8 KB of LDS allow as well; the waves take tickets until none is left)
-    if (a.tie_rule) hipLaunchKernelGGL((k_raster_tie_replay<MODE>), dim3((unsigned int)device_cus() * 24u), dim3(64), lds, stream, a);
+    // (as many waves as the registers let a CU hold - the ~6 KB of LDS per wave allow more; they take tickets until none is left)
+    if (a.tie_rule) hipLaunchKernelGGL((k_raster_tie_replay<MODE>), dim3((unsigned int)device_cus() * 4u * TIE_WAVES_PER_SIMD), dim3(64), lds, stream, a);
 }
 
 extern "C" int smil_silhouette_forward(const SmilModel *m, const float *verts_ndc, int32_t N, int32_t S,

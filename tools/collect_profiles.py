@@ -51,6 +51,37 @@ if tr:
         for r in rows[a + 1:b + 1]:
             fh.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} us +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  {r['Kernel_Name'][:100]}\n")
         fh.write(f"{b - a} launches; {(int(rows[b]['End_Timestamp']) - int(rows[a]['End_Timestamp'])) / 1e3:.1f} us from optimiser step to optimiser step (under the profiler)\n")
+
+# Register / LDS / spill figures of every rasteriser and LBS kernel, straight from the compiler's resource remarks on the shipped sources
+# (DESIGN.md section 4.1 quotes this file instead of hand-copied numbers)
+import re
+
+hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+lines = []
+for unit in ("raster.hip", "lbs.hip", "fit.hip", "project.hip"):
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(REPO, "include"), "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(REPO, "smilify_amd", "csrc", unit), "-o", os.devnull],
+                       capture_output=True, text=True)
+    cur = {}
+    for ln in r.stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|SGPRs Spill|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", ln)
+        if not m:
+            continue
+        if m.group(1) == "Function Name":
+            if cur:
+                lines.append(cur)
+            cur = {"unit": unit, "kernel": subprocess.run(["c++filt", m.group(2)], capture_output=True, text=True).stdout.strip() or m.group(2)}
+        else:
+            cur[m.group(1)] = m.group(2)
+    if cur:
+        lines.append(cur)
+if lines:
+    with open(os.path.join(dst, f"{tag}_kernel_resources.txt"), "w") as fh:
+        fh.write("hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage on smilify_amd/csrc (static LDS only; dynamic LDS is set at launch)\n")
+        fh.write(f"{'kernel':70s} VGPRs AGPRs vgpr_spill sgpr_spill scratch_B/lane waves/SIMD static_LDS_B\n")
+        for c in lines:
+            fh.write(f"{c['kernel'][:70]:70s} {c.get('VGPRs', '?'):>5s} {c.get('AGPRs', '?'):>5s} {c.get('VGPRs Spill', '?'):>10s} {c.get('SGPRs Spill', '?'):>10s} "
+                     f"{c.get('ScratchSize [bytes/lane]', '?'):>14s} {c.get('Occupancy [waves/SIMD]', '?'):>10s} {c.get('LDS Size [bytes/block]', '?'):>12s}\n")
 print(sorted(os.path.basename(p) for p in glob.glob(os.path.join(dst, f"{tag}_*"))))
 for w in ("cfg2b", "cfg2", "cfg3", "cfg4", "cfg5s"):
     p = os.path.join(dst, f"{tag}_bench_{w}.json")

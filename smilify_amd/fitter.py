@@ -83,11 +83,11 @@ _WEIGHT_OF = {"joint": 0, "sil_reproj": 1, "betas": 2, "pose": 3, "limit": 4, "s
 
 
 class _EpochEval(torch.autograd.Function):
-    """Every window of an epoch in ONE evaluation: ``(losses (windows,), terms (windows, 6))``.  The per-window ``forward`` calls
-    of the reference's driver index into these; autograd adds their upstream gradients up into one vector, so backward runs once
-    per epoch.  With the same upstream gradient on every window (the driver adds the window losses with weight 1) the whole-batch
-    gradients are the answer; windows whose upstream gradient differs (left out, weighted differently) are corrected by a direct
-    evaluation of just those windows - exact for every use of ``forward``."""
+    """Every window of an epoch in ONE evaluation: one loss scalar per window + the terms (windows, 6).  The per-window ``forward``
+    calls of the reference's driver hand these out; autograd brings every window's upstream gradient to ONE backward per epoch (each
+    window is an output of this node: no select / scatter nodes in between).  With the same upstream gradient on every window (the
+    driver adds the window losses with weight 1) the whole-batch gradients are the answer; windows whose upstream gradient differs
+    (left out, weighted differently) are handled exactly - see ``backward``."""
 
     @staticmethod
     def forward(ctx, fitter, weights, window, betas, log_beta_scales, betas_trans, pose, trans, fov):
@@ -95,21 +95,29 @@ class _EpochEval(torch.autograd.Function):
         objs_win = grads.pop("_objs_win")
         ctx.fitter, ctx.weights, ctx.window, ctx.grads = fitter, weights, window, grads
         ctx.key = fitter._state_key(tuple(weights))
+        ctx.set_materialize_grads(False)  # (a window nobody used arrives as None, not as a zero tensor)
         ctx.mark_non_differentiable(objs_win)
-        return objs_win.sum(1), objs_win
+        return (*objs_win.sum(1).unbind(0), objs_win)
 
     @staticmethod
-    def backward(ctx, g_losses, _g_terms):
+    def backward(ctx, *upstream):
         # sum_j g_j G_j.  Rows of per-frame parameters belong to one window each: they are scaled by their window's upstream value
         # (exact, also for a window left out: its rows are exactly zero).  Shared parameters (betas, a shared fov or scale table):
         # c G_total + sum_{g_j != c} (g_j - c) G_j with c the most frequent upstream value - nothing to correct in the driver's loop,
         # one direct evaluation per deviating window otherwise (the window an epoch's first call evaluated on its own, ...).
         f, W = ctx.fitter, ctx.window
         N, views = f.num_images, f.views
-        vals = g_losses.tolist()  # (the one host sync of an epoch's backward)
+        g_win = upstream[:-1]
+        used = [t for t in g_win if t is not None]
+        if not used:
+            return (None,) * 9
+        it = iter(torch.stack(used).tolist())  # (the one host sync of an epoch's backward)
+        vals = [0.0 if t is None else next(it) for t in g_win]
         c = Counter(vals).most_common(1)[0][0]
         deviating = [(j, gj) for j, gj in enumerate(vals) if gj != c]
-        per_row = lambda t, rep: t * g_losses.repeat_interleave(rep)[:t.shape[0]].reshape((-1,) + (1,) * (t.dim() - 1))  # noqa: E731
+        if deviating:
+            g_losses = torch.tensor(vals, dtype=torch.float32, device=f.device)
+            per_row = lambda t, rep: t * g_losses.repeat_interleave(rep)[:t.shape[0]].reshape((-1,) + (1,) * (t.dim() - 1))  # noqa: E731
         out, shared = {}, []
         for k, v in ctx.grads.items():
             if v is None:
@@ -504,7 +512,7 @@ class SMALFitter(nn.Module):
         wts = tuple(float(w) for w in weights)
         j = self._epoch_window(batch_range, wts)
         if j is not None:
-            total, objs = self._epoch["losses"][j], self._epoch["objs_win"][j]
+            total, objs = self._epoch["losses"][j], self._epoch["objs_win"][j]  # (a tuple of scalars: no autograd node per window)
         else:
             total, objs = _FitWindow.apply(self, list(batch_range), list(wts), 0.0, self.betas, self.log_beta_scales,
                                            self.betas_trans, self._pose_leaf(), self.trans, self.fov)
@@ -519,13 +527,18 @@ class SMALFitter(nn.Module):
     def _state_key(self, wts):
         """Everything a cached epoch depends on: the parameters (identity + in-place version counter: ``optimizer.step()`` and
         ``param[...] = x`` bump it), which of them train, loss weights, targets, masks, cameras and rasteriser settings.  Edits that
-        bypass the counter (``param.data[...] = x``) need ``invalidate_epoch()``."""
-        ps = (self.betas, self.log_beta_scales, self.betas_trans, self.global_rotation, self.joint_rotations, self.trans, self.fov)
-        cam, rs = self.renderer.cameras, self.renderer.raster_settings
-        tv = lambda t: None if t is None else (t.data_ptr(), t._version)  # noqa: E731
-        return (wts, tuple((id(q), q._version, q.requires_grad) for q in ps), self._signature(), tv(self.global_mask), tv(self.rotation_mask),
-                tv(cam.R), tv(cam.T), tv(cam.aspect_ratio), self.propagate_scaling, self.rgb_only,
-                (float(rs.blur_radius), float(rs.sigma), int(rs.faces_per_pixel), float(rs.z_clip), int(rs.tie_rule)))
+        bypass the counter (``param.data[...] = x``) need ``invalidate_epoch()``.  (Called once per ``forward``: plain attribute reads.)"""
+        P = self._parameters
+        b, ls, bt, gr, jr, tr, fv = P["betas"], P["log_beta_scales"], P["betas_trans"], P["global_rotation"], P["joint_rotations"], P["trans"], P["fov"]
+        cam = self.renderer.cameras
+        R, T, asp, canon = cam.R, cam.T, cam.aspect_ratio, self.config.CANONICAL_MODEL_JOINTS
+        tv, tj, si, gm, rm = self.target_visibility, self.target_joints, self.sil_imgs, self.global_mask, self.rotation_mask
+        return (wts, id(b), b._version, b.requires_grad, id(ls), ls._version, ls.requires_grad, id(bt), bt._version, bt.requires_grad,
+                id(gr), gr._version, gr.requires_grad, id(jr), jr._version, jr.requires_grad, id(tr), tr._version, tr.requires_grad,
+                id(fv), fv._version, fv.requires_grad, id(tv), tv._version, id(tj), tj._version, id(si), None if si is None else si._version,
+                id(canon), len(canon), gm.data_ptr(), gm._version, rm.data_ptr(), rm._version, R.data_ptr(), R._version, T.data_ptr(), T._version,
+                None if asp is None else (asp.data_ptr(), asp._version), self.propagate_scaling, self.rgb_only,
+                bytes(self.renderer.raster_settings))
 
     def invalidate_epoch(self):
         """Forget the cached epoch (after editing a parameter through ``.data`` or any other route autograd's version counters miss)."""
@@ -542,12 +555,12 @@ class SMALFitter(nn.Module):
         if not self.epoch_cache or W <= 0 or n == 0 or N <= W:
             return None
         j0 = int(batch_range[0])
-        if j0 % W or n != min(W, N - j0) or int(batch_range[-1]) != j0 + n - 1 or self.frame0 % W:
+        if j0 % W or n != min(W, N - j0) or self.frame0 % W:
             return None
-        if isinstance(batch_range, range):
-            if batch_range.step != 1:
-                return None
-        elif any(int(b) != j0 + k for k, b in enumerate(batch_range)):
+        wl = self.__dict__.get("_win_lists")
+        if wl is None or wl[0] != (N, W):
+            wl = self.__dict__["_win_lists"] = ((N, W), [list(range(j, min(N, j + W))) for j in range(0, N, W)])
+        if (batch_range if type(batch_range) is list else [int(b) for b in batch_range]) != wl[1][j0 // W]:
             return None
         key = self._state_key(wts)
         ep = self.__dict__.get("_epoch")
@@ -565,8 +578,8 @@ class SMALFitter(nn.Module):
         return j0 // W
 
     def _evaluate_epoch(self, ep, wts, W):
-        ep["losses"], ep["objs_win"] = _EpochEval.apply(self, list(wts), W, self.betas, self.log_beta_scales, self.betas_trans,
-                                                        self._pose_leaf(), self.trans, self.fov)
+        out = _EpochEval.apply(self, list(wts), W, self.betas, self.log_beta_scales, self.betas_trans, self._pose_leaf(), self.trans, self.fov)
+        ep["losses"], ep["objs_win"] = out[:-1], out[-1]
 
     def _pose_leaf(self):
         """Autograd handle tying the fused pose gradient to the two rotation Parameters."""

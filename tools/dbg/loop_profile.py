@@ -1,0 +1,43 @@
+"""cProfile of the reference-style driver loop (bench.py time_reference_loop) on cfg2: where the host time of an epoch goes."""
+import cProfile, os, pstats, sys, time
+import torch
+REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, REPO)
+from smilify_amd import model_io, synthetic
+tables = model_io.load_model(os.path.join(REPO, "data", "models", "SMILy_STICK.npz"))
+n, window = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 10
+model = synthetic.make_problem(tables, n, 1, 256, "cuda:0", radius=2.7, seed=1234, window=window)
+weights, w_temp, lr = synthetic.STAGE1_WEIGHTS, synthetic.STAGE1_TEMPORAL, synthetic.STAGE1_LR
+opt = torch.optim.Adam([{"params": [p for name, p in model.named_parameters() if name != "fov"], "lr": lr}, {"params": [model.fov], "lr": 1}], lr=lr, betas=(0.5, 0.999))
+T = {}
+def epoch(timed=False):
+    t0 = time.perf_counter()
+    acc = 0
+    opt.zero_grad()
+    for j in range(0, n, window):
+        loss, _ = model(list(range(j, min(n, j + window))), weights, 1)
+        acc += loss.mean()
+    t1 = time.perf_counter()
+    jl, gl, tl = model.get_temporal(w_temp)
+    t2 = time.perf_counter()
+    desc = "{:.2f} ({}, {}, {})".format(acc.data, jl.data, gl.data, tl.data)
+    t3 = time.perf_counter()
+    acc = acc + jl + gl + tl
+    acc.backward()
+    t4 = time.perf_counter()
+    opt.step()
+    t5 = time.perf_counter()
+    if timed:
+        for k, v in (("forward loop", t1 - t0), ("get_temporal", t2 - t1), ("progress line (sync)", t3 - t2), ("backward", t4 - t3), ("optimizer.step", t5 - t4)):
+            T[k] = T.get(k, 0.0) + v
+for _ in range(5): epoch()
+torch.cuda.synchronize()
+E = 50
+t0 = time.perf_counter()
+for _ in range(E): epoch(True)
+torch.cuda.synchronize()
+print(f"{1e3 * (time.perf_counter() - t0) / E:.3f} ms per epoch;", {k: round(1e3 * v / E, 3) for k, v in T.items()})
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20): epoch()
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy
 PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 1024  # 256 CUs x 4 SIMD-32: one wave64 VALU instruction occupies a SIMD's pipe for 2 cycles
-TRAFFIC_FILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")  # PMC counts per launch (tools/pmc_traffic.sh); the newest that exists is used
+TRAFFIC_FILES = ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")  # PMC counts per launch (tools/pmc_traffic.sh); the newest that exists is used
 PARITY_TOL = 1e-4  # north star: fp32 losses within 1e-4 relative of the reference algorithm (here: its CPU oracle)
 
 

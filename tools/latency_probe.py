@@ -14,7 +14,10 @@ for B in (1, 8, 64, 512):
         f.begin_stage(5e-3)
         step = f.fit_step_graph if mode == "graph" else f.fit_step
         for _ in range(3): step(synthetic.STAGE1_WEIGHTS, 100.0)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(30): step(synthetic.STAGE1_WEIGHTS, 100.0)
-        torch.cuda.synchronize(); out.append((time.perf_counter() - t0) / 30 * 1e3)
+        blocks = []
+        for _ in range(7):  # median of seven blocks of 30 iterations (a shared box shows a slow block now and then)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30): step(synthetic.STAGE1_WEIGHTS, 100.0)
+            torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / 30 * 1e3)
+        out.append(sorted(blocks)[3])
     print(f"B={B}: fit_step {out[0]:.3f} ms   fit_step_graph {out[1]:.3f} ms" + (f"   [tie_rule {TIE}]" if TIE else ""))

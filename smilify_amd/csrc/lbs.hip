@@ -74,20 +74,54 @@ __device__ __forceinline__ void rodrigues_bwd(float tx, float ty, float tz, cons
 // ---------------------------------------------------------------------------------------------
 // shape blend: v_shaped[s] = (v_template (+ del_v[s])) + beta[s] @ shapedirs     (smal_torch.py:240-248)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_shape_blend(const float *__restrict__ vt, const float *__restrict__ sd,
-                              const float *__restrict__ beta, const float *__restrict__ del_v,
-                              float *__restrict__ v_shaped, int V3, int nB_used, int beta_stride) {
-    __shared__ float sbeta[SMIL_MAX_BETAS];
-    const int s = blockIdx.x;
-    if (threadIdx.x < nB_used) sbeta[threadIdx.x] = beta[(size_t)s * beta_stride + threadIdx.x];
-    __syncthreads();
-    const int e = blockIdx.y * blockDim.x + threadIdx.x;
-    if (e >= V3) return;
-    float acc = 0.f;
-    for (int k = 0; k < nB_used; ++k) acc += sbeta[k] * sd[(size_t)k * V3 + e];
-    float base = vt[e];
-    if (del_v) base += del_v[(size_t)s * V3 + e];
-    v_shaped[(size_t)s * V3 + e] = base + acc;
+// A workgroup owns a TILE of the 3V-vector (256 threads x SB_EPT elements) and a share of the frames: the tile's rows of shapedirs and of
+// the template are read ONCE into registers, after which every frame costs its betas (wave-uniform: scalar loads) and one coalesced
+// store per element - the kernel is the write stream of v_shaped (12 V bytes per frame) and nothing else.  Round 6: the first form - one
+// thread per (frame, element), every thread re-reading nB rows of shapedirs through L2 - ran at 1.3 TB/s and was the LARGEST kernel of the
+// LBS forward once betas are per frame (the reference's neural caller, smil_image_regressor.py:2663): 109 us of 330 on STICK, 426 of 780
+// on the mouse at 4 096 frames (profiles/r6_shape_blend.txt).  NB: register rows (>= nB_used); 0 = any nB, rows re-read per frame.
+#define SB_EPT 4
+template <int NB>
+__global__ void __launch_bounds__(256) k_shape_blend(const float *__restrict__ vt, const float *__restrict__ sd,
+                                                     const float *__restrict__ beta, const float *__restrict__ del_v,
+                                                     float *__restrict__ v_shaped, int V3, int nB_used, int beta_stride, int nS) {
+    const int e0 = blockIdx.x * (256 * SB_EPT) + threadIdx.x;
+    float base[SB_EPT], row[NB > 0 ? NB : 1][SB_EPT];
+#pragma unroll
+    for (int i = 0; i < SB_EPT; ++i) {
+        const int e = e0 + 256 * i;
+        base[i] = e < V3 ? vt[e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) row[k][i] = (k < nB_used && e < V3) ? sd[(size_t)k * V3 + e] : 0.f;
+    }
+    for (int s_ = blockIdx.y; s_ < nS; s_ += gridDim.y) {
+        const float *__restrict__ b = beta + (size_t)s_ * beta_stride;  // (beta_stride 0: one row shared by every frame)
+        float acc[SB_EPT];
+#pragma unroll
+        for (int i = 0; i < SB_EPT; ++i) acc[i] = 0.f;
+        if (NB > 0) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const float bk = k < nB_used ? b[k] : 0.f;
+#pragma unroll
+                for (int i = 0; i < SB_EPT; ++i) acc[i] += bk * row[k][i];
+            }
+        } else {
+            for (int k = 0; k < nB_used; ++k) {
+                const float bk = b[k];
+#pragma unroll
+                for (int i = 0; i < SB_EPT; ++i) { const int e = e0 + 256 * i; acc[i] += bk * (e < V3 ? sd[(size_t)k * V3 + e] : 0.f); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SB_EPT; ++i) {
+            const int e = e0 + 256 * i;
+            if (e >= V3) continue;
+            float v = base[i];
+            if (del_v) v += del_v[(size_t)s_ * V3 + e];
+            v_shaped[(size_t)s_ * V3 + e] = v + acc[i];
+        }
+    }
 }
 
 // rest joints: J = J_static or J_regressor^T v_shaped (CSR gather)               (smal_torch.py:257-264)
@@ -600,9 +634,16 @@ static int lbs_forward_impl(const SmilModel *m, const SmilLbsInputs *in, const S
     const int nS = (in->shared_beta && !in->del_v) ? 1 : B;
     const float *vt = in->v_template ? in->v_template : m->v_template;
     {
-        dim3 grid(nS, ceil_div(3 * V, 256));  // batch on x: gridDim.y stops at 65 535
-        hipLaunchKernelGGL(k_shape_blend, grid, dim3(256), 0, stream, vt, m->shapedirs, in->beta, in->del_v,
-                           out->v_shaped, 3 * V, in->nB_used, in->shared_beta ? 0 : in->nB_used);
+        // tiles of the 3V-vector on x, frames strided over y: as many blocks as keep every CU busy eight deep, no more (each block
+        // first loads its tile's rows of shapedirs)
+        const int tiles = ceil_div(3 * V, 256 * SB_EPT);
+        const dim3 grid(tiles, std::max(1, std::min(nS, ceil_div(device_cu_count() * 8, tiles))));
+        const int bstride = in->shared_beta ? 0 : in->nB_used;
+#define SB_LAUNCH(NB) hipLaunchKernelGGL(k_shape_blend<NB>, grid, dim3(256), 0, stream, vt, m->shapedirs, in->beta, in->del_v, out->v_shaped, 3 * V, in->nB_used, bstride, nS)
+        if (in->nB_used <= 8) SB_LAUNCH(8);
+        else if (in->nB_used <= 16) SB_LAUNCH(16);
+        else SB_LAUNCH(0);
+#undef SB_LAUNCH
         SMIL_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rest_joints, dim3(nS), dim3(1024), 0, stream,  // 16 waves: 3-4 joints each (latency of a single frame)

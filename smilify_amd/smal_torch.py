@@ -26,6 +26,8 @@ from . import engine, model_io
 
 
 class _LbsFunction(torch.autograd.Function):
+    _OUTPUTS = ("verts", "joints", "Rs", "v_shaped", "new_J")
+
     @staticmethod
     def forward(ctx, dm, flags, beta, theta, trans, logscale, btrans, del_v, v_template):
         dev = dm.device
@@ -38,7 +40,13 @@ class _LbsFunction(torch.autograd.Function):
             v_template=c(v_template), Rs_in=theta_c if rot_in else None, logscale_shared=flags["logscale_shared"],
             btrans_shared=flags["btrans_shared"], propagate_scaling=flags["propagate_scaling"],
             allow_limb_scaling=flags["allow_limb_scaling"])
-        ctx.dm, ctx.saved = dm, out
+        # The five RETURNED tensors go through save_for_backward: kept as plain attributes they close a cycle (output -> grad_fn -> ctx ->
+        # output) that crosses into C++ where Python's collector cannot follow it, and every call's (B,V,3) outputs stayed allocated
+        # for the life of the process (round 6: 1 GiB per call with the mouse at 4 096 frames).  Everything else is an intermediate no
+        # output refers to.
+        ctx.dm = dm
+        ctx.rest = {k: v for k, v in out.items() if k not in _LbsFunction._OUTPUTS}
+        ctx.save_for_backward(*(out[k] for k in _LbsFunction._OUTPUTS))
         ctx.has = (beta is not None and beta.shape[-1] > 0, not rot_in, trans is not None, logscale is not None, btrans is not None)
         ctx.rot_in = rot_in
         ctx.shared = (flags["logscale_shared"], flags["btrans_shared"])
@@ -53,7 +61,9 @@ class _LbsFunction(torch.autograd.Function):
         dv, dj, dR, dvs = cont(d_verts), cont(d_joints), cont(d_Rs), cont(d_vs)
         if dv is None and dj is None and dR is None and dvs is None:
             return (None,) * 9
-        g = engine.lbs_backward(ctx.dm, ctx.saved, dv, dj, need_beta=need[2] and ctx.has[0], need_theta=need[3] and ctx.has[1],
+        saved = dict(ctx.rest)
+        saved.update(zip(_LbsFunction._OUTPUTS, ctx.saved_tensors))
+        g = engine.lbs_backward(ctx.dm, saved, dv, dj, need_beta=need[2] and ctx.has[0], need_theta=need[3] and ctx.has[1],
                                 need_logscale=need[5] and ctx.has[3], need_btrans=need[6] and ctx.has[4],
                                 need_trans=need[4] and ctx.has[2], need_vshaped=need[7] or need[8], need_Rs=need[3] and ctx.rot_in,
                                 up_Rs=dR, up_v_shaped=dvs)

@@ -146,3 +146,38 @@ def test_gradients_flow_through_all_four_tensors_smal_returns(key, matrices, tab
                 continue
             assert got is not None, (which, k)
             _close(got, ref, 3e-4, (which, k))
+
+
+def test_repeated_calls_do_not_keep_their_outputs_alive(tables):
+    """A training loop calls ``SMAL.__call__`` + ``backward()`` thousands of times (the reference's neural caller): the (B,V,3) outputs
+    of a finished iteration must be released.  (Round 6: the autograd node kept its own outputs as plain attributes - a cycle through
+    C++ that Python's collector cannot see - and every call leaked them.)"""
+    import gc
+
+    from smilify_amd.smal_torch import SMAL
+
+    t = tables("stick")
+    smal = SMAL(DEV, tables=t)
+    B = 64
+    g = torch.Generator().manual_seed(0)
+    beta = (0.5 * torch.randn(B, t.nB, generator=g)).to(DEV).requires_grad_()
+    theta = (0.1 * torch.randn(B, t.J, 3, generator=g)).to(DEV).requires_grad_()
+    trans = torch.zeros(B, 3, device=DEV, requires_grad=True)
+
+    def step():
+        verts, joints, _, _ = smal(beta, theta, trans=trans)
+        (verts.sum() + joints.sum()).backward()
+        for p in (beta, theta, trans):
+            p.grad = None
+
+    for _ in range(3):
+        step()
+    gc.collect()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    for _ in range(10):
+        step()
+    gc.collect()
+    torch.cuda.synchronize()
+    grown = torch.cuda.memory_allocated() - before
+    assert grown < B * t.V * 3 * 4, f"{grown} bytes still allocated after ten more calls (one (B,V,3) output is {B * t.V * 3 * 4})"

@@ -608,11 +608,69 @@ class SMALFitter(nn.Module):
         scales = torch.from_numpy(np.mean(scale_list, axis=0)).float().to(self.device).reshape(1, -1, 3)
         self.log_beta_scales = nn.Parameter(scales, requires_grad=self.log_beta_scales.requires_grad)
 
-    def generate_visualization(self, image_exporter, *args, **kwargs):
-        """Collage / mesh export of the reference (fitter.py:373-517) is image I/O and out of scope for this build;
-        ``export_parameters`` provides the per-frame parameter dict it writes next to the images."""
-        raise NotImplementedError("generate_visualization (png/ply export) is not part of the MI355X fitting path; "
-                                  "use export_parameters(frame_id) for the per-frame parameter dict")
+    def generate_visualization(self, image_exporter, apply_UE_transform=False, img_idx=0, mesh_scale=None, epoch=None):
+        """Reference fitter.py:373-517, as far as this build goes: for every frame ``image_exporter.export(collage, batch_id,
+        global_id, img_parameters, verts, faces, img_idx, epoch=epoch)`` with the SAME per-frame parameter dict (what the reference
+        pickles as ``st{S}_ep{E}.pkl`` and ``load_checkpoint`` reads back), the same posed vertices (the ``.ply``) and a collage of the
+        same layout (target | render | overlay | silhouette agreement | view from behind).  The reference's driver calls this
+        every ``VIS_FREQUENCY`` epochs (optimize_to_joints.py:177-178), so the unchanged loop needs it to work.  What differs: the
+        colour / HardPhong shading (p3d_renderer.py render_texture=True) and the joint markers (SMALJointDrawer, cv2) are
+        visualisation code outside this build - the "render" panels show the soft silhouette in the mesh colour, without markers.
+        Frames are posed and rendered by the HIP kernels; the collage is assembled on the host."""
+        cfg, dev, views, S = self.config, self.device, self.views, self.image_size
+        J = self.smal_model.tables.J
+        faces_np = self.smal_model.faces.detach().cpu().numpy()
+        color = torch.tensor([c / 255.0 for c in getattr(cfg, "MESH_COLOR", [0, 172, 223])], dtype=torch.float32).view(1, 3, 1, 1)
+        rot = torch.tensor([[-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]], device=dev)  # 180 degrees about y (fitter.py:388)
+        cam_all = self.renderer.cameras
+        W = int(self.batch_size) if self.batch_size else self.num_images
+        try:
+            with torch.no_grad():
+                for j in range(0, self.num_images, W):
+                    rows = list(range(j, min(self.num_images, j + W)))
+                    idx = torch.tensor(rows, device=dev)
+                    n = len(rows)
+                    pick = lambda p_: (p_.detach() if p_.shape[0] == 1 else p_.detach().index_select(0, idx))  # noqa: E731
+                    theta = torch.cat([(self.global_rotation.detach().index_select(0, idx) * self.global_mask)[:, None],
+                                       self.joint_rotations.detach().index_select(0, idx) * self.rotation_mask], 1)
+                    trans = self.trans.detach().index_select(0, idx)
+                    verts, joints, _, _ = self.smal_model(self.betas.detach()[None].expand(n, -1), theta, betas_logscale=pick(self.log_beta_scales),
+                                                          betas_trans=pick(self.betas_trans), propagate_scaling=self.propagate_scaling)
+                    if apply_UE_transform:  # (the replicAnt convention: ten times larger about the root joint)
+                        root = joints[:, :1]
+                        verts, joints = (verts - root) * 10 + trans[:, None], (joints - root) * 10 + trans[:, None]
+                    elif mesh_scale is not None:
+                        sc = torch.as_tensor(mesh_scale, dtype=torch.float32, device=dev).reshape(-1, 1, 1)
+                        root = joints[:, :1]
+                        verts, joints = (verts - root) * sc + trans[:, None], (joints - root) * sc + trans[:, None]
+                    else:
+                        verts, joints = verts + trans[:, None], joints + trans[:, None]
+                    canon = joints[:, list(cfg.CANONICAL_MODEL_JOINTS)].contiguous()
+                    img_rows = (idx[:, None] * views + torch.arange(views, device=dev)[None]).reshape(-1)
+
+                    def table(t_, per_row):  # camera tables with one row per image follow the window; shared / per-view ones stay
+                        return t_ if t_ is None or t_.shape[0] != self.num_images * views else t_.index_select(0, img_rows)
+                    fov = self.fov.detach().reshape(-1)
+                    self.renderer.cameras = FoVCameras(table(cam_all.R, 9), table(cam_all.T, 3), table(fov, 1),
+                                                       table(cam_all.aspect_ratio, 1), cam_all.znear, cam_all.zfar)
+                    faces_b = self.smal_model.faces[None].expand(n, -1, -1)
+                    sil, _ = self.renderer(verts.contiguous(), canon, faces_b)
+                    centre = verts.mean(1, keepdim=True)
+                    sil_rev, _ = self.renderer(((verts - centre) @ rot.T).contiguous(), ((canon - centre) @ rot.T).contiguous(), faces_b)
+                    first = torch.arange(n, device=dev) * views  # a frame's first view stands for it
+                    sil = sil.reshape(n * views, 1, S, S).index_select(0, first).cpu()
+                    sil_rev = sil_rev.reshape(n * views, 1, S, S).index_select(0, first).cpu()
+                    take = (idx * views).cpu()
+                    rgb = self.rgb_imgs[take].float().cpu()
+                    target_sil = torch.zeros_like(sil) if (self.rgb_only or self.sil_imgs is None) else self.sil_imgs[take].float().cpu().reshape(n, 1, S, S)
+                    rendered = sil * color
+                    agreement = (1.0 - (target_sil - sil).abs()).expand_as(rgb)
+                    collage = torch.cat([rgb, rendered, 0.5 * rendered + 0.5 * rgb, agreement, sil_rev * color], dim=3).clamp(0.0, 1.0)
+                    for batch_id, global_id in enumerate(rows):
+                        image_exporter.export((collage[batch_id].permute(1, 2, 0).numpy() * 255.0).astype(np.uint8), batch_id, global_id,
+                                              self.export_parameters(global_id), verts, faces_np, img_idx, epoch=epoch)
+        finally:
+            self.renderer.cameras = cam_all
 
     def export_parameters(self, frame_id: int) -> Dict[str, np.ndarray]:
         """The per-frame dict the reference pickles (optimize_to_joints.py:48-63, fitter.py:241-261,507)."""

@@ -307,3 +307,52 @@ def test_forward_serves_an_epoch_from_one_evaluation(tables, frames, window):
             opt_a.step()
             opt_b.step()
         np.testing.assert_allclose(a.trans.detach().cpu().numpy(), b.trans.detach().cpu().numpy(), atol=2e-6)
+
+
+def test_generate_visualization_feeds_the_reference_exporter(tables):
+    """The reference's driver calls ``model.generate_visualization(image_exporter)`` every VIS_FREQUENCY epochs
+    (optimize_to_joints.py:177-178) and its ImageExporter pickles the parameter dict / writes the mesh it is handed
+    (:48-68): every frame is exported once, with the dict ``export_parameters`` builds (= what ``load_checkpoint`` reads back),
+    the posed vertices of its window and a (S, 5 S, 3) uint8 collage."""
+    from smilify_amd import engine, synthetic
+
+    t = tables("synthetic")
+    N, W, S = 5, 2, 40
+    model = synthetic.make_problem(t, N, 1, S, DEV, radius=2.2, seed=3, window=W)
+    calls = []
+
+    class Exporter:
+        stage_id, epoch_name = 1, "0"
+
+        def export(self, collage_np, batch_id, global_id, img_parameters, vertices, faces, img_idx=0, epoch=None):
+            calls.append((collage_np, batch_id, global_id, img_parameters, vertices[batch_id].cpu().numpy().copy(), faces, img_idx, epoch))
+
+    cams_before = model.renderer.cameras
+    model.generate_visualization(Exporter(), epoch=7)
+    assert model.renderer.cameras is cams_before
+    assert [c[2] for c in calls] == list(range(N)) and [c[1] for c in calls] == [0, 1, 0, 1, 0] and all(c[7] == 7 for c in calls)
+    lbs = engine.lbs_forward(model.device_model, model.betas.detach(), model._pose.detach().contiguous(), trans=model.trans.detach().contiguous(),
+                             logscale=model.log_beta_scales.detach().contiguous(), btrans=model.betas_trans.detach().contiguous(), shared_beta=True,
+                             trans_after_joints=True)
+    verts = lbs["verts"].cpu().numpy()  # (the fit iteration's own posed, translated vertices)
+    for collage, _, gid, params, v, faces, _, _ in calls:
+        assert collage.shape == (S, 5 * S, 3) and collage.dtype == np.uint8 and collage[:, S:2 * S].max() > 0  # the render panel shows the mesh
+        want = model.export_parameters(gid)
+        assert params.keys() == want.keys()
+        for k in want:
+            np.testing.assert_array_equal(params[k], want[k])
+        np.testing.assert_allclose(v, verts[gid], atol=2e-6)
+        assert faces.shape == (t.F, 3)
+    # ... and the reference-style epoch body still runs with the call inside it
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, betas=(0.5, 0.999))
+    for epoch in range(2):
+        opt.zero_grad()
+        acc = 0
+        for j in range(0, N, W):
+            loss, _ = model(list(range(j, min(N, j + W))), [10.0, 500.0, 1.0, 1.0, 100.0, 0.1], 1)
+            acc += loss.mean()
+        acc.backward()
+        opt.step()
+        if epoch % 1 == 0:
+            model.generate_visualization(Exporter())
+    assert len(calls) == 3 * N

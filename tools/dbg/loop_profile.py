@@ -32,10 +32,12 @@ def epoch(timed=False):
             T[k] = T.get(k, 0.0) + v
 for _ in range(5): epoch()
 torch.cuda.synchronize()
+print(f"memory after 5 epochs: {torch.cuda.memory_allocated() / 2**20:.1f} MiB")
 E = 50
 t0 = time.perf_counter()
 for _ in range(E): epoch(True)
 torch.cuda.synchronize()
+print(f"memory after {E} more epochs: {torch.cuda.memory_allocated() / 2**20:.1f} MiB")
 print(f"{1e3 * (time.perf_counter() - t0) / E:.3f} ms per epoch;", {k: round(1e3 * v / E, 3) for k, v in T.items()})
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): epoch()

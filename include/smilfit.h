@@ -53,7 +53,10 @@ int smil_model_create(const SmilModelDesc *desc, SmilModel **out);
 void smil_model_destroy(SmilModel *m);
 int smil_model_dims(const SmilModel *m, int32_t dims[4]); /* V,F,J,nB */
 const char *smil_last_error(void);
-const char *smil_version(void);
+const char *smil_version(void);   /* "smilfit 0.3 (gfx950)".  0.3 = the layout of rounds 5 - 6: SmilLbsGrads carries clip_depth in front of
+                                    * beta_rows (which must hold 2 * B * nB_used + 16 floats), SmilRasterSettings ends in {tie_rule, clip_depth,
+                                    * image0}, smil_window_terms exists.  Callers zero-initialise every struct they pass and rebuild against
+                                    * this header when the number changes: there is no binary compatibility across it. */
 
 /* ------------------------------------------------------------------------------------------
  * Linear blend skinning.  Replaces SMAL.__call__ (smal_torch.py:198-370) including

@@ -260,6 +260,48 @@ def time_reference_loop(key, dev, epochs=20, warmup=3, fit_step_ms=None):
     return out
 
 
+def time_smal_call(key, dev, frames=4096, reps=30):
+    """The drop-in ``SMAL`` module on its own, as the reference's neural caller uses it (one beta row per frame,
+    smil_image_regressor.py:2663): ``SMAL.__call__`` forward + ``backward()`` through verts and joints at ``frames`` frames.  Bytes by
+    SURVEY.md 8(d)'s LBS figure without the Adam part (24V + 240J per frame: every tensor the API exposes written / read once)."""
+    from smilify_amd import model_io
+    from smilify_amd.smal_torch import SMAL
+
+    wl = WORKLOADS[key]
+    t = model_io.load_model(os.path.join(REPO, "data", "models", wl["model"] + ".npz"))
+    smal = SMAL(dev, tables=t)
+    g = torch.Generator().manual_seed(1)
+    beta = (0.5 * torch.randn(frames, t.nB, generator=g)).to(dev).requires_grad_()
+    theta = (0.15 * torch.randn(frames, t.J, 3, generator=g)).to(dev).requires_grad_()
+    trans = (0.05 * torch.randn(frames, 3, generator=g)).to(dev).requires_grad_()
+    ls = (0.05 * torch.randn(frames, t.J, 3, generator=g)).to(dev).requires_grad_()
+    gv = torch.randn(frames, t.V, 3, generator=g).to(dev)
+    gj = torch.randn(frames, t.J, 3, generator=g).to(dev)
+
+    def call():
+        verts, joints, _, _ = smal(beta, theta, trans=trans, betas_logscale=ls)
+        torch.autograd.backward([verts, joints], [gv, gj])
+        for p_ in (beta, theta, trans, ls):
+            p_.grad = None
+
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    ms = 1000.0 * (time.perf_counter() - t0) / reps
+    alg = frames * (24 * t.V + 240 * t.J)
+    out = {"workload": f"SMAL.__call__ forward + backward, {wl['model']}, {frames} frames, one beta row per frame", "frames": frames, "ms_per_call": ms,
+           "frames_per_s": frames / (ms * 1e-3), "algorithmic_bytes": alg, "frac": (alg / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+           "memory_growth_bytes": int(torch.cuda.memory_allocated() - mem0)}
+    del smal, beta, theta, trans, ls, gv, gj
+    torch.cuda.empty_cache()
+    return out
+
+
 def relaunch_multi_gpu(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD
     process (never exec: nothing here has touched the GPU yet, and it stays that way in this process), relay its output
@@ -482,6 +524,9 @@ def main():
             others["cfg2b_tie_rule_reference_queue"] = time_other_workload(args.workload, dev, steps=40, frames=args.frames, tie_rule="reference_queue")
             # the reference's unchanged driver loop (the drop-in boundary) beside fit_step on the same configuration
             others["reference_loop_cfg2"] = time_reference_loop("cfg2", dev, epochs=100, fit_step_ms=others["cfg2"]["ms_per_step"])
+            # the drop-in SMAL module on its own (the neural caller's shape): LBS forward + backward with a beta row per frame
+            others["smal_call_stick_4096"] = time_smal_call("cfg2b", dev)
+            others["smal_call_mouse_4096"] = time_smal_call("cfg3", dev)
             out["other_workloads"] = others
         print(json.dumps(out), flush=True)
         if parity is not None and not parity["ok"]:

@@ -274,8 +274,8 @@ def _reference_epoch(model, N, W, weights, w_temp, window_weight=None):
     return per_window, terms, float(acc), grads
 
 
-@pytest.mark.parametrize("frames,window", [(7, 2), (8, 4)])
-def test_forward_serves_an_epoch_from_one_evaluation(tables, frames, window):
+@pytest.mark.parametrize("frames,window,views", [(7, 2, 1), (8, 4, 1), (6, 2, 2)])
+def test_forward_serves_an_epoch_from_one_evaluation(tables, frames, window, views):
     """The per-window forward() calls of the reference's loop are answered from ONE whole-batch evaluation (SMALFitter._epoch_window):
     same window losses, same terms, same parameter gradients as the window-by-window evaluation - also when the windows are weighted
     differently or one is left out (the correction path of _EpochEval.backward), and a parameter update starts a new epoch."""
@@ -285,8 +285,8 @@ def test_forward_serves_an_epoch_from_one_evaluation(tables, frames, window):
     weights, w_temp = [10.0, 500.0, 1.0, 1.0, 100.0, 0.1], 100.0
     n_win = (frames + window - 1) // window
     for ww in (None, [1.0 + 0.5 * k for k in range(n_win)], [0.0] + [1.0] * (n_win - 1)):
-        a = synthetic.make_problem(t, frames, 1, 40, DEV, radius=2.2, seed=5, window=window)
-        b = synthetic.make_problem(t, frames, 1, 40, DEV, radius=2.2, seed=5, window=window)
+        a = synthetic.make_problem(t, frames, views, 40, DEV, radius=2.2, seed=5, window=window)
+        b = synthetic.make_problem(t, frames, views, 40, DEV, radius=2.2, seed=5, window=window)
         b.epoch_cache = False
         opt_a = torch.optim.Adam(a.parameters(), lr=5e-3, betas=(0.5, 0.999))
         opt_b = torch.optim.Adam(b.parameters(), lr=5e-3, betas=(0.5, 0.999))

@@ -5,7 +5,7 @@
 #   exp / expns with SMIL_STOP=1 - the tile kernel cut off after pass 1, with / without the record stores
 cd "$GRAFT_REPO_ROOT"; L=$PWD/smilify_amd/lib; mkdir -p gpurun_out/r6
 {
-bash tools/dbg/ab.sh main rec8 p3na
+bash tools/dbg/ab.sh main rec8 p3na   # (variants built from tools/dbg/r6/ablations.patch applied to raster.hip)
 for rep in 1 2; do for v in exp expns; do
   echo "== $v stop=1 STICK: $(SMILFIT_LIB=$L/libsmilfit_$v.so SMIL_STOP=1 python tools/raster_probe.py --frames 4096 --quick --reps 5 2>&1 | grep images)"
 done; done

@@ -61,6 +61,18 @@ class _Prior:
         self.use_ind_tch = torch.from_numpy(self.use_ind).float().to(device)
 
 
+class _WindowLoss(torch.Tensor):
+    """The scalar loss ``forward`` returns.  The reference's driver does ``acc_loss += loss.mean()`` once per window
+    (optimize_to_joints.py:156): on a 0-dim tensor ``mean()`` is the identity, but as a torch op it is a kernel launch and an autograd
+    node per window, forward and backward - a quarter of the host time of an epoch of the loop at 52 windows.  Here it returns the tensor
+    itself (same value, same gradient); every other operation gives a plain ``torch.Tensor`` at plain-tensor cost."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def mean(self, *args, **kwargs):
+        return self
+
+
 class _FitWindow(torch.autograd.Function):
     """(loss, objs) of one window; gradients were computed by the kernels in forward."""
 
@@ -69,7 +81,7 @@ class _FitWindow(torch.autograd.Function):
         objs, grads = fitter._loss_and_grads(frames, weights, w_temp)
         ctx.grads = grads
         total = objs[:9].sum()
-        return total, objs.clone()
+        return total.as_subclass(_WindowLoss), objs.clone()
 
     @staticmethod
     def backward(ctx, g_total, _g_objs):
@@ -97,7 +109,7 @@ class _EpochEval(torch.autograd.Function):
         ctx.key = fitter._state_key(tuple(weights))
         ctx.set_materialize_grads(False)  # (a window nobody used arrives as None, not as a zero tensor)
         ctx.mark_non_differentiable(objs_win)
-        return (*objs_win.sum(1).unbind(0), objs_win)
+        return (*(t_.as_subclass(_WindowLoss) for t_ in objs_win.sum(1).unbind(0)), objs_win)
 
     @staticmethod
     def backward(ctx, *upstream):

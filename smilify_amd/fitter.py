@@ -550,7 +550,7 @@ class SMALFitter(nn.Module):
                 id(fv), fv._version, fv.requires_grad, id(tv), tv._version, id(tj), tj._version, id(si), None if si is None else si._version,
                 id(canon), len(canon), gm.data_ptr(), gm._version, rm.data_ptr(), rm._version, R.data_ptr(), R._version, T.data_ptr(), T._version,
                 None if asp is None else (asp.data_ptr(), asp._version), self.propagate_scaling, self.rgb_only,
-                bytes(self.renderer.raster_settings))
+                bytes(self.renderer.raster_settings), torch.is_grad_enabled())  # (an evaluation under no_grad carries no graph)
 
     def invalidate_epoch(self):
         """Forget the cached epoch (after editing a parameter through ``.data`` or any other route autograd's version counters miss)."""

@@ -307,6 +307,14 @@ def test_forward_serves_an_epoch_from_one_evaluation(tables, frames, window, vie
             opt_a.step()
             opt_b.step()
         np.testing.assert_allclose(a.trans.detach().cpu().numpy(), b.trans.detach().cpu().numpy(), atol=2e-6)
+    # windows evaluated under no_grad (logging) must not be handed to a later differentiable call of the same parameter state
+    with torch.no_grad():
+        for j in range(0, frames, window):
+            a(list(range(j, min(frames, j + window))), weights, 1)
+    loss, _ = a(list(range(0, window)), weights, 1)
+    loss2, _ = a(list(range(window, min(frames, 2 * window))), weights, 1)
+    assert loss.requires_grad and loss2.requires_grad
+    (loss.mean() + loss2.mean()).backward()
 
 
 def test_generate_visualization_feeds_the_reference_exporter(tables):

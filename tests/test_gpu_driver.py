@@ -364,3 +364,42 @@ def test_generate_visualization_feeds_the_reference_exporter(tables):
         if epoch % 1 == 0:
             model.generate_visualization(Exporter())
     assert len(calls) == 3 * N
+
+
+def test_epoch_served_forward_with_a_joint_subset_and_frozen_parameters(tables):
+    """``smil_window_terms`` and the cached epoch under the reference's stage-0 conditions: a subset of annotated joints
+    (config.CANONICAL_MODEL_JOINTS), visibility masked in place, joint rotations / betas / scales frozen, zero silhouette weight
+    (optimize_to_joints.py:129-138, column 0 of OPT_WEIGHTS) - window losses, terms and gradients as the window-by-window path."""
+    from smilify_amd import synthetic
+
+    t = tables("synthetic")
+    N, W = 6, 3
+    weights, w_temp = [25.0, 0.0, 0.0, 0.0, 0.0, 0.0], 500.0
+    fits = []
+    for cache in (True, False):
+        f = synthetic.make_problem(t, N, 1, 40, DEV, radius=2.2, seed=9, window=W)
+        f.epoch_cache = cache
+        canon = [0, 2, 5, 7]
+        f.config.CANONICAL_MODEL_JOINTS = canon
+        f.target_joints = f.target_joints[:, canon].contiguous()
+        f.target_visibility = f.target_visibility[:, canon].contiguous()
+        f.target_visibility[:, 1] = 0  # in place, as the driver masks the non-torso joints
+        for p in (f.joint_rotations, f.betas, f.log_beta_scales):
+            p.requires_grad = False
+        fits.append(f)
+    a, b = fits
+    for epoch in range(2):
+        la, ta, _, ga = _reference_epoch(a, N, W, weights, w_temp)
+        lb, tb, _, gb = _reference_epoch(b, N, W, weights, w_temp)
+        np.testing.assert_allclose(la, lb, rtol=2e-5)
+        for da, db in zip(ta, tb):
+            assert da.keys() == db.keys() == {"joint"}
+            np.testing.assert_allclose(da["joint"], db["joint"], rtol=2e-5)
+        for n in gb:
+            assert (ga[n] is None) == (gb[n] is None), n
+            if gb[n] is not None:
+                assert float((ga[n] - gb[n]).abs().max()) <= 2e-4 * (float(gb[n].abs().max()) + 1e-12), (n, epoch)
+        with torch.no_grad():
+            for f in (a, b):
+                f.trans += 0.01  # an in-place parameter edit starts a new epoch for the cache (version counter)
+    assert a._epoch is not None and a._epoch["served"] == N // W
